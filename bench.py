@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — correspondence-pairs/s and ICP iterations/s of the MI355X alignment engine.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by torch.distributed.run,
+one rank per GPU).  A *step* is one ICP iteration: source transform + exact brute-force NN scan +
+covariance accumulation + (N > 1: one RCCL all-reduce of 17 doubles) + host Kabsch/convergence, all
+through `mi355_icp_align`.  Clouds are uploaded before the timed region (inputs resident in HBM).
+
+Workload (BASELINE.json): N = 1 is config[2] "1M<->1M synthetic scene, 1 MI355X"; N > 1 keeps one
+2^20-point source slab per GPU against the replicated 2^20-point target (weak scaling), so N = 8 is
+config[4] "8M<->1M, source slab-sharded across 8 GPUs, per-iteration RCCL all-reduce over xGMI".
+A *pair* is one (source point, target point) distance evaluation: pairs = Ns * Nt * iterations
+(SURVEY.md 8d); `correspondences_per_s` (= Ns * iterations / s) is reported next to it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (vector)" (= f32 MFMA dense peak)
+HBM_PEAK_GBS = 8000.0             # same guide, HBM3E spec
+FLOP_PER_PAIR = 8                 # 3 sub + 3 mul + 2 add (SURVEY.md 8d FLOP model; the min is not counted)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-source", type=int, default=1 << 20, help="source points PER GPU")
+    ap.add_argument("--n-target", type=int, default=1 << 20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=3)
+    ap.add_argument("--collective", choices=["native", "torch"], default="native",
+                    help="N > 1: RCCL all-reduce issued inside the engine (native) or by torch.distributed")
+    ap.add_argument("--force-dist", action="store_true", help="exercise the distributed code path even at N = 1")
+    return ap.parse_args()
+
+
+def cpu_baseline(src, tgt, iters):
+    """CPU restatement of point-to-point ICP (KD-tree), timed on this host: oracle/icp_oracle.c.
+    Never labelled PCL/OpenCV: neither exists here."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as ora
+    threads = ora.max_threads()
+    p = ora.params(max_iterations=iters)
+    t0 = time.perf_counter()
+    r = ora.icp(src, tgt, np.eye(4), p, use_kdtree=True, nthreads=threads)
+    dt = time.perf_counter() - t0
+    pairs = float(src.shape[0]) * float(tgt.shape[0]) * r["iterations"]
+    return {
+        "value": pairs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+        "iters_per_s": r["iterations"] / dt,
+        "sample": f"{r['iterations']} ICP iterations of the same {src.shape[0]}x{tgt.shape[0]} workload incl. KD-tree build, "
+                  f"exact KD-tree NN (pairs counted as Ns*Nt per iteration, i.e. brute-force-equivalent), {dt:.2f} s",
+        "pose": r["pose"],
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist_mode = world > 1 or a.force_dist
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch = dist = None
+    if dist_mode:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch  # loads the HIP runtime first so the engine binds to the same one
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    import pose_estimation_amd as pa
+    from pose_estimation_amd import distributed as pd
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth_twin as st  # seeds / named configurations only
+
+    ns_local, nt = a.n_source, a.n_target
+    ns_total = ns_local * world
+    T = st.perturbation(-1)
+    tgt = pa.synth_cloud(st.TARGET_SEED, nt)
+    begin, count = pa.slab_range(ns_total, rank, world)
+    src = pa.synth_cloud(st.SOURCE_SEED, count, first_index=begin, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T)
+
+    eng = pa.IcpEngine(local_rank)
+    t_up = time.perf_counter()
+    eng.set_targets([tgt])
+    eng.set_sources([src])
+    upload_s = time.perf_counter() - t_up
+
+    collective = "none"
+    if dist_mode:
+        if a.collective == "native":
+            try:
+                pd.attach_native_comm(eng)
+                collective = "rccl-native"
+            except Exception as e:  # keep the run alive: same path with torch issuing the all-reduce
+                print(f"[rank {rank}] native RCCL attach failed ({e}); falling back to torch.distributed", file=sys.stderr)
+                collective = "torch.distributed"
+        else:
+            collective = "torch.distributed"
+        flag = torch.tensor([1 if collective == "rccl-native" else 0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks must agree
+        if flag.item() == 0 and collective == "rccl-native":
+            eng.comm_detach()
+            collective = "torch.distributed"
+
+    def run(iters, profile):
+        p = pa.default_params(max_iterations=iters, flags=(pa._lib.FLAG_PROFILE if profile else 0))
+        if collective == "torch.distributed":
+            return pd.align_external_collective(pd.engine_pass(eng, [0], [0]), pd.torch_allreduce(device="cuda"),
+                                                np.eye(4)[None], p)
+        return eng.align(np.eye(4)[None], p)
+
+    def fence():
+        if dist_mode:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if a.warmup > 0:
+        run(a.warmup, False)
+    eng.reset_profile()
+    fence()
+    t0 = time.perf_counter()
+    res = run(a.steps, True)   # align() returns after its stream has drained
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist_mode:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert int(res.iterations[0]) == a.steps and int(res.status[0]) == 0, (res.iterations, res.status)
+
+    prof = eng.profile()
+    if rank == 0:
+        pairs_step = float(ns_total) * float(nt)
+        scan_ms = prof.nn_scan_ms / max(prof.nn_scan_launches, 1)
+        pairs_launch = float(count) * float(nt)
+        alg_bytes = 12.0 * count + 12.0 * nt + 8.0 * count   # read both clouds once, write index + d2
+        out = {
+            "metric": "correspondence_pairs_per_sec", "value": pairs_step * a.steps / elapsed, "unit": "pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "icp_iters_per_sec": a.steps / elapsed,
+            "correspondences_per_sec": float(ns_total) * a.steps / elapsed,
+            "config": {"workload": f"{ns_total}x{nt} point-to-point ICP, exact brute-force NN "
+                                   f"({'BASELINE config[2] 1M<->1M' if world == 1 else 'source slab-sharded, ' + str(ns_local) + ' pts/GPU, target replicated'})",
+                       "n_source_total": ns_total, "n_target": nt, "source_points_per_gpu": ns_local,
+                       "collective": collective, "pair_definition": "one (source,target) distance evaluation: Ns*Nt*iterations"},
+            "roofline": {
+                "bound": "valu", "kernel": "nn_scan_kernel",
+                "achieved": FLOP_PER_PAIR * pairs_launch / (scan_ms * 1e-3) / 1e12, "peak": FP32_VECTOR_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": FLOP_PER_PAIR * pairs_launch / (scan_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                "traffic": None, "avg_launch_ms": scan_ms, "launches": int(prof.nn_scan_launches),
+                "note": "FP32 vector ALU bound (8 FLOP/pair, no FMA allowed by the bit-exact contract, so 9 issue slots "
+                        "per 8 FLOP: attainable ceiling is 8/18 = 44% of the FMA-counted 157.3 TFLOP/s peak); DESIGN.md",
+            },
+            "roofline_hbm": {
+                "bound": "hbm", "kernel": "nn_scan_kernel", "achieved": alg_bytes / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": alg_bytes / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "north_star asks for the HBM figure; the scan is compute-bound by ~4 orders of magnitude (DESIGN.md)",
+            },
+            "kernels_ms_per_step": {"nn_scan": scan_ms, "resolve_accumulate": prof.resolve_ms / max(prof.resolve_launches, 1),
+                                    "final_reduce": prof.reduce_ms / max(prof.reduce_launches, 1)},
+            "upload_s": upload_s, "device": eng.device_info()["name"],
+            "final_pose_error_vs_truth": float(np.linalg.norm(res.poses[0] - np.linalg.inv(T))),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            cb = cpu_baseline(src, tgt, a.cpu_baseline_iters)
+            cpu_pose = cb.pop("pose")
+            if a.cpu_baseline_iters == a.steps:
+                out["pose_vs_cpu_frobenius"] = float(np.linalg.norm(res.poses[0] - cpu_pose))
+            out["cpu_baseline"] = cb
+        print(json.dumps(out))
+    if dist_mode:
+        if collective == "rccl-native":
+            eng.comm_detach()
+        eng.close()
+        dist.destroy_process_group()
+    else:
+        eng.close()
+
+
+if __name__ == "__main__":
+    main()

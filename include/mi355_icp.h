@@ -1,0 +1,244 @@
+/*
+ * mi355_icp.h — C-ABI of the MI355X-native rigid point-cloud alignment engine.
+ *
+ * This is the drop-in boundary for ONE path of yumi-crew/pose_estimation: the ICP
+ * pose refinement that OpenCVSurfaceMatch::find_object_in_scene runs through
+ *     cv::ppf_match_3d::ICP icp(250, 0.005f, 2.5f, 8);        (reference
+ *     icp.registerModelToScene(model, scene, poses);           pose_estimation/src/opencv_surface_match.cpp:85,94)
+ * Each entry point below names the reference interface it replaces.  Plain
+ * pointers and sizes only: no OpenCV, ROS, torch or C++ types cross this line,
+ * no exception crosses it either (integer status + mi355_icp_last_error()).
+ *
+ * Vocabulary follows the reference: the *scene* is the TARGET cloud (searched),
+ * the *model* is the SOURCE cloud (moved); a pose is a row-major 4x4 double
+ * matrix taking model coordinates to scene coordinates (cv::Matx44d,
+ * Pose3D::pose); a 7-float pose is {x,y,z,qx,qy,qz,qw}
+ * (reference pose_estimation/include/pose_estimation.hpp:83-88).
+ *
+ * All compute entry points run on the GPU (gfx950).  There is no CPU fallback:
+ * without a usable HIP device mi355_icp_create() fails with
+ * MI355_ICP_ERR_NO_DEVICE.  Entry points marked [host] are pure host
+ * arithmetic (the 3x3 SVD / convergence / pose packing the design keeps on the
+ * CPU) and work without a GPU.
+ */
+#ifndef MI355_ICP_H
+#define MI355_ICP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_ICP_ABI_VERSION 1
+
+/* Number of double-precision scalars one correspondence pass reduces to.
+ * Layout (all sums run over the ACCEPTED correspondences (s0_i, t_j(i))):
+ *   [0]      n            number of accepted pairs
+ *   [1..3]   sum s0       untransformed source (model) point
+ *   [4..6]   sum t        matched target (scene) point
+ *   [7..15]  sum s0 t^T   row-major 3x3, row = source component, col = target component
+ *   [16]     sum d2       float32 squared distance of each accepted pair
+ * [4..15] are the "12 covariance/centroid scalars" of the design brief; [0..3]
+ * and [16] are the bookkeeping the convergence test and rejection need.  This
+ * block is what crosses xGMI in the per-iteration RCCL all-reduce. */
+#define MI355_ICP_NSUMS 17
+
+typedef enum mi355_icp_status {
+  MI355_ICP_OK = 0,
+  MI355_ICP_ERR_INVALID_ARGUMENT = 1,
+  MI355_ICP_ERR_NO_DEVICE = 2,        /* no HIP device / HIP runtime failure at create */
+  MI355_ICP_ERR_HIP = 3,              /* a HIP call failed; see mi355_icp_last_error */
+  MI355_ICP_ERR_NONFINITE_INPUT = 4,  /* NaN/Inf in an uploaded cloud or pose (the reference strips NaNs
+                                         before this path: pose_estimation.cpp:248) */
+  MI355_ICP_ERR_TOO_FEW_PAIRS = 5,    /* < 3 accepted correspondences: pose left unrefined */
+  MI355_ICP_ERR_NUMERIC = 6,          /* non-finite sums / degenerate solve */
+  MI355_ICP_ERR_COMM = 7,             /* RCCL failure or RCCL not loadable */
+  MI355_ICP_ERR_INTERNAL = 8
+} mi355_icp_status;
+
+typedef struct mi355_icp_ctx mi355_icp_ctx; /* opaque; one per OpenCVSurfaceMatch instance
+                                               (reference pose_estimation.hpp:161) */
+
+/* Alignment parameters.  The numeric definition (exact float32 NN, double sums,
+ * Kabsch) is fixed; these only steer the iteration. */
+typedef struct mi355_icp_params {
+  int32_t max_iterations;              /* >= 1.  Reference call site passes 250 (opencv_surface_match.cpp:85) */
+  float   max_correspondence_distance; /* pairs with d2 > this^2 (float32) are rejected; <= 0 => keep all */
+  double  transformation_epsilon;      /* criterion A: converged when |dt|^2 <= this AND 1-cos(dtheta) <= rotation_epsilon
+                                          (incremental transform of one iteration); <= 0 disables A */
+  double  rotation_epsilon;            /* used with criterion A */
+  double  relative_mse_epsilon;        /* criterion B: converged when |mse_k - mse_{k-1}| <= this * mse_{k-1};
+                                          <= 0 disables B.  Reference passes tolerance 0.005 (same call site) */
+  int32_t flags;                       /* MI355_ICP_FLAG_* */
+} mi355_icp_params;
+
+#define MI355_ICP_FLAG_PROFILE 1  /* bracket every kernel launch with HIP events (see mi355_icp_get_profile) */
+
+/* Kernel timing collected when MI355_ICP_FLAG_PROFILE is set; cumulative since
+ * the last mi355_icp_reset_profile(). */
+typedef struct mi355_icp_profile {
+  double   nn_scan_ms;       /* brute-force NN scan kernel (the dominant kernel) */
+  double   resolve_ms;       /* index resolve + covariance accumulation kernel */
+  double   reduce_ms;        /* fixed-order final reduction kernel */
+  uint64_t nn_scan_launches;
+  uint64_t resolve_launches;
+  uint64_t reduce_launches;
+  double   pairs_evaluated;  /* sum over nn_scan launches of Ns*Nt actually scanned */
+  uint64_t iterations;       /* ICP iterations (correspondence passes) executed */
+} mi355_icp_profile;
+
+/* ---- lifetime ------------------------------------------------------------ */
+
+unsigned mi355_icp_abi_version(void); /* [host] */
+
+/* Creates an engine bound to HIP device `device_id` with its own stream.
+ * Replaces: construction of cv::ppf_match_3d::ICP (opencv_surface_match.cpp:85). */
+int mi355_icp_create(int device_id, mi355_icp_ctx** out);
+void mi355_icp_destroy(mi355_icp_ctx* ctx);
+
+/* Last error text of this context (never NULL; "" if none).  With ctx == NULL
+ * returns the text of the last failed mi355_icp_create on this thread. */
+const char* mi355_icp_last_error(const mi355_icp_ctx* ctx); /* [host] */
+
+/* Fills the defaults of the design: 50 iterations, no rejection, criterion A
+ * off, criterion B 1e-9 off by default (<=0).  [host] */
+void mi355_icp_default_params(mi355_icp_params* p);
+
+/* Maps the reference's constructor arguments ICP(iterations, tolerance,
+ * rejectionScale, numLevels) (opencv_surface_match.cpp:85) onto params.
+ * iterations -> max_iterations, tolerance -> relative_mse_epsilon.
+ * rejectionScale and numLevels belong to the point-to-plane/pyramid mode
+ *  and are accepted but not used by this point-to-point
+ * engine; returns MI355_ICP_OK.  [host] */
+int mi355_icp_params_from_reference(int iterations, float tolerance, float rejection_scale, int num_levels,
+                                    mi355_icp_params* p);
+
+/* ---- clouds -------------------------------------------------------------- */
+
+/* Uploads `n_clouds` target (scene) clouds, replacing any previous targets.
+ * xyz[c] points at rows of >= 3 float32 (x,y,z first) `stride_bytes` apart: 12
+ * for the M x 3 scene (reference pose_estimation.cpp:263-276), 24 for M x 6
+ * with normals (opencv_surface_match.cpp:57-59).  The library copies and
+ * re-lays the data out as SoA on the device; the caller's buffer may be freed
+ * on return.  Replaces: the `scene` argument of registerModelToScene. */
+int mi355_icp_set_targets(mi355_icp_ctx* ctx, int n_clouds, const float* const* xyz, const size_t* n_points,
+                          size_t stride_bytes);
+
+/* Same for source (model) clouds; these persist across requests like
+ * OpenCVSurfaceMatch::models_ (opencv_surface_match.hpp:45).  Replaces: the
+ * `model` argument of registerModelToScene.
+ * For slab-sharded multi-GPU runs each rank uploads only its slab of the
+ * source (see mi355_icp_slab_range). */
+int mi355_icp_set_sources(mi355_icp_ctx* ctx, int n_clouds, const float* const* xyz, const size_t* n_points,
+                          size_t stride_bytes);
+
+/* Contiguous slab [begin, begin+count) of `n` points owned by `rank` of
+ * `n_ranks` (sizes differ by at most one, lower ranks get the extra).  [host] */
+int mi355_icp_slab_range(size_t n, int rank, int n_ranks, size_t* begin, size_t* count);
+
+/* ---- alignment ----------------------------------------------------------- */
+
+/* Refines `n_jobs` poses in one batched call.  Job k aligns source cloud
+ * source_ids[k] onto target cloud target_ids[k] starting from the row-major
+ * 4x4 double pose init_poses[16*k..] (model -> scene).  The reference batches
+ * <= 6 candidate poses of one model against one scene
+ * (opencv_surface_match.cpp:89-94); any mix of clouds is allowed here.
+ *
+ * Outputs (caller-allocated, may be NULL to skip):
+ *   out_poses      16*n_jobs doubles, refined pose  (Pose3D::pose)
+ *   out_residual   n_jobs doubles, RMS correspondence distance of the last
+ *                  correspondence pass               (Pose3D::residual)
+ *   out_iterations n_jobs ints, correspondence passes executed
+ *   out_status     n_jobs ints: MI355_ICP_OK (converged or ran max_iterations;
+ *                  see out_converged), MI355_ICP_ERR_TOO_FEW_PAIRS or
+ *                  MI355_ICP_ERR_NUMERIC, in which case out_poses[k] is the
+ *                  last valid pose (the initial pose if the first pass failed):
+ *                  "leave the candidate unrefined", matching how the reference
+ *                  swallows exceptions (opencv_surface_match.cpp:144-147)
+ *   out_converged  n_jobs ints, 1 if criterion A or B fired
+ * Returns MI355_ICP_OK unless the call as a whole could not run.
+ * With a communicator attached every rank must make the same call (same jobs,
+ * same poses); sums are all-reduced so every rank returns identical poses.
+ * Replaces: ICP::registerModelToScene(model, scene, poses). */
+int mi355_icp_align(mi355_icp_ctx* ctx, int n_jobs, const int* source_ids, const int* target_ids,
+                    const double* init_poses, const mi355_icp_params* params, double* out_poses,
+                    double* out_residual, int* out_iterations, int* out_status, int* out_converged);
+
+/* One correspondence pass (no solve), for parity checks and for drivers that
+ * run their own collective.  For each job: transform the source by the float32
+ * rounding of poses[16*k..], exact 1-NN, accumulate.
+ *   out_index   concatenated over jobs, source-cloud order: int32 target index  (may be NULL)
+ *   out_dist2   same shape: float32 squared distance                         (may be NULL)
+ *   out_sums    MI355_ICP_NSUMS * n_jobs doubles, LOCAL to this rank (never all-reduced)
+ * max_correspondence_distance as in params (<= 0 keeps all). */
+int mi355_icp_correspond(mi355_icp_ctx* ctx, int n_jobs, const int* source_ids, const int* target_ids,
+                         const double* poses, float max_correspondence_distance, int32_t* out_index,
+                         float* out_dist2, double* out_sums);
+
+/* ---- host arithmetic (no GPU needed) ------------------------------------- */
+
+/* Kabsch: the rigid transform minimising sum |R s0 + t - t_j|^2 over the pairs
+ * summarised by `sums` (3x3 SVD in double, reflection fixed).  Writes a
+ * row-major 4x4.  Returns MI355_ICP_ERR_TOO_FEW_PAIRS if n < 3,
+ * MI355_ICP_ERR_NUMERIC on non-finite input.  [host] */
+int mi355_icp_solve_rigid(const double sums[MI355_ICP_NSUMS], double out_pose[16]);
+
+/* One step of the host iteration controller used by mi355_icp_align (exposed
+ * so an external driver - e.g. one all-reducing `sums` itself - follows the
+ * identical rule).  `iteration` is the 0-based index of the pass that produced
+ * `sums`; `pose` is the pose that pass was evaluated under and is overwritten
+ * with the new pose; `prev_mse` carries mse_{k-1} (ignored when iteration==0)
+ * and is overwritten with mse_k; *out_done = 1 when iteration+1 reached
+ * max_iterations or a criterion fired, *out_converged = 1 only for the latter.
+ * On a non-OK return pose is left untouched.  [host] */
+int mi355_icp_host_update(const mi355_icp_params* params, const double sums[MI355_ICP_NSUMS], int iteration,
+                          double pose[16], double* prev_mse, int* out_done, int* out_converged);
+
+/* Row-major 4x4 pose -> 7 floats {x,y,z,qx,qy,qz,qw} using the reference's own
+ * matrix->quaternion formula (chessboard_pose_estimator.cpp:196-207).
+ * reference_packing != 0 reproduces the packing defect of
+ * opencv_surface_match.cpp:133-142 byte for byte (out[5] left 0, out[6] = qw);
+ * 0 gives the intended full quaternion.  [host] */
+int mi355_icp_pose_to_pose7(const double pose[16], float out7[7], int reference_packing);
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) ---------------------- */
+
+#define MI355_ICP_UNIQUE_ID_BYTES 128
+
+/* Rank 0 obtains an RCCL unique id (ncclGetUniqueId) and ships the bytes to the
+ * other ranks by any means (bench.py uses torch.distributed).  [host+RCCL] */
+int mi355_icp_comm_unique_id(unsigned char out_id[MI355_ICP_UNIQUE_ID_BYTES]);
+
+/* Joins this context to an RCCL communicator of `n_ranks` ranks.  Afterwards
+ * mi355_icp_align all-reduces the MI355_ICP_NSUMS * n_jobs doubles once per
+ * iteration (ncclAllReduce, sum, float64) on the engine's stream. */
+int mi355_icp_comm_attach(mi355_icp_ctx* ctx, const unsigned char id[MI355_ICP_UNIQUE_ID_BYTES], int rank,
+                          int n_ranks);
+int mi355_icp_comm_detach(mi355_icp_ctx* ctx);
+
+/* ---- measurement ---------------------------------------------------------- */
+
+int mi355_icp_get_profile(const mi355_icp_ctx* ctx, mi355_icp_profile* out);
+int mi355_icp_reset_profile(mi355_icp_ctx* ctx);
+
+/* Device name / CU count of the bound device (name buffer >= 64 bytes). */
+int mi355_icp_device_info(const mi355_icp_ctx* ctx, char* name, size_t name_len, int* compute_units,
+                          size_t* total_mem);
+
+/* ---- synthetic clouds (bench and tests; exact IEEE +,-,*,/,sqrt only, so the
+ * output is bit-reproducible on any host) ---------------------------------- */
+
+/* Writes `count` points, index first_index.., of the synthetic "bumpy sphere"
+ * surface sample with PRNG key `seed` as AoS float32 xyz.  If sigma > 0 adds
+ * zero-mean noise (unit-variance Irwin-Hall(4) * sigma) keyed by noise_seed.
+ * If transform12 != NULL applies the row-major 3x4 double rigid transform
+ * before rounding to float32.  [host] */
+int mi355_icp_synth_cloud(uint64_t seed, uint64_t noise_seed, double sigma, const double* transform12,
+                          size_t first_index, size_t count, float* out_xyz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_ICP_H */

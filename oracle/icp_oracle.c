@@ -1,0 +1,544 @@
+/*
+ * icp_oracle.c — CPU restatement of the point-to-point ICP hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under pose_estimation_amd/ may include,
+ * link, import or execute this file; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it, as the checker and the CPU baseline.
+ *
+ * PARITY UNPINNED.  The reference (yumi-crew/pose_estimation) holds no tests,
+ * golden vectors or sample clouds for this path, and the arithmetic it runs
+ * lives in an un-vendored, un-pinned third-party module
+ * (opencv_contrib surface_matching, cv::ppf_match_3d::ICP; call site
+ * pose_estimation/src/opencv_surface_match.cpp:85,94; README.md:14-22 clones
+ * the default branch) that is not present in the build container, so it can be
+ * neither compiled nor run here.  This file therefore restates the algorithm
+ * the design brief (BASELINE.json north_star) mandates,
+ * anchored on the reference's call-site contract:
+ *   - clouds are float32 xyz rows            (pose_estimation.cpp:263-276)
+ *   - poses are row-major 4x4 double, model->scene, refined in place together
+ *     with a scalar residual                 (opencv_surface_match.cpp:80-94)
+ *   - 7-float pose {x,y,z,qx,qy,qz,qw}       (pose_estimation.hpp:83-88) with the
+ *     matrix->quaternion formula of          chessboard_pose_estimator.cpp:196-207
+ *     and the packing of                     opencv_surface_match.cpp:133-142
+ * and cross-checked in tests/ against scipy.spatial.cKDTree (exact NN) and
+ * numpy.linalg.svd (Kabsch), which are independent of this file.
+ *
+ * Numeric definition (the thing the GPU path must reproduce):
+ *   pose -> float32 (round to nearest) 3x4 [R|t]
+ *   s'   = ((r0*x + r1*y) + r2*z) + t      every product and sum rounded to float32, no FMA
+ *   d2   = ((dx*dx) + (dy*dy)) + (dz*dz)   dx = s'x - tx etc., float32, no FMA
+ *          (the accumulation order of FLANN's L2 functor on a non-FMA x86 build)
+ *   nn   = lowest target index among the float32 minima of d2
+ *   accept pair if d2 <= max_d2 (float32), max_d2 = maxdist*maxdist in float32
+ *   sums in double over accepted pairs (layout: include/mi355_icp.h MI355_ICP_NSUMS)
+ *   Kabsch: H = sum s0 t^T - (sum s0)(sum t)^T / n, H = U S V^T,
+ *           R = V diag(1,1,det(V U^T)) U^T, t = tbar - R s0bar
+ *   convergence: see oracle_host_update
+ *
+ * Build: oracle/Makefile  (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NSUMS 17
+
+enum { OR_OK = 0, OR_INVALID = 1, OR_TOO_FEW = 5, OR_NUMERIC = 6 };
+
+typedef struct oracle_params {
+  int32_t max_iterations;
+  float max_correspondence_distance;
+  double transformation_epsilon;
+  double rotation_epsilon;
+  double relative_mse_epsilon;
+  int32_t flags;
+} oracle_params;
+
+/* ------------------------------------------------------------------------ */
+/* float32 building blocks (volatile-free; -ffp-contract=off keeps them exact) */
+
+void oracle_pose_to_f32(const double pose[16], float out12[12]) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) out12[4 * r + c] = (float)pose[4 * r + c];
+}
+
+static inline void xform(const float m[12], float x, float y, float z, float* ox, float* oy, float* oz) {
+  float a, b;
+  a = m[0] * x; b = m[1] * y; a = a + b; b = m[2] * z; a = a + b; *ox = a + m[3];
+  a = m[4] * x; b = m[5] * y; a = a + b; b = m[6] * z; a = a + b; *oy = a + m[7];
+  a = m[8] * x; b = m[9] * y; a = a + b; b = m[10] * z; a = a + b; *oz = a + m[11];
+}
+
+static inline float dist2(float qx, float qy, float qz, float tx, float ty, float tz) {
+  float dx = qx - tx, dy = qy - ty, dz = qz - tz;
+  float a = dx * dx, b = dy * dy, c = dz * dz;
+  a = a + b;
+  return a + c;
+}
+
+void oracle_transform(const float pose12[12], const float* src_xyz, size_t n, float* out_xyz) {
+  for (size_t i = 0; i < n; ++i)
+    xform(pose12, src_xyz[3 * i], src_xyz[3 * i + 1], src_xyz[3 * i + 2], &out_xyz[3 * i], &out_xyz[3 * i + 1],
+          &out_xyz[3 * i + 2]);
+}
+
+/* ------------------------------------------------------------------------ */
+/* exact brute-force 1-NN: lowest index among equal float32 minima           */
+
+void oracle_nn_brute(const float* q_xyz, size_t nq, const float* t_xyz, size_t nt, int32_t* idx, float* d2,
+                     int nthreads) {
+#ifdef _OPENMP
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+  for (long long i = 0; i < (long long)nq; ++i) {
+    float qx = q_xyz[3 * i], qy = q_xyz[3 * i + 1], qz = q_xyz[3 * i + 2];
+    float best = INFINITY;
+    int32_t bj = 0;
+    for (size_t j = 0; j < nt; ++j) {
+      float d = dist2(qx, qy, qz, t_xyz[3 * j], t_xyz[3 * j + 1], t_xyz[3 * j + 2]);
+      if (d < best) { best = d; bj = (int32_t)j; }
+    }
+    idx[i] = bj;
+    d2[i] = best;
+  }
+  (void)nthreads;
+}
+
+/* ------------------------------------------------------------------------ */
+/* exact KD-tree 1-NN with the same float32 distance and the same tie rule.
+ * Bounding-box lower bounds are evaluated with the SAME rounded operations as
+ * dist2, and rounding is monotone, so lb <= d2 of every point in the box holds
+ * in floating point, not just in exact arithmetic; a subtree is skipped only
+ * when lb > best (strict), and equal distances prefer the lower index, so the
+ * result equals oracle_nn_brute bit for bit.                                */
+
+typedef struct kd_node {
+  float lo[3], hi[3];
+  int32_t left, right; /* children, or -1 */
+  int32_t begin, end;  /* leaf range into perm */
+} kd_node;
+
+typedef struct oracle_kdtree {
+  size_t n;
+  float* pts;    /* reordered xyz, leaf-contiguous */
+  int32_t* perm; /* original index of reordered point */
+  kd_node* nodes;
+  int32_t n_nodes, cap_nodes;
+} oracle_kdtree;
+
+#define KD_LEAF 12
+
+static int32_t kd_new_node(oracle_kdtree* t) {
+  if (t->n_nodes == t->cap_nodes) {
+    t->cap_nodes = t->cap_nodes ? t->cap_nodes * 2 : 1024;
+    t->nodes = (kd_node*)realloc(t->nodes, (size_t)t->cap_nodes * sizeof(kd_node));
+  }
+  return t->n_nodes++;
+}
+
+static void kd_select(const float* xyz, int32_t* perm, int32_t lo, int32_t hi, int32_t k, int dim) {
+  /* quickselect on perm[lo,hi) by coordinate dim, ties by index for determinism */
+  while (hi - lo > 1) {
+    int32_t mid = lo + (hi - lo) / 2;
+    int32_t pv = perm[mid];
+    float pvv = xyz[3 * (size_t)pv + dim];
+    perm[mid] = perm[hi - 1];
+    perm[hi - 1] = pv;
+    int32_t store = lo;
+    for (int32_t i = lo; i < hi - 1; ++i) {
+      float v = xyz[3 * (size_t)perm[i] + dim];
+      if (v < pvv || (v == pvv && perm[i] < pv)) {
+        int32_t tmp = perm[i]; perm[i] = perm[store]; perm[store] = tmp;
+        ++store;
+      }
+    }
+    int32_t tmp = perm[store]; perm[store] = perm[hi - 1]; perm[hi - 1] = tmp;
+    if (store == k) return;
+    if (k < store) hi = store; else lo = store + 1;
+  }
+}
+
+static int32_t kd_build_rec(oracle_kdtree* t, const float* xyz, int32_t lo, int32_t hi) {
+  int32_t id = kd_new_node(t);
+  float bl[3] = {INFINITY, INFINITY, INFINITY}, bh[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int32_t i = lo; i < hi; ++i)
+    for (int d = 0; d < 3; ++d) {
+      float v = xyz[3 * (size_t)t->perm[i] + d];
+      if (v < bl[d]) bl[d] = v;
+      if (v > bh[d]) bh[d] = v;
+    }
+  for (int d = 0; d < 3; ++d) { t->nodes[id].lo[d] = bl[d]; t->nodes[id].hi[d] = bh[d]; }
+  t->nodes[id].begin = lo;
+  t->nodes[id].end = hi;
+  t->nodes[id].left = t->nodes[id].right = -1;
+  if (hi - lo > KD_LEAF) {
+    int dim = 0;
+    float ext = bh[0] - bl[0];
+    if (bh[1] - bl[1] > ext) { ext = bh[1] - bl[1]; dim = 1; }
+    if (bh[2] - bl[2] > ext) { ext = bh[2] - bl[2]; dim = 2; }
+    if (ext > 0.0f) {
+      int32_t mid = lo + (hi - lo) / 2;
+      kd_select(xyz, t->perm, lo, hi, mid, dim);
+      int32_t l = kd_build_rec(t, xyz, lo, mid);
+      int32_t r = kd_build_rec(t, xyz, mid, hi);
+      t->nodes[id].left = l;
+      t->nodes[id].right = r;
+    }
+  }
+  return id;
+}
+
+oracle_kdtree* oracle_kdtree_build(const float* t_xyz, size_t nt) {
+  oracle_kdtree* t = (oracle_kdtree*)calloc(1, sizeof(*t));
+  t->n = nt;
+  t->perm = (int32_t*)malloc((nt ? nt : 1) * sizeof(int32_t));
+  t->pts = (float*)malloc((nt ? nt : 1) * 3 * sizeof(float));
+  for (size_t i = 0; i < nt; ++i) t->perm[i] = (int32_t)i;
+  if (nt) kd_build_rec(t, t_xyz, 0, (int32_t)nt);
+  for (size_t i = 0; i < nt; ++i) memcpy(&t->pts[3 * i], &t_xyz[3 * (size_t)t->perm[i]], 3 * sizeof(float));
+  return t;
+}
+
+void oracle_kdtree_free(oracle_kdtree* t) {
+  if (!t) return;
+  free(t->perm); free(t->pts); free(t->nodes); free(t);
+}
+
+static inline float box_lb(const kd_node* nd, float qx, float qy, float qz) {
+  float q[3] = {qx, qy, qz}, b[3];
+  for (int d = 0; d < 3; ++d) {
+    float v = 0.0f;
+    if (q[d] < nd->lo[d]) v = q[d] - nd->lo[d];
+    else if (q[d] > nd->hi[d]) v = q[d] - nd->hi[d];
+    b[d] = v;
+  }
+  float a = b[0] * b[0], bb = b[1] * b[1], c = b[2] * b[2];
+  a = a + bb;
+  return a + c;
+}
+
+static void kd_query_one(const oracle_kdtree* t, float qx, float qy, float qz, int32_t* out_idx, float* out_d2) {
+  /* same initial state and update rule as oracle_nn_brute: (index 0, +inf), replaced only by a strictly
+   * smaller distance, or by an equal distance at a lower original index (the tree visits out of order). */
+  float best = INFINITY;
+  int32_t bj = 0;
+  int32_t stack[128];
+  int sp = 0;
+  if (t->n) stack[sp++] = 0;
+  while (sp) {
+    const kd_node* nd = &t->nodes[stack[--sp]];
+    if (box_lb(nd, qx, qy, qz) > best) continue;
+    if (nd->left < 0) {
+      for (int32_t i = nd->begin; i < nd->end; ++i) {
+        float d = dist2(qx, qy, qz, t->pts[3 * (size_t)i], t->pts[3 * (size_t)i + 1], t->pts[3 * (size_t)i + 2]);
+        int32_t j = t->perm[i];
+        if (d < best || (d == best && j < bj)) { best = d; bj = j; }
+      }
+    } else {
+      const kd_node* l = &t->nodes[nd->left];
+      const kd_node* r = &t->nodes[nd->right];
+      float ll = box_lb(l, qx, qy, qz), lr = box_lb(r, qx, qy, qz);
+      /* visit the nearer child first (push it last) */
+      if (ll <= lr) { stack[sp++] = nd->right; stack[sp++] = nd->left; }
+      else { stack[sp++] = nd->left; stack[sp++] = nd->right; }
+    }
+  }
+  *out_idx = bj;
+  *out_d2 = best;
+}
+
+void oracle_kdtree_query(const oracle_kdtree* t, const float* q_xyz, size_t nq, int32_t* idx, float* d2,
+                         int nthreads) {
+#ifdef _OPENMP
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 256)
+#endif
+  for (long long i = 0; i < (long long)nq; ++i)
+    kd_query_one(t, q_xyz[3 * i], q_xyz[3 * i + 1], q_xyz[3 * i + 2], &idx[i], &d2[i]);
+  (void)nthreads;
+}
+
+/* ------------------------------------------------------------------------ */
+/* covariance / centroid accumulation (sequential, index order, double)      */
+
+void oracle_accumulate(const float* src0_xyz, const float* t_xyz, const int32_t* idx, const float* d2, size_t n,
+                       float max_corr_dist, double sums[NSUMS]) {
+  float max_d2 = INFINITY;
+  if (max_corr_dist > 0.0f) max_d2 = max_corr_dist * max_corr_dist;
+  for (int k = 0; k < NSUMS; ++k) sums[k] = 0.0;
+  for (size_t i = 0; i < n; ++i) {
+    if (!(d2[i] <= max_d2)) continue;
+    const float* s = &src0_xyz[3 * i];
+    const float* t = &t_xyz[3 * (size_t)idx[i]];
+    sums[0] += 1.0;
+    for (int a = 0; a < 3; ++a) {
+      sums[1 + a] += (double)s[a];
+      sums[4 + a] += (double)t[a];
+      for (int b = 0; b < 3; ++b) sums[7 + 3 * a + b] += (double)s[a] * (double)t[b];
+    }
+    sums[16] += (double)d2[i];
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Kabsch via eigen-decomposition of H^T H (cyclic Jacobi), then U = H V / s
+ * with Gram-Schmidt completion for vanishing singular values.               */
+
+static void jacobi_eig3(double A[3][3], double V[3][3], double w[3]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) V[i][j] = (i == j);
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+    double diag = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+    if (off <= 1e-300 || off <= 1e-32 * diag) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (A[p][q] == 0.0) continue;
+        double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+        for (int k = 0; k < 3; ++k) { /* A <- A J */
+          double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - s * akq;
+          A[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) { /* A <- J^T A */
+          double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - s * aqk;
+          A[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  for (int i = 0; i < 3; ++i) w[i] = A[i][i];
+}
+
+static double det3(double M[3][3]) {
+  return M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+         M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+}
+
+int oracle_solve_rigid(const double sums[NSUMS], double pose[16]) {
+  for (int k = 0; k < NSUMS; ++k)
+    if (!isfinite(sums[k])) return OR_NUMERIC;
+  double n = sums[0];
+  if (n < 3.0) return OR_TOO_FEW;
+  double sb[3], tb[3], H[3][3];
+  for (int a = 0; a < 3; ++a) { sb[a] = sums[1 + a] / n; tb[a] = sums[4 + a] / n; }
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) H[a][b] = sums[7 + 3 * a + b] - sums[1 + a] * sums[4 + b] / n;
+  /* H^T H = V S^2 V^T */
+  double A[3][3], V[3][3], w[3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double acc = 0;
+      for (int k = 0; k < 3; ++k) acc += H[k][i] * H[k][j];
+      A[i][j] = acc;
+    }
+  jacobi_eig3(A, V, w);
+  /* sort descending */
+  int ord[3] = {0, 1, 2};
+  for (int i = 0; i < 2; ++i)
+    for (int j = i + 1; j < 3; ++j)
+      if (w[ord[j]] > w[ord[i]]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+  double Vs[3][3], U[3][3], sv[3];
+  for (int c = 0; c < 3; ++c) {
+    for (int r = 0; r < 3; ++r) Vs[r][c] = V[r][ord[c]];
+    sv[c] = w[ord[c]] > 0 ? sqrt(w[ord[c]]) : 0.0;
+  }
+  double smax = sv[0];
+  int rank = 0;
+  for (int c = 0; c < 3; ++c) {
+    double u[3];
+    for (int r = 0; r < 3; ++r) u[r] = H[r][0] * Vs[0][c] + H[r][1] * Vs[1][c] + H[r][2] * Vs[2][c];
+    /* orthogonalise against accepted columns (twice for safety) */
+    for (int pass = 0; pass < 2; ++pass)
+      for (int p = 0; p < rank; ++p) {
+        double dot = u[0] * U[0][p] + u[1] * U[1][p] + u[2] * U[2][p];
+        for (int r = 0; r < 3; ++r) u[r] -= dot * U[r][p];
+      }
+    double nrm = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    if (smax > 0 && nrm > 1e-9 * smax && c == rank) {
+      for (int r = 0; r < 3; ++r) U[r][rank] = u[r] / nrm;
+      ++rank;
+    } else {
+      break;
+    }
+  }
+  /* complete U to an orthonormal basis */
+  if (rank == 0) {
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) { U[r][c] = (r == c); Vs[r][c] = (r == c); }
+  } else if (rank == 1) {
+    double a[3] = {U[0][0], U[1][0], U[2][0]};
+    int m = 0;
+    if (fabs(a[1]) < fabs(a[m])) m = 1;
+    if (fabs(a[2]) < fabs(a[m])) m = 2;
+    double e[3] = {0, 0, 0};
+    e[m] = 1.0;
+    double dot = a[m];
+    double b[3] = {e[0] - dot * a[0], e[1] - dot * a[1], e[2] - dot * a[2]};
+    double nb = sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+    for (int r = 0; r < 3; ++r) U[r][1] = b[r] / nb;
+    U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+    U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+    U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+  } else if (rank == 2) {
+    U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+    U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+    U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+  }
+  /* R = V diag(1,1,det(V U^T)) U^T */
+  double dV = det3(Vs), dU = det3(U);
+  double sgn = (dV * dU < 0) ? -1.0 : 1.0;
+  double R[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[i][j] = Vs[i][0] * U[j][0] + Vs[i][1] * U[j][1] + sgn * Vs[i][2] * U[j][2];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) pose[4 * i + j] = R[i][j];
+    pose[4 * i + 3] = tb[i] - (R[i][0] * sb[0] + R[i][1] * sb[1] + R[i][2] * sb[2]);
+  }
+  pose[12] = pose[13] = pose[14] = 0.0;
+  pose[15] = 1.0;
+  for (int k = 0; k < 16; ++k)
+    if (!isfinite(pose[k])) return OR_NUMERIC;
+  return OR_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* iteration controller                                                      */
+
+int oracle_host_update(const oracle_params* p, const double sums[NSUMS], int iteration, double pose[16],
+                       double* prev_mse, int* done, int* converged) {
+  double np[16];
+  int st = oracle_solve_rigid(sums, np);
+  if (st != OR_OK) return st;
+  double mse = sums[16] / sums[0];
+  /* incremental transform D = Pnew * Pold^-1 ; Pold^-1 = [R^T | -R^T t] */
+  double Ro[3][3], to[3], Rn[3][3], tn[3];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) { Ro[i][j] = pose[4 * i + j]; Rn[i][j] = np[4 * i + j]; }
+    to[i] = pose[4 * i + 3];
+    tn[i] = np[4 * i + 3];
+  }
+  double trace = 0.0, dt[3];
+  for (int i = 0; i < 3; ++i) {
+    /* (Rn Ro^T)_ii */
+    trace += Rn[i][0] * Ro[i][0] + Rn[i][1] * Ro[i][1] + Rn[i][2] * Ro[i][2];
+  }
+  for (int i = 0; i < 3; ++i) {
+    double acc = 0.0; /* (Rn Ro^T to)_i */
+    for (int k = 0; k < 3; ++k) {
+      double dik = Rn[i][0] * Ro[k][0] + Rn[i][1] * Ro[k][1] + Rn[i][2] * Ro[k][2];
+      acc += dik * to[k];
+    }
+    dt[i] = tn[i] - acc;
+  }
+  double one_minus_cos = 1.0 - 0.5 * (trace - 1.0);
+  double dt2 = dt[0] * dt[0] + dt[1] * dt[1] + dt[2] * dt[2];
+  int conv = 0;
+  if (p->transformation_epsilon > 0.0 && dt2 <= p->transformation_epsilon && one_minus_cos <= p->rotation_epsilon)
+    conv = 1;
+  if (p->relative_mse_epsilon > 0.0 && iteration > 0 && fabs(mse - *prev_mse) <= p->relative_mse_epsilon * (*prev_mse))
+    conv = 1;
+  memcpy(pose, np, sizeof(np));
+  *prev_mse = mse;
+  *converged = conv;
+  *done = conv || (iteration + 1 >= p->max_iterations);
+  return OR_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* full ICP.  Optional trace: per iteration NSUMS sums, 16 pose entries (the
+ * pose the pass was evaluated under) — arrays sized max_iterations*...       */
+
+int oracle_icp(const float* src_xyz, size_t ns, const float* tgt_xyz, size_t nt, const double init_pose[16],
+               const oracle_params* p, int use_kdtree, int nthreads, double out_pose[16], double* out_residual,
+               int* out_iters, int* out_converged, double* trace_sums, double* trace_pose, int32_t* last_idx,
+               float* last_d2) {
+  if (!p || p->max_iterations < 1 || !ns || !nt) return OR_INVALID;
+  double pose[16];
+  memcpy(pose, init_pose, sizeof(pose));
+  float* moved = (float*)malloc(ns * 3 * sizeof(float));
+  int32_t* idx = (int32_t*)malloc(ns * sizeof(int32_t));
+  float* d2 = (float*)malloc(ns * sizeof(float));
+  oracle_kdtree* tree = use_kdtree ? oracle_kdtree_build(tgt_xyz, nt) : NULL;
+  double prev_mse = 0.0, residual = 0.0;
+  int iters = 0, conv = 0, st = OR_OK;
+  for (int it = 0; it < p->max_iterations; ++it) {
+    float pf[12];
+    double sums[NSUMS];
+    oracle_pose_to_f32(pose, pf);
+    oracle_transform(pf, src_xyz, ns, moved);
+    if (tree) oracle_kdtree_query(tree, moved, ns, idx, d2, nthreads);
+    else oracle_nn_brute(moved, ns, tgt_xyz, nt, idx, d2, nthreads);
+    oracle_accumulate(src_xyz, tgt_xyz, idx, d2, ns, p->max_correspondence_distance, sums);
+    if (trace_sums) memcpy(&trace_sums[(size_t)it * NSUMS], sums, sizeof(sums));
+    if (trace_pose) memcpy(&trace_pose[(size_t)it * 16], pose, sizeof(pose));
+    int done = 0;
+    st = oracle_host_update(p, sums, it, pose, &prev_mse, &done, &conv);
+    if (st != OR_OK) break;
+    iters = it + 1;
+    residual = sqrt(prev_mse);
+    if (done) break;
+  }
+  if (last_idx) memcpy(last_idx, idx, ns * sizeof(int32_t));
+  if (last_d2) memcpy(last_d2, d2, ns * sizeof(float));
+  memcpy(out_pose, pose, sizeof(pose));
+  if (out_residual) *out_residual = residual;
+  if (out_iters) *out_iters = iters;
+  if (out_converged) *out_converged = conv;
+  oracle_kdtree_free(tree);
+  free(moved); free(idx); free(d2);
+  return st;
+}
+
+/* ------------------------------------------------------------------------ */
+/* pose packing: chessboard_pose_estimator.cpp:196-207 formula (evaluated in
+ * float like the reference's xt::xarray<float>), and the reference packing of
+ * opencv_surface_match.cpp:133-142.                                         */
+
+static float quat_axis(float sign_arg, float a, float b, float c) {
+  /* 0.5 * copysign(1.0, sign_arg) * sqrt(a - b - c + 1): float arithmetic inside, as on xt::xarray<float>.
+   * The argument is clamped at 0: the reference formula returns NaN when rounding drives it just below 0. */
+  float arg = ((a - b) - c) + 1.0f;
+  if (arg < 0.0f) arg = 0.0f;
+  float r = sqrtf(arg);
+  return (float)(0.5 * copysign(1.0, (double)sign_arg) * (double)r);
+}
+
+void oracle_pose_to_pose7(const double pose[16], float out7[7], int reference_packing) {
+  float h[3][4];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) h[i][j] = (float)pose[4 * i + j];
+  float ox = quat_axis(h[2][1] - h[1][2], h[0][0], h[1][1], h[2][2]);
+  float oy = quat_axis(h[0][2] - h[2][0], h[1][1], h[2][2], h[0][0]);
+  float oz = quat_axis(h[1][0] - h[0][1], h[2][2], h[0][0], h[1][1]);
+  float warg = ((h[0][0] + h[1][1]) + h[2][2]) + 1.0f;
+  if (warg < 0.0f) warg = 0.0f;
+  float w = (float)(0.5 * (double)sqrtf(warg));
+  out7[0] = h[0][3]; out7[1] = h[1][3]; out7[2] = h[2][3];
+  if (reference_packing) {
+    /* pose[3]=q[1]; pose[4]=q[2]; pose[6]=q[3]; pose[6]=q[0]; with q = (w,x,y,z): pose[5] never set */
+    out7[3] = ox; out7[4] = oy; out7[5] = 0.0f; out7[6] = oz; out7[6] = w;
+  } else {
+    out7[3] = ox; out7[4] = oy; out7[5] = oz; out7[6] = w;
+  }
+}
+
+int oracle_omp_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

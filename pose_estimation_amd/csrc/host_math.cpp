@@ -1,0 +1,253 @@
+// host_math.cpp — the host half of one ICP iteration: Kabsch (3x3 SVD in
+// double), the convergence rule, and pose packing.  The design keeps these on
+// the CPU (BASELINE.json north_star: "the 3x3 SVD done on the host"): they see
+// 17 doubles per job per iteration.  In the reference this arithmetic is inside
+// cv::ppf_match_3d::ICP::registerModelToScene
+// (pose_estimation/src/opencv_surface_match.cpp:94); the only in-repo
+// centroid+SVD is plane_fit (chessboard_pose_estimator.cpp:82-124).
+#include <cmath>
+#include <cstring>
+
+#include "../../include/mi355_icp.h"
+#include "icp_internal.h"
+
+namespace mi355 {
+
+// One-sided (Hestenes) Jacobi SVD of a 3x3: rotates column pairs of G = H V until
+// they are mutually orthogonal; then column norms are the singular values and
+// the normalised columns are U.  Robust for rank-deficient H (coplanar /
+// collinear clouds): vanishing columns are completed by cross products.
+static void svd3(const double H[3][3], double U[3][3], double S[3], double V[3][3]) {
+  double G[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      G[i][j] = H[i][j];
+      V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int k = 0; k < 3; ++k) {
+          alpha += G[k][p] * G[k][p];
+          beta += G[k][q] * G[k][q];
+          gamma += G[k][p] * G[k][q];
+        }
+        if (gamma == 0.0 || std::fabs(gamma) <= 1e-17 * std::sqrt(alpha * beta)) continue;
+        rotated = true;
+        double zeta = (beta - alpha) / (2.0 * gamma);
+        double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+        for (int k = 0; k < 3; ++k) {
+          double gp = G[k][p], gq = G[k][q];
+          G[k][p] = c * gp - s * gq;
+          G[k][q] = s * gp + c * gq;
+          double vp = V[k][p], vq = V[k][q];
+          V[k][p] = c * vp - s * vq;
+          V[k][q] = s * vp + c * vq;
+        }
+      }
+    if (!rotated) break;
+  }
+  double nrm[3];
+  for (int j = 0; j < 3; ++j) nrm[j] = std::sqrt(G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j]);
+  // order columns by decreasing singular value
+  int ord[3] = {0, 1, 2};
+  for (int i = 0; i < 2; ++i)
+    for (int j = i + 1; j < 3; ++j)
+      if (nrm[ord[j]] > nrm[ord[i]]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+  double Vo[3][3], Go[3][3];
+  for (int c = 0; c < 3; ++c) {
+    S[c] = nrm[ord[c]];
+    for (int r = 0; r < 3; ++r) { Vo[r][c] = V[r][ord[c]]; Go[r][c] = G[r][ord[c]]; }
+  }
+  std::memcpy(V, Vo, sizeof(Vo));
+  const double tiny = 1e-12 * S[0];
+  int rank = 0;
+  for (int c = 0; c < 3; ++c) {
+    if (S[0] > 0.0 && S[c] > tiny) {
+      for (int r = 0; r < 3; ++r) U[r][c] = Go[r][c] / S[c];
+      rank = c + 1;
+    } else {
+      break;
+    }
+  }
+  auto cross_into = [&](int a, int b, int out) {
+    U[0][out] = U[1][a] * U[2][b] - U[2][a] * U[1][b];
+    U[1][out] = U[2][a] * U[0][b] - U[0][a] * U[2][b];
+    U[2][out] = U[0][a] * U[1][b] - U[1][a] * U[0][b];
+  };
+  if (rank == 0) {
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) U[r][c] = (r == c) ? 1.0 : 0.0;
+  } else if (rank == 1) {
+    int m = 0;
+    if (std::fabs(U[1][0]) < std::fabs(U[m][0])) m = 1;
+    if (std::fabs(U[2][0]) < std::fabs(U[m][0])) m = 2;
+    double e[3] = {0, 0, 0};
+    e[m] = 1.0;
+    double dot = U[m][0], b[3], nb = 0;
+    for (int r = 0; r < 3; ++r) { b[r] = e[r] - dot * U[r][0]; nb += b[r] * b[r]; }
+    nb = std::sqrt(nb);
+    for (int r = 0; r < 3; ++r) U[r][1] = b[r] / nb;
+    cross_into(0, 1, 2);
+  } else if (rank == 2) {
+    cross_into(0, 1, 2);
+  }
+}
+
+static double det3(const double M[3][3]) {
+  return M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+         M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+}
+
+int solve_rigid(const double* sums, double* pose) {
+  for (int k = 0; k < MI355_ICP_NSUMS; ++k)
+    if (!std::isfinite(sums[k])) return MI355_ICP_ERR_NUMERIC;
+  const double n = sums[0];
+  if (n < 3.0) return MI355_ICP_ERR_TOO_FEW_PAIRS;
+  double sbar[3], tbar[3], H[3][3];
+  for (int a = 0; a < 3; ++a) {
+    sbar[a] = sums[1 + a] / n;
+    tbar[a] = sums[4 + a] / n;
+  }
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) H[a][b] = sums[7 + 3 * a + b] - sums[1 + a] * sums[4 + b] / n;
+  double U[3][3], S[3], V[3][3];
+  svd3(H, U, S, V);
+  const double sgn = (det3(V) * det3(U) < 0.0) ? -1.0 : 1.0;
+  double out[16];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) out[4 * i + j] = V[i][0] * U[j][0] + V[i][1] * U[j][1] + sgn * V[i][2] * U[j][2];
+    out[4 * i + 3] = tbar[i] - (out[4 * i + 0] * sbar[0] + out[4 * i + 1] * sbar[1] + out[4 * i + 2] * sbar[2]);
+  }
+  out[12] = out[13] = out[14] = 0.0;
+  out[15] = 1.0;
+  for (int k = 0; k < 16; ++k)
+    if (!std::isfinite(out[k])) return MI355_ICP_ERR_NUMERIC;
+  std::memcpy(pose, out, sizeof(out));
+  return MI355_ICP_OK;
+}
+
+int host_update(const mi355_icp_params* p, const double* sums, int iteration, double* pose, double* prev_mse,
+                int* out_done, int* out_converged) {
+  double next[16];
+  int st = solve_rigid(sums, next);
+  if (st != MI355_ICP_OK) return st;
+  const double mse = sums[16] / sums[0];
+  // incremental transform D = P_next * P_prev^-1 = [Rn Ro^T | tn - Rn Ro^T to]
+  double D[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 3; ++k)
+      D[i][k] = next[4 * i + 0] * pose[4 * k + 0] + next[4 * i + 1] * pose[4 * k + 1] + next[4 * i + 2] * pose[4 * k + 2];
+  double dt2 = 0.0;
+  for (int i = 0; i < 3; ++i) {
+    double acc = 0.0;
+    for (int k = 0; k < 3; ++k) acc += D[i][k] * pose[4 * k + 3];
+    double d = next[4 * i + 3] - acc;
+    dt2 += d * d;
+  }
+  const double one_minus_cos = 1.0 - 0.5 * ((D[0][0] + D[1][1] + D[2][2]) - 1.0);
+  int conv = 0;
+  if (p->transformation_epsilon > 0.0 && dt2 <= p->transformation_epsilon && one_minus_cos <= p->rotation_epsilon)
+    conv = 1;
+  if (p->relative_mse_epsilon > 0.0 && iteration > 0 &&
+      std::fabs(mse - *prev_mse) <= p->relative_mse_epsilon * (*prev_mse))
+    conv = 1;
+  std::memcpy(pose, next, sizeof(next));
+  *prev_mse = mse;
+  *out_converged = conv;
+  *out_done = (conv || iteration + 1 >= p->max_iterations) ? 1 : 0;
+  return MI355_ICP_OK;
+}
+
+// 0.5 * copysign(1, sign_arg) * sqrt(a - b - c + 1) with float arithmetic inside,
+// as the reference evaluates it on xt::xarray<float>
+// (chessboard_pose_estimator.cpp:196-207).  Deviation: the sqrt argument is
+// clamped at 0; the reference returns NaN when rounding takes it below 0.
+static float quat_axis(float sign_arg, float a, float b, float c) {
+  float arg = ((a - b) - c) + 1.0f;
+  if (arg < 0.0f) arg = 0.0f;
+  const float r = std::sqrt(arg);
+  return static_cast<float>(0.5 * std::copysign(1.0, static_cast<double>(sign_arg)) * static_cast<double>(r));
+}
+
+}  // namespace mi355
+
+extern "C" {
+
+unsigned mi355_icp_abi_version(void) { return MI355_ICP_ABI_VERSION; }
+
+void mi355_icp_default_params(mi355_icp_params* p) {
+  if (!p) return;
+  p->max_iterations = 50;
+  p->max_correspondence_distance = 0.0f;
+  p->transformation_epsilon = 0.0;
+  p->rotation_epsilon = 1e-5;
+  p->relative_mse_epsilon = 0.0;
+  p->flags = 0;
+}
+
+int mi355_icp_params_from_reference(int iterations, float tolerance, float rejection_scale, int num_levels,
+                                    mi355_icp_params* p) {
+  if (!p || iterations < 1) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  (void)rejection_scale;  // point-to-plane / MAD-rejection mode: SURVEY.md 8f rank 1
+  (void)num_levels;       // pyramid: same
+  mi355_icp_default_params(p);
+  p->max_iterations = iterations;
+  p->relative_mse_epsilon = tolerance > 0.0f ? static_cast<double>(tolerance) : 0.0;
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_slab_range(size_t n, int rank, int n_ranks, size_t* begin, size_t* count) {
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks || !begin || !count) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  const size_t base = n / static_cast<size_t>(n_ranks), extra = n % static_cast<size_t>(n_ranks);
+  const size_t r = static_cast<size_t>(rank);
+  *begin = r * base + (r < extra ? r : extra);
+  *count = base + (r < extra ? 1 : 0);
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_solve_rigid(const double sums[MI355_ICP_NSUMS], double out_pose[16]) {
+  if (!sums || !out_pose) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  return mi355::solve_rigid(sums, out_pose);
+}
+
+int mi355_icp_host_update(const mi355_icp_params* params, const double sums[MI355_ICP_NSUMS], int iteration,
+                          double pose[16], double* prev_mse, int* out_done, int* out_converged) {
+  if (!params || !sums || !pose || !prev_mse || !out_done || !out_converged || iteration < 0 ||
+      params->max_iterations < 1)
+    return MI355_ICP_ERR_INVALID_ARGUMENT;
+  return mi355::host_update(params, sums, iteration, pose, prev_mse, out_done, out_converged);
+}
+
+int mi355_icp_pose_to_pose7(const double pose[16], float out7[7], int reference_packing) {
+  if (!pose || !out7) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  float h[3][4];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) h[i][j] = static_cast<float>(pose[4 * i + j]);
+  const float ox = mi355::quat_axis(h[2][1] - h[1][2], h[0][0], h[1][1], h[2][2]);
+  const float oy = mi355::quat_axis(h[0][2] - h[2][0], h[1][1], h[2][2], h[0][0]);
+  const float oz = mi355::quat_axis(h[1][0] - h[0][1], h[2][2], h[0][0], h[1][1]);
+  float warg = ((h[0][0] + h[1][1]) + h[2][2]) + 1.0f;
+  if (warg < 0.0f) warg = 0.0f;
+  const float w = static_cast<float>(0.5 * static_cast<double>(std::sqrt(warg)));
+  out7[0] = h[0][3];
+  out7[1] = h[1][3];
+  out7[2] = h[2][3];
+  out7[3] = ox;
+  out7[4] = oy;
+  if (reference_packing) {
+    // opencv_surface_match.cpp:138-141: pose[3]=q[1]; pose[4]=q[2]; pose[6]=q[3]; pose[6]=q[0];
+    // (q = {w,x,y,z}) -> orientation.z is never written, qz is overwritten by qw.
+    out7[5] = 0.0f;
+    out7[6] = w;
+  } else {
+    out7[5] = oz;
+    out7[6] = w;
+  }
+  return MI355_ICP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,523 @@
+// icp_engine.hip — host side of the engine behind include/mi355_icp.h:
+// device-resident clouds (SoA planes), the per-call planner, the ICP iteration
+// loop (launch scan -> resolve/accumulate -> final reduce -> [RCCL all-reduce]
+// -> 17 doubles to the host -> Kabsch + convergence), and the C-ABI glue.
+//
+// Replaces, in the reference, the object constructed at
+// pose_estimation/src/opencv_surface_match.cpp:85 and the call at :94.
+// No CPU compute fallback exists: every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "icp_internal.h"
+
+namespace mi355 {
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct CloudEntry {
+  uint32_t off;     // first point in the planes
+  uint32_t n;       // real points
+  uint32_t padded;  // slots occupied
+};
+
+struct CloudSet {
+  float* planes = nullptr;  // x | y | z, each `stride` floats
+  size_t stride = 0;
+  std::vector<CloudEntry> clouds;
+  DevicePlanes view() const { return DevicePlanes{planes, planes + stride, planes + 2 * stride}; }
+};
+
+struct Plan {
+  std::vector<JobDesc> jobs;
+  uint32_t out_total = 0;      // padded output slots over all jobs (= key stride)
+  uint32_t partial_total = 0;  // per-block partial rows over all jobs
+  uint32_t max_split = 1;
+  uint32_t max_blocks_x = 0;   // scan grid.x
+  uint32_t max_src_blocks = 0; // resolve grid.x
+};
+
+uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* v = std::getenv(name);
+  if (!v || !*v) return dflt;
+  char* end = nullptr;
+  unsigned long x = std::strtoul(v, &end, 10);
+  return (end && *end == 0 && x > 0) ? static_cast<uint32_t>(x) : dflt;
+}
+
+}  // namespace
+
+}  // namespace mi355
+
+using namespace mi355;
+
+struct mi355_icp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  CloudSet targets, sources;
+
+  // per-call work buffers (grown on demand, never shrunk)
+  unsigned long long* keys = nullptr; size_t keys_cap = 0;
+  int32_t* out_index = nullptr;       size_t out_cap = 0;
+  float* out_dist2 = nullptr;
+  double* partials = nullptr;         size_t partials_cap = 0;
+  double* sums_dev = nullptr;         size_t jobs_cap = 0;
+  JobDesc* jobs_dev = nullptr;
+  uint32_t* error_flag = nullptr;
+  JobDesc* jobs_host = nullptr;  // pinned
+  double* sums_host = nullptr;   // pinned
+  uint32_t* flag_host = nullptr; // pinned
+
+  void* comm = nullptr;
+  int comm_rank = 0, comm_size = 1;
+
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  mi355_icp_profile prof{};
+
+  uint32_t target_blocks = 6144;     // planner: aim for about this many scan workgroups per launch
+  uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
+};
+
+namespace {
+
+int fail(mi355_icp_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                          \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      return fail((ctx), MI355_ICP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* const* xyz, const size_t* n_points,
+                  size_t stride_bytes, uint32_t pad_multiple, float pad_value, bool allow_empty, const char* what) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  if (n_clouds < 1 || !xyz || !n_points) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, std::string(what) + ": no clouds");
+  if (stride_bytes < 12 || stride_bytes % 4 != 0)
+    return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, std::string(what) + ": stride_bytes must be a multiple of 4 and >= 12");
+  std::vector<CloudEntry> entries(static_cast<size_t>(n_clouds));
+  uint64_t total = 0;
+  for (int k = 0; k < n_clouds; ++k) {
+    const size_t n = n_points[k];
+    if (n == 0 && !allow_empty) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, std::string(what) + ": empty cloud");
+    if (n && !xyz[k]) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, std::string(what) + ": null cloud pointer");
+    const uint64_t padded = (static_cast<uint64_t>(n) + pad_multiple - 1) / pad_multiple * pad_multiple;
+    if (total + padded > 0xFFFF0000ull) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, std::string(what) + ": too many points");
+    entries[k] = CloudEntry{static_cast<uint32_t>(total), static_cast<uint32_t>(n), static_cast<uint32_t>(padded)};
+    total += padded;
+  }
+  const size_t stride = static_cast<size_t>(std::max<uint64_t>(total, pad_multiple));
+  std::vector<float> host(3 * stride, pad_value);
+  const size_t fstride = stride_bytes / 4;
+  for (int k = 0; k < n_clouds; ++k) {
+    const float* src = xyz[k];
+    float* px = host.data() + entries[k].off;
+    float* py = px + stride;
+    float* pz = py + stride;
+    bool finite = true;
+    for (size_t i = 0; i < entries[k].n; ++i) {
+      const float x = src[i * fstride], y = src[i * fstride + 1], z = src[i * fstride + 2];
+      finite = finite && std::isfinite(x) && std::isfinite(y) && std::isfinite(z);
+      px[i] = x; py[i] = y; pz[i] = z;
+    }
+    if (!finite)
+      return fail(c, MI355_ICP_ERR_NONFINITE_INPUT,
+                  std::string(what) + ": cloud " + std::to_string(k) + " holds NaN/Inf (strip them first, as the reference does at pose_estimation.cpp:248)");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (set.planes) { HIP_TRY(c, hipFree(set.planes)); set.planes = nullptr; }
+  set.clouds.clear();
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.planes), 3 * stride * sizeof(float)));
+  HIP_TRY(c, hipMemcpy(set.planes, host.data(), 3 * stride * sizeof(float), hipMemcpyHostToDevice));
+  set.stride = stride;
+  set.clouds = std::move(entries);
+  return MI355_ICP_OK;
+}
+
+template <typename T>
+int grow(mi355_icp_ctx* c, T*& ptr, size_t& cap, size_t need) {
+  if (need <= cap) return MI355_ICP_OK;
+  if (ptr) { HIP_TRY(c, hipFree(ptr)); ptr = nullptr; cap = 0; }
+  const size_t want = need + need / 4;
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&ptr), want * sizeof(T)));
+  cap = want;
+  return MI355_ICP_OK;
+}
+
+int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs) {
+  int st;
+  if ((st = grow(c, c->keys, c->keys_cap, static_cast<size_t>(plan.max_split) * plan.out_total)) != MI355_ICP_OK) return st;
+  if (plan.out_total > c->out_cap) {
+    if (c->out_index) { HIP_TRY(c, hipFree(c->out_index)); c->out_index = nullptr; }
+    if (c->out_dist2) { HIP_TRY(c, hipFree(c->out_dist2)); c->out_dist2 = nullptr; }
+    c->out_cap = 0;
+    const size_t want = plan.out_total + plan.out_total / 4;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->out_index), want * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->out_dist2), want * sizeof(float)));
+    c->out_cap = want;
+  }
+  if ((st = grow(c, c->partials, c->partials_cap, static_cast<size_t>(std::max<uint32_t>(plan.partial_total, 1)) * MI355_ICP_NSUMS)) != MI355_ICP_OK) return st;
+  if (n_jobs > c->jobs_cap) {
+    if (c->sums_dev) { HIP_TRY(c, hipFree(c->sums_dev)); c->sums_dev = nullptr; }
+    if (c->jobs_dev) { HIP_TRY(c, hipFree(c->jobs_dev)); c->jobs_dev = nullptr; }
+    if (c->jobs_host) { HIP_TRY(c, hipHostFree(c->jobs_host)); c->jobs_host = nullptr; }
+    if (c->sums_host) { HIP_TRY(c, hipHostFree(c->sums_host)); c->sums_host = nullptr; }
+    c->jobs_cap = 0;
+    const size_t want = std::max<size_t>(n_jobs, 8) * 2;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sums_dev), want * MI355_ICP_NSUMS * sizeof(double)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->jobs_dev), want * sizeof(JobDesc)));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->jobs_host), want * sizeof(JobDesc), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->sums_host), want * MI355_ICP_NSUMS * sizeof(double), hipHostMallocDefault));
+    c->jobs_cap = want;
+  }
+  return MI355_ICP_OK;
+}
+
+// Lays the jobs out and decides how finely to cut each target: enough scan workgroups to keep
+// 256 CUs x 4 resident workgroups busy for several rounds, never finer than min_tiles_per_split.
+int make_plan(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* target_ids, float max_corr, Plan& plan) {
+  if (c->targets.clouds.empty()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "no target clouds uploaded (mi355_icp_set_targets)");
+  if (c->sources.clouds.empty()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "no source clouds uploaded (mi355_icp_set_sources)");
+  plan = Plan{};
+  plan.jobs.resize(static_cast<size_t>(n_jobs));
+  uint64_t total_src_blocks = 0;
+  for (int k = 0; k < n_jobs; ++k) {
+    const int s = source_ids ? source_ids[k] : 0, t = target_ids ? target_ids[k] : 0;
+    if (s < 0 || static_cast<size_t>(s) >= c->sources.clouds.size()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "source id out of range");
+    if (t < 0 || static_cast<size_t>(t) >= c->targets.clouds.size()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "target id out of range");
+    total_src_blocks += c->sources.clouds[s].padded / kSrcPerBlock;
+  }
+  float max_d2 = std::numeric_limits<float>::infinity();
+  if (max_corr > 0.0f) max_d2 = max_corr * max_corr;  // float32 product, as the oracle
+  const uint32_t want_split = static_cast<uint32_t>(
+      std::max<uint64_t>(1, (c->target_blocks + std::max<uint64_t>(total_src_blocks, 1) - 1) / std::max<uint64_t>(total_src_blocks, 1)));
+  uint64_t out_off = 0, partial_off = 0;
+  for (int k = 0; k < n_jobs; ++k) {
+    const CloudEntry& S = c->sources.clouds[source_ids ? source_ids[k] : 0];
+    const CloudEntry& T = c->targets.clouds[target_ids ? target_ids[k] : 0];
+    JobDesc& J = plan.jobs[k];
+    std::memset(&J, 0, sizeof(J));
+    J.src_off = S.off;
+    J.src_n = S.n;
+    J.src_blocks = S.padded / kSrcPerBlock;
+    J.tgt_off = T.off;
+    J.tgt_n = T.n;
+    J.tgt_tiles = T.padded / kTile;
+    const uint32_t cap = std::max<uint32_t>(1, J.tgt_tiles / std::max<uint32_t>(1, c->min_tiles_per_split));
+    uint32_t split = std::min(std::max<uint32_t>(want_split, 1), cap);
+    J.tiles_per_split = (J.tgt_tiles + split - 1) / split;
+    J.n_split = (J.tgt_tiles + J.tiles_per_split - 1) / J.tiles_per_split;
+    J.out_off = static_cast<uint32_t>(out_off);
+    J.partial_off = static_cast<uint32_t>(partial_off);
+    J.max_d2 = max_d2;
+    out_off += S.padded;
+    partial_off += J.src_blocks;
+    if (out_off > 0xFFFF0000ull) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "batch too large");
+    plan.max_split = std::max(plan.max_split, J.n_split);
+    plan.max_blocks_x = std::max(plan.max_blocks_x, J.src_blocks * J.n_split);
+    plan.max_src_blocks = std::max(plan.max_src_blocks, J.src_blocks);
+  }
+  plan.out_total = static_cast<uint32_t>(out_off);
+  plan.partial_total = static_cast<uint32_t>(partial_off);
+  if (static_cast<uint64_t>(plan.max_split) * plan.out_total > 0xFFFF0000ull) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "batch too large");
+  return MI355_ICP_OK;
+}
+
+bool pose_to_f32(const double* pose16, float* out12) {
+  bool ok = true;
+  for (int r = 0; r < 3; ++r)
+    for (int col = 0; col < 4; ++col) {
+      const float v = static_cast<float>(pose16[4 * r + col]);
+      ok = ok && std::isfinite(v);
+      out12[4 * r + col] = v;
+    }
+  return ok;
+}
+
+// Enqueues one correspondence pass for the first n_active descriptors of jobs_host and leaves
+// their sums in sums_host (synchronises the stream).  `local_only` skips the collective.
+int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only) {
+  HIP_TRY(c, hipMemcpyAsync(c->jobs_dev, c->jobs_host, static_cast<size_t>(n_active) * sizeof(JobDesc), hipMemcpyHostToDevice, c->stream));
+  uint32_t bx = 0, sbx = 0;
+  double pairs = 0.0;
+  for (int k = 0; k < n_active; ++k) {
+    const JobDesc& J = c->jobs_host[k];
+    bx = std::max(bx, J.src_blocks * J.n_split);
+    sbx = std::max(sbx, J.src_blocks);
+    pairs += static_cast<double>(J.src_n) * static_cast<double>(J.tgt_n);
+  }
+  (void)plan;
+  const DevicePlanes S = c->sources.view(), T = c->targets.view();
+  if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  if (bx) launch_nn_scan(c->stream, c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
+  if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
+  if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+  launch_final_reduce(c->stream, c->jobs_dev, n_active, c->partials, c->sums_dev);
+  if (profile) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+  HIP_TRY(c, hipGetLastError());
+  if (c->comm && !local_only) {
+    const char* why = nullptr;
+    if (rccl_allreduce_f64_sum(c->comm, c->sums_dev, static_cast<size_t>(n_active) * MI355_ICP_NSUMS, c->stream, &why) != MI355_ICP_OK)
+      return fail(c, MI355_ICP_ERR_COMM, std::string("ncclAllReduce: ") + (why ? why : "?"));
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->sums_host, c->sums_dev, static_cast<size_t>(n_active) * MI355_ICP_NSUMS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->prof.iterations += 1;
+  c->prof.pairs_evaluated += pairs;
+  if (profile) {
+    float ms = 0.f;
+    if (bx) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->prof.nn_scan_ms += ms; c->prof.nn_scan_launches += 1; }
+    if (sbx) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->prof.resolve_ms += ms; c->prof.resolve_launches += 1; }
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->prof.reduce_ms += ms; c->prof.reduce_launches += 1;
+  }
+  return MI355_ICP_OK;
+}
+
+int check_error_flag(mi355_icp_ctx* c) {
+  HIP_TRY(c, hipMemcpyAsync(c->flag_host, c->error_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (*c->flag_host) c->err = "a non-finite distance was met during the scan (overflowing pose or coordinates)";
+  return MI355_ICP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mi355_icp_last_error(const mi355_icp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
+  if (!out) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count < 1) {
+    g_create_error = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+                     " (this engine has no CPU fallback)";
+    return MI355_ICP_ERR_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= count) {
+    g_create_error = "device_id out of range";
+    return MI355_ICP_ERR_INVALID_ARGUMENT;
+  }
+  mi355_icp_ctx* c = new (std::nothrow) mi355_icp_ctx();
+  if (!c) return MI355_ICP_ERR_INTERNAL;
+  c->device = device_id;
+  c->target_blocks = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks);
+  c->min_tiles_per_split = env_u32("MI355_ICP_MIN_TILES_PER_SPLIT", c->min_tiles_per_split);
+  auto bail = [&](const char* what, hipError_t err) {
+    g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+    mi355_icp_destroy(c);
+    return MI355_ICP_ERR_HIP;
+  };
+  if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  for (auto& ev : c->ev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipMalloc(reinterpret_cast<void**>(&c->error_flag), sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMemset(c->error_flag, 0, sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->flag_host), sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+  *out = c;
+  return MI355_ICP_OK;
+}
+
+void mi355_icp_destroy(mi355_icp_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) rccl_comm_destroy(c->comm);
+  for (auto& ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  (void)hipFree(c->targets.planes);
+  (void)hipFree(c->sources.planes);
+  (void)hipFree(c->keys);
+  (void)hipFree(c->out_index);
+  (void)hipFree(c->out_dist2);
+  (void)hipFree(c->partials);
+  (void)hipFree(c->sums_dev);
+  (void)hipFree(c->jobs_dev);
+  (void)hipFree(c->error_flag);
+  if (c->jobs_host) (void)hipHostFree(c->jobs_host);
+  if (c->sums_host) (void)hipHostFree(c->sums_host);
+  if (c->flag_host) (void)hipHostFree(c->flag_host);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int mi355_icp_set_targets(mi355_icp_ctx* ctx, int n_clouds, const float* const* xyz, const size_t* n_points, size_t stride_bytes) {
+  if (!ctx) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  ctx->err.clear();
+  return upload_clouds(ctx, ctx->targets, n_clouds, xyz, n_points, stride_bytes, kTile, kTargetPad, false, "set_targets");
+}
+
+int mi355_icp_set_sources(mi355_icp_ctx* ctx, int n_clouds, const float* const* xyz, const size_t* n_points, size_t stride_bytes) {
+  if (!ctx) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  ctx->err.clear();
+  return upload_clouds(ctx, ctx->sources, n_clouds, xyz, n_points, stride_bytes, kSrcPerBlock, 0.0f, true, "set_sources");
+}
+
+int mi355_icp_align(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* target_ids, const double* init_poses,
+                    const mi355_icp_params* params, double* out_poses, double* out_residual, int* out_iterations,
+                    int* out_status, int* out_converged) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  c->err.clear();
+  if (n_jobs < 1 || !init_poses || !params) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align: bad arguments");
+  if (params->max_iterations < 1) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align: max_iterations must be >= 1");
+  HIP_TRY(c, hipSetDevice(c->device));
+  Plan plan;
+  int st = make_plan(c, n_jobs, source_ids, target_ids, params->max_correspondence_distance, plan);
+  if (st != MI355_ICP_OK) return st;
+  if ((st = ensure_buffers(c, plan, static_cast<size_t>(n_jobs))) != MI355_ICP_OK) return st;
+  HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+
+  struct JobState { double pose[16]; double prev_mse = 0.0; double residual = 0.0; int iters = 0; int status = MI355_ICP_OK; int converged = 0; };
+  std::vector<JobState> js(static_cast<size_t>(n_jobs));
+  std::vector<int> active;
+  for (int k = 0; k < n_jobs; ++k) {
+    std::memcpy(js[k].pose, init_poses + 16 * static_cast<size_t>(k), sizeof(js[k].pose));
+    float tmp[12];
+    if (!pose_to_f32(js[k].pose, tmp)) return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "align: non-finite initial pose");
+    active.push_back(k);
+  }
+  const bool profile = (params->flags & MI355_ICP_FLAG_PROFILE) != 0;
+
+  for (int it = 0; it < params->max_iterations && !active.empty(); ++it) {
+    for (size_t a = 0; a < active.size(); ++a) {
+      JobDesc J = plan.jobs[static_cast<size_t>(active[a])];
+      if (!pose_to_f32(js[active[a]].pose, J.pose)) return fail(c, MI355_ICP_ERR_NUMERIC, "align: pose overflowed float32");
+      c->jobs_host[a] = J;
+    }
+    if ((st = run_pass(c, plan, static_cast<int>(active.size()), profile, false)) != MI355_ICP_OK) return st;
+    std::vector<int> next;
+    for (size_t a = 0; a < active.size(); ++a) {
+      JobState& s = js[active[a]];
+      int done = 0, conv = 0;
+      const int hs = host_update(params, c->sums_host + a * MI355_ICP_NSUMS, it, s.pose, &s.prev_mse, &done, &conv);
+      if (hs != MI355_ICP_OK) {
+        s.status = hs;  // pose left at the last valid value: candidate stays unrefined
+        continue;
+      }
+      s.iters = it + 1;
+      s.residual = std::sqrt(s.prev_mse);
+      s.converged = conv;
+      if (!done) next.push_back(active[a]);
+    }
+    active.swap(next);
+  }
+  if ((st = check_error_flag(c)) != MI355_ICP_OK) return st;
+  for (int k = 0; k < n_jobs; ++k) {
+    if (out_poses) std::memcpy(out_poses + 16 * static_cast<size_t>(k), js[k].pose, sizeof(js[k].pose));
+    if (out_residual) out_residual[k] = js[k].residual;
+    if (out_iterations) out_iterations[k] = js[k].iters;
+    if (out_status) out_status[k] = js[k].status;
+    if (out_converged) out_converged[k] = js[k].converged;
+  }
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_correspond(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* target_ids, const double* poses,
+                         float max_correspondence_distance, int32_t* out_index, float* out_dist2, double* out_sums) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  c->err.clear();
+  if (n_jobs < 1 || !poses) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "correspond: bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  Plan plan;
+  int st = make_plan(c, n_jobs, source_ids, target_ids, max_correspondence_distance, plan);
+  if (st != MI355_ICP_OK) return st;
+  if ((st = ensure_buffers(c, plan, static_cast<size_t>(n_jobs))) != MI355_ICP_OK) return st;
+  HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+  for (int k = 0; k < n_jobs; ++k) {
+    JobDesc J = plan.jobs[static_cast<size_t>(k)];
+    if (!pose_to_f32(poses + 16 * static_cast<size_t>(k), J.pose)) return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "correspond: non-finite pose");
+    c->jobs_host[k] = J;
+  }
+  if ((st = run_pass(c, plan, n_jobs, false, true)) != MI355_ICP_OK) return st;
+  if (out_sums) std::memcpy(out_sums, c->sums_host, static_cast<size_t>(n_jobs) * MI355_ICP_NSUMS * sizeof(double));
+  size_t cursor = 0;
+  for (int k = 0; k < n_jobs; ++k) {
+    const JobDesc& J = plan.jobs[static_cast<size_t>(k)];
+    if (J.src_n) {
+      if (out_index) HIP_TRY(c, hipMemcpy(out_index + cursor, c->out_index + J.out_off, J.src_n * sizeof(int32_t), hipMemcpyDeviceToHost));
+      if (out_dist2) HIP_TRY(c, hipMemcpy(out_dist2 + cursor, c->out_dist2 + J.out_off, J.src_n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    cursor += J.src_n;
+  }
+  return check_error_flag(c);
+}
+
+int mi355_icp_comm_unique_id(unsigned char out_id[MI355_ICP_UNIQUE_ID_BYTES]) {
+  if (!out_id) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  const char* why = nullptr;
+  const int st = rccl_unique_id(out_id, &why);
+  if (st != MI355_ICP_OK) g_create_error = std::string("ncclGetUniqueId: ") + (why ? why : "?");
+  return st;
+}
+
+int mi355_icp_comm_attach(mi355_icp_ctx* c, const unsigned char id[MI355_ICP_UNIQUE_ID_BYTES], int rank, int n_ranks) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "comm_attach: bad rank / size");
+  if (c->comm) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "comm_attach: a communicator is already attached");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const char* why = nullptr;
+  void* comm = nullptr;
+  if (rccl_comm_init(&comm, id, rank, n_ranks, &why) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_COMM, std::string("ncclCommInitRank: ") + (why ? why : "?"));
+  c->comm = comm;
+  c->comm_rank = rank;
+  c->comm_size = n_ranks;
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_comm_detach(mi355_icp_ctx* c) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  if (c->comm) {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    rccl_comm_destroy(c->comm);
+    c->comm = nullptr;
+    c->comm_rank = 0;
+    c->comm_size = 1;
+  }
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_get_profile(const mi355_icp_ctx* c, mi355_icp_profile* out) {
+  if (!c || !out) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  *out = c->prof;
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_reset_profile(mi355_icp_ctx* c) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  c->prof = mi355_icp_profile{};
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_device_info(const mi355_icp_ctx* c, char* name, size_t name_len, int* compute_units, size_t* total_mem) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return MI355_ICP_ERR_HIP;
+  if (name && name_len) {
+    std::snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (total_mem) *total_mem = prop.totalGlobalMem;
+  return MI355_ICP_OK;
+}
+
+}  // extern "C"

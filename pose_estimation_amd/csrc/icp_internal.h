@@ -1,0 +1,64 @@
+// icp_internal.h — declarations shared by the engine's translation units
+// (not part of the C-ABI; see include/mi355_icp.h for that).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/mi355_icp.h"
+
+namespace mi355 {
+
+// ---- geometry of the scan (compile-time; the kernels and the host planner agree on these) ----
+constexpr int kBlockThreads = 256;                       // 4 wave64 per workgroup
+constexpr int kPointsPerLane = 4;                        // source points register-blocked per lane
+constexpr int kSrcPerBlock = kBlockThreads * kPointsPerLane;  // 1024 source points per workgroup
+constexpr int kTile = 1024;                              // target points per LDS tile (12 KiB SoA, x2 buffers)
+constexpr int kChunk = 32;                               // granule at which the scan remembers "where the min fell"
+constexpr int kChunksPerTile = kTile / kChunk;
+constexpr float kTargetPad = 3.0e38f;                    // coordinate of padding targets: d2 overflows to +inf
+
+// One alignment job as the kernels see it (read with scalar loads; 96 bytes).
+struct JobDesc {
+  uint32_t src_off;          // first point of the source cloud in the source planes (multiple of kSrcPerBlock)
+  uint32_t src_n;            // real source points
+  uint32_t src_blocks;       // ceil(src_n / kSrcPerBlock)
+  uint32_t tgt_off;          // first point of the target cloud in the target planes (multiple of kTile)
+  uint32_t tgt_n;            // real target points
+  uint32_t tgt_tiles;        // ceil(tgt_n / kTile)
+  uint32_t n_split;          // the target range is cut into n_split runs of tiles_per_split tiles
+  uint32_t tiles_per_split;
+  uint32_t out_off;          // first slot of this job in the per-call outputs (keys, index, dist2)
+  uint32_t partial_off;      // first per-block partial-sum slot of this job
+  float max_d2;              // accept a pair iff d2 <= max_d2 (+inf keeps all)
+  uint32_t pad_;
+  float pose[12];            // float32 rounding of the row-major 3x4 [R|t] the pass is evaluated under
+};
+static_assert(sizeof(JobDesc) == 96, "JobDesc layout");
+
+// ---- host math (host_math.cpp) ----
+int solve_rigid(const double* sums, double* pose16);
+int host_update(const mi355_icp_params* p, const double* sums, int iteration, double* pose16, double* prev_mse,
+                int* out_done, int* out_converged);
+
+// ---- kernel launchers (icp_kernels.hip); all asynchronous on `stream` ----
+struct DevicePlanes {
+  const float* x;
+  const float* y;
+  const float* z;
+};
+void launch_nn_scan(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
+                    DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride);
+void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
+                    DevicePlanes tgt, const unsigned long long* keys, uint32_t key_stride, int32_t* out_index,
+                    float* out_dist2, double* partials, uint32_t* error_flag);
+void launch_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums);
+
+// ---- RCCL, bound at run time (rccl_dyn.cpp) ----
+struct RcclApi;
+const RcclApi* rccl_api(const char** why_not);
+int rccl_unique_id(unsigned char* out128, const char** err);
+int rccl_comm_init(void** comm, const unsigned char* id128, int rank, int n_ranks, const char** err);
+int rccl_allreduce_f64_sum(void* comm, double* dev_buf, size_t count, void* stream, const char** err);
+void rccl_comm_destroy(void* comm);
+
+}  // namespace mi355

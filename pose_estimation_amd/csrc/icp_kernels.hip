@@ -1,0 +1,338 @@
+// icp_kernels.hip — gfx950 (CDNA4) kernels of one ICP correspondence pass.
+//
+//   nn_scan_kernel            N1  fused source transform + brute-force exact 1-NN scan
+//   resolve_accumulate_kernel N1/N2  exact index recovery + centroid / cross-covariance partial sums
+//   final_reduce_kernel       N2  fixed-order reduction of the per-workgroup partials
+//
+// (N1/N2: SURVEY.md 8a.  In the reference this work is the KD-tree query and the
+// least-squares accumulation inside cv::ppf_match_3d::ICP::registerModelToScene,
+// called at pose_estimation/src/opencv_surface_match.cpp:94.)
+//
+// Arithmetic contract (bit-exact against oracle/icp_oracle.c): float32, every
+// product and sum rounded separately.  This file MUST be compiled with
+// -ffp-contract=off; csrc/Makefile greps the ISA for fused ops after the build.
+//
+// Why the scan is shaped this way.  8 float ops + a min per (source, target)
+// pair against 32 bytes of compulsory traffic per source point makes the scan
+// FP32-VALU-issue bound by four orders of magnitude, so the design
+// goal is "no VALU instruction that is not one of those nine":
+//   * a lane keeps kPointsPerLane source points in registers; the target tile is
+//     SoA in LDS and is read with wave-uniform ds_read_b128 (a broadcast: 3 LDS
+//     instructions feed 4 targets x 4 sources x 64 lanes = 1024 pairs);
+//   * the inner loop tracks only the running minimum (v_min3_f32 folds two
+//     candidates per instruction).  WHICH target won is not tracked per pair:
+//     once per 32-target chunk the lane notes whether its minimum improved, and
+//     the exact index is recovered afterwards by re-scanning that one chunk
+//     (resolve_accumulate_kernel) with the same arithmetic, where equality of
+//     the float32 bits identifies the winner and "first hit" gives the
+//     lowest-index tie rule of the oracle;
+//   * the target range is also split across workgroups so small clouds still
+//     fill 256 CUs; partial results are 64-bit keys (d2 bits << 32 | chunk id)
+//     whose unsigned minimum is the lowest distance, then the lowest chunk.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "icp_internal.h"
+
+namespace mi355 {
+
+namespace {
+
+__device__ __forceinline__ void transform_point(const float* __restrict__ m, float x, float y, float z, float& ox,
+                                                float& oy, float& oz) {
+  float a, b;
+  a = m[0] * x; b = m[1] * y; a = a + b; b = m[2] * z; a = a + b; ox = a + m[3];
+  a = m[4] * x; b = m[5] * y; a = a + b; b = m[6] * z; a = a + b; oy = a + m[7];
+  a = m[8] * x; b = m[9] * y; a = a + b; b = m[10] * z; a = a + b; oz = a + m[11];
+}
+
+__device__ __forceinline__ float dist2(float qx, float qy, float qz, float tx, float ty, float tz) {
+  const float dx = qx - tx, dy = qy - ty, dz = qz - tz;
+  float a = dx * dx;
+  const float b = dy * dy, c = dz * dz;
+  a = a + b;
+  return a + c;
+}
+
+__device__ __forceinline__ float min3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// N1: scan.  grid = (max_j src_blocks_j * n_split_j, n_jobs), block = 256.
+// Workgroup (sb, sp) of job j scans source points [sb*1024, +1024) against target tiles
+// [sp*tiles_per_split, +tiles_per_split) and writes one key per source point.
+__global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* __restrict__ jobs,
+                                                                 const float* __restrict__ sx,
+                                                                 const float* __restrict__ sy,
+                                                                 const float* __restrict__ sz,
+                                                                 const float* __restrict__ tx,
+                                                                 const float* __restrict__ ty,
+                                                                 const float* __restrict__ tz,
+                                                                 unsigned long long* __restrict__ keys,
+                                                                 uint32_t key_stride) {
+  // [buffer][plane][tile/4] float4: 2 x 12 KiB
+  __shared__ float4 lds[2][3][kTile / 4];
+
+  const JobDesc& J = jobs[blockIdx.y];
+  const uint32_t n_split = J.n_split;
+  const uint32_t sb = blockIdx.x / n_split;
+  const uint32_t sp = blockIdx.x - sb * n_split;
+  if (sb >= J.src_blocks) return;
+  const uint32_t tile0 = sp * J.tiles_per_split;
+  uint32_t tile1 = tile0 + J.tiles_per_split;
+  if (tile1 > J.tgt_tiles) tile1 = J.tgt_tiles;
+
+  const uint32_t tid = threadIdx.x;
+  float pose[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
+
+  float qx[kPointsPerLane], qy[kPointsPerLane], qz[kPointsPerLane];
+  float best[kPointsPerLane], prev[kPointsPerLane];
+  uint32_t cid[kPointsPerLane];
+  const uint32_t src_base = J.src_off + sb * kSrcPerBlock + tid;
+#pragma unroll
+  for (int p = 0; p < kPointsPerLane; ++p) {
+    const uint32_t i = src_base + p * kBlockThreads;  // planes are padded to whole blocks: always in bounds
+    transform_point(pose, sx[i], sy[i], sz[i], qx[p], qy[p], qz[p]);
+    best[p] = __builtin_inff();
+    prev[p] = __builtin_inff();
+    cid[p] = tile0 * kChunksPerTile;
+  }
+
+  const float4* __restrict__ gx = reinterpret_cast<const float4*>(tx + J.tgt_off);
+  const float4* __restrict__ gy = reinterpret_cast<const float4*>(ty + J.tgt_off);
+  const float4* __restrict__ gz = reinterpret_cast<const float4*>(tz + J.tgt_off);
+
+  // prologue: first tile -> LDS buffer 0 (target planes are padded to whole tiles)
+  {
+    const uint32_t g = tile0 * (kTile / 4) + tid;
+    lds[0][0][tid] = gx[g];
+    lds[0][1][tid] = gy[g];
+    lds[0][2][tid] = gz[g];
+  }
+  __syncthreads();
+
+  uint32_t cur = 0;
+  for (uint32_t tile = tile0; tile < tile1; ++tile) {
+    const bool more = tile + 1 < tile1;
+    float4 rx, ry, rz;
+    if (more) {  // prefetch the next tile into registers; its latency hides under this tile's scan
+      const uint32_t g = (tile + 1) * (kTile / 4) + tid;
+      rx = gx[g];
+      ry = gy[g];
+      rz = gz[g];
+    }
+    const float4* __restrict__ LX = lds[cur][0];
+    const float4* __restrict__ LY = lds[cur][1];
+    const float4* __restrict__ LZ = lds[cur][2];
+    const uint32_t chunk_base = tile * kChunksPerTile;
+    for (uint32_t c = 0; c < kChunksPerTile; ++c) {
+#pragma unroll
+      for (uint32_t g = 0; g < kChunk / 4; ++g) {
+        const float4 X = LX[c * (kChunk / 4) + g];  // wave-uniform address: LDS broadcast
+        const float4 Y = LY[c * (kChunk / 4) + g];
+        const float4 Z = LZ[c * (kChunk / 4) + g];
+#pragma unroll
+        for (int p = 0; p < kPointsPerLane; ++p) {
+          const float d0 = dist2(qx[p], qy[p], qz[p], X.x, Y.x, Z.x);
+          const float d1 = dist2(qx[p], qy[p], qz[p], X.y, Y.y, Z.y);
+          const float d2 = dist2(qx[p], qy[p], qz[p], X.z, Y.z, Z.z);
+          const float d3 = dist2(qx[p], qy[p], qz[p], X.w, Y.w, Z.w);
+          best[p] = min3(best[p], d0, d1);
+          best[p] = min3(best[p], d2, d3);
+        }
+      }
+      const uint32_t chunk = chunk_base + c;
+#pragma unroll
+      for (int p = 0; p < kPointsPerLane; ++p) {
+        if (best[p] < prev[p]) cid[p] = chunk;  // strict: the FIRST chunk that reaches the final minimum wins
+        prev[p] = best[p];
+      }
+    }
+    if (more) {
+      lds[cur ^ 1][0][tid] = rx;
+      lds[cur ^ 1][1][tid] = ry;
+      lds[cur ^ 1][2][tid] = rz;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  const uint32_t out = sp * key_stride + J.out_off + sb * kSrcPerBlock + tid;
+#pragma unroll
+  for (int p = 0; p < kPointsPerLane; ++p) {
+    const unsigned long long key =
+        (static_cast<unsigned long long>(__float_as_uint(best[p])) << 32) | static_cast<unsigned long long>(cid[p]);
+    keys[out + p * kBlockThreads] = key;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block-wide sum of NV doubles per thread, fixed order: xor-shuffle tree inside each wave64,
+// then waves 0..3 in order.  Result valid in threads 0..NV-1 of the block (value k in thread k).
+template <int NV>
+__device__ __forceinline__ double block_sum(double (&v)[NV], double (*scratch)[NV]) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double x = v[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    v[k] = x;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) scratch[wave][k] = v[k];
+  }
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x < NV) {
+    r = scratch[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kBlockThreads / 64; ++w) r += scratch[w][threadIdx.x];
+  }
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// N1 (index recovery) + N2 (accumulation).  grid = (max_j src_blocks_j, n_jobs), block = 256.
+// Same (block, lane, p) -> source point mapping as the scan.
+__global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
+    const JobDesc* __restrict__ jobs, const float* __restrict__ sx, const float* __restrict__ sy,
+    const float* __restrict__ sz, const float* __restrict__ tx, const float* __restrict__ ty,
+    const float* __restrict__ tz, const unsigned long long* __restrict__ keys, uint32_t key_stride,
+    int32_t* __restrict__ out_index, float* __restrict__ out_dist2, double* __restrict__ partials,
+    uint32_t* __restrict__ error_flag) {
+  __shared__ double scratch[kBlockThreads / 64][MI355_ICP_NSUMS];
+
+  const JobDesc& J = jobs[blockIdx.y];
+  const uint32_t sb = blockIdx.x;
+  if (sb >= J.src_blocks) return;
+  const uint32_t tid = threadIdx.x;
+  float pose[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
+  const float max_d2 = J.max_d2;
+  const uint32_t n_split = J.n_split;
+
+  double acc[MI355_ICP_NSUMS];
+#pragma unroll
+  for (int k = 0; k < MI355_ICP_NSUMS; ++k) acc[k] = 0.0;
+
+#pragma unroll 1
+  for (int p = 0; p < kPointsPerLane; ++p) {
+    const uint32_t local = sb * kSrcPerBlock + p * kBlockThreads + tid;
+    if (local < J.src_n) {
+      unsigned long long key = ~0ull;
+      for (uint32_t sp = 0; sp < n_split; ++sp) {
+        const unsigned long long k = keys[sp * key_stride + J.out_off + local];
+        key = k < key ? k : key;
+      }
+      const uint32_t best_bits = static_cast<uint32_t>(key >> 32);
+      const uint32_t chunk = static_cast<uint32_t>(key);
+      const uint32_t i = J.src_off + local;
+      const float s0x = sx[i], s0y = sy[i], s0z = sz[i];
+      float qx, qy, qz;
+      transform_point(pose, s0x, s0y, s0z, qx, qy, qz);
+
+      const uint32_t tbase = J.tgt_off + chunk * kChunk;
+      const float4* __restrict__ gx = reinterpret_cast<const float4*>(tx + tbase);
+      const float4* __restrict__ gy = reinterpret_cast<const float4*>(ty + tbase);
+      const float4* __restrict__ gz = reinterpret_cast<const float4*>(tz + tbase);
+      int found = -1;
+      float mx = 0.f, my = 0.f, mz = 0.f;
+#pragma unroll
+      for (int g = 0; g < kChunk / 4; ++g) {
+        const float4 X = gx[g], Y = gy[g], Z = gz[g];
+        const float xs[4] = {X.x, X.y, X.z, X.w};
+        const float ys[4] = {Y.x, Y.y, Y.z, Y.w};
+        const float zs[4] = {Z.x, Z.y, Z.z, Z.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = dist2(qx, qy, qz, xs[e], ys[e], zs[e]);
+          const bool hit = (found < 0) && (__float_as_uint(d) == best_bits);
+          if (hit) {
+            found = g * 4 + e;
+            mx = xs[e];
+            my = ys[e];
+            mz = zs[e];
+          }
+        }
+      }
+      if (found < 0) {
+        // Cannot happen for finite inputs (the scan and this loop evaluate identical expressions).
+        // With a NaN distance (overflowed transform) report the oracle's answer for "nothing below +inf".
+        atomicOr(error_flag, 1u);
+        found = 0;
+        mx = gx[0].x;
+        my = gy[0].x;
+        mz = gz[0].x;
+      }
+      const float best = __uint_as_float(best_bits);
+      const uint32_t o = J.out_off + local;
+      out_index[o] = static_cast<int32_t>(chunk * kChunk + static_cast<uint32_t>(found));
+      out_dist2[o] = best;
+      if (best <= max_d2) {
+        const double a0 = s0x, a1 = s0y, a2 = s0z, b0 = mx, b1 = my, b2 = mz;
+        acc[0] += 1.0;
+        acc[1] += a0; acc[2] += a1; acc[3] += a2;
+        acc[4] += b0; acc[5] += b1; acc[6] += b2;
+        acc[7] += a0 * b0; acc[8] += a0 * b1; acc[9] += a0 * b2;
+        acc[10] += a1 * b0; acc[11] += a1 * b1; acc[12] += a1 * b2;
+        acc[13] += a2 * b0; acc[14] += a2 * b1; acc[15] += a2 * b2;
+        acc[16] += static_cast<double>(best);
+      }
+    }
+  }
+
+  const double r = block_sum<MI355_ICP_NSUMS>(acc, scratch);
+  if (tid < MI355_ICP_NSUMS) partials[static_cast<size_t>(J.partial_off + sb) * MI355_ICP_NSUMS + tid] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// N2 final reduction: one workgroup per job sums that job's per-block partials in a fixed order
+// (thread t takes blocks t, t+256, ... ascending; then the block_sum tree), so a given cloud,
+// pose and slab always reduces to the same bits.
+__global__ __launch_bounds__(kBlockThreads) void final_reduce_kernel(const JobDesc* __restrict__ jobs,
+                                                                      const double* __restrict__ partials,
+                                                                      double* __restrict__ sums) {
+  __shared__ double scratch[kBlockThreads / 64][MI355_ICP_NSUMS];
+  const JobDesc& J = jobs[blockIdx.x];
+  double acc[MI355_ICP_NSUMS];
+#pragma unroll
+  for (int k = 0; k < MI355_ICP_NSUMS; ++k) acc[k] = 0.0;
+  for (uint32_t b = threadIdx.x; b < J.src_blocks; b += kBlockThreads) {
+    const double* __restrict__ row = partials + static_cast<size_t>(J.partial_off + b) * MI355_ICP_NSUMS;
+#pragma unroll
+    for (int k = 0; k < MI355_ICP_NSUMS; ++k) acc[k] += row[k];
+  }
+  const double r = block_sum<MI355_ICP_NSUMS>(acc, scratch);
+  if (threadIdx.x < MI355_ICP_NSUMS) sums[static_cast<size_t>(blockIdx.x) * MI355_ICP_NSUMS + threadIdx.x] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+void launch_nn_scan(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
+                    DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride) {
+  dim3 grid(max_blocks_x, static_cast<uint32_t>(n_jobs));
+  hipLaunchKernelGGL(nn_scan_kernel, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x,
+                     src.y, src.z, tgt.x, tgt.y, tgt.z, keys, key_stride);
+}
+
+void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
+                    DevicePlanes tgt, const unsigned long long* keys, uint32_t key_stride, int32_t* out_index,
+                    float* out_dist2, double* partials, uint32_t* error_flag) {
+  dim3 grid(max_src_blocks, static_cast<uint32_t>(n_jobs));
+  hipLaunchKernelGGL(resolve_accumulate_kernel, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
+                     jobs_dev, src.x, src.y, src.z, tgt.x, tgt.y, tgt.z, keys, key_stride, out_index, out_dist2,
+                     partials, error_flag);
+}
+
+void launch_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums) {
+  hipLaunchKernelGGL(final_reduce_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0,
+                     static_cast<hipStream_t>(stream), jobs_dev, partials, sums);
+}
+
+}  // namespace mi355

@@ -1,0 +1,245 @@
+"""IcpEngine: Python handle on one mi355_icp_ctx (include/mi355_icp.h).
+
+Thin by design: numpy arrays in, numpy arrays out, every call goes through the C-ABI.
+The alignment arithmetic lives in csrc/ (HIP kernels + host Kabsch); nothing here computes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, Params, Profile, NSUMS
+
+
+class IcpError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"mi355_icp: {_lib.STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+def default_params(**overrides) -> Params:
+    p = Params()
+    lib.mi355_icp_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise TypeError(f"unknown ICP parameter {k!r}")
+        setattr(p, k, v)
+    return p
+
+
+def params_from_reference(iterations: int, tolerance: float = 0.05, rejection_scale: float = 2.5,
+                          num_levels: int = 6) -> Params:
+    """Maps cv::ppf_match_3d::ICP(iterations, tolerance, rejectionScale, numLevels)
+    (reference opencv_surface_match.cpp:85) onto engine parameters."""
+    p = Params()
+    st = lib.mi355_icp_params_from_reference(iterations, tolerance, rejection_scale, num_levels, C.byref(p))
+    if st != _lib.OK:
+        raise IcpError(st, "params_from_reference")
+    return p
+
+
+def slab_range(n: int, rank: int, n_ranks: int) -> tuple[int, int]:
+    b, c = C.c_size_t(), C.c_size_t()
+    st = lib.mi355_icp_slab_range(n, rank, n_ranks, C.byref(b), C.byref(c))
+    if st != _lib.OK:
+        raise IcpError(st, "slab_range")
+    return b.value, c.value
+
+
+def solve_rigid(sums: np.ndarray) -> np.ndarray:
+    sums = np.ascontiguousarray(sums, dtype=np.float64)
+    assert sums.shape == (NSUMS,)
+    out = np.empty(16, dtype=np.float64)
+    st = lib.mi355_icp_solve_rigid(sums.ctypes.data, out.ctypes.data)
+    if st != _lib.OK:
+        raise IcpError(st, "solve_rigid")
+    return out.reshape(4, 4)
+
+
+def host_update(params: Params, sums: np.ndarray, iteration: int, pose: np.ndarray, prev_mse: float):
+    """One step of the host iteration controller. Returns (status, new_pose, mse, done, converged)."""
+    sums = np.ascontiguousarray(sums, dtype=np.float64)
+    p = np.array(pose, dtype=np.float64).reshape(16).copy()
+    mse = C.c_double(prev_mse)
+    done, conv = C.c_int(0), C.c_int(0)
+    st = lib.mi355_icp_host_update(C.byref(params), sums.ctypes.data, iteration, p.ctypes.data, C.byref(mse),
+                                   C.byref(done), C.byref(conv))
+    return st, p.reshape(4, 4), mse.value, bool(done.value), bool(conv.value)
+
+
+def pose_to_pose7(pose: np.ndarray, reference_packing: bool = False) -> np.ndarray:
+    p = np.ascontiguousarray(pose, dtype=np.float64).reshape(16)
+    out = np.zeros(7, dtype=np.float32)
+    st = lib.mi355_icp_pose_to_pose7(p.ctypes.data, out.ctypes.data, int(reference_packing))
+    if st != _lib.OK:
+        raise IcpError(st, "pose_to_pose7")
+    return out
+
+
+def synth_cloud(seed: int, count: int, first_index: int = 0, noise_seed: int = 0, sigma: float = 0.0,
+                transform: Optional[np.ndarray] = None) -> np.ndarray:
+    """Deterministic synthetic surface sample (csrc/synth.c), float32 [count, 3]."""
+    out = np.empty((count, 3), dtype=np.float32)
+    t = None
+    if transform is not None:
+        t = np.ascontiguousarray(np.asarray(transform, dtype=np.float64)[:3, :4]).reshape(12)
+    st = lib.mi355_icp_synth_cloud(seed, noise_seed, float(sigma), t.ctypes.data if t is not None else None,
+                                   first_index, count, out.ctypes.data)
+    if st != _lib.OK:
+        raise IcpError(st, "synth_cloud")
+    return out
+
+
+@dataclass
+class AlignResult:
+    poses: np.ndarray       # [n_jobs, 4, 4] float64
+    residual: np.ndarray    # [n_jobs] RMS correspondence distance of the last pass
+    iterations: np.ndarray  # [n_jobs] int32
+    status: np.ndarray      # [n_jobs] int32 (0 = OK)
+    converged: np.ndarray   # [n_jobs] int32
+
+
+def _cloud_ptrs(clouds: Sequence[np.ndarray]):
+    keep, ptrs, counts, stride = [], [], [], None
+    for a in clouds:
+        a = np.asarray(a)
+        if a.dtype != np.float32 or a.ndim != 2 or a.shape[1] < 3:
+            raise TypeError("clouds must be float32 arrays of shape [N, >=3] (xyz first)")
+        if a.shape[0] and (a.strides[1] != 4 or a.strides[0] % 4 != 0 or a.strides[0] < 12):
+            a = np.ascontiguousarray(a)
+        s = a.strides[0] if a.shape[0] else 4 * a.shape[1]
+        if stride is None:
+            stride = s
+        elif s != stride:
+            a = np.ascontiguousarray(a[:, :3])
+            if 12 != stride:
+                raise TypeError("all clouds of one upload must share a row stride")
+        keep.append(a)
+        ptrs.append(a.ctypes.data if a.shape[0] else None)
+        counts.append(a.shape[0])
+    arr_p = (C.c_void_p * len(ptrs))(*ptrs)
+    arr_n = (C.c_size_t * len(counts))(*counts)
+    return keep, arr_p, arr_n, stride
+
+
+class IcpEngine:
+    """One engine per GPU. Not thread-safe (the reference calls this path from one executor thread)."""
+
+    def __init__(self, device_id: int = 0):
+        h = C.c_void_p()
+        st = lib.mi355_icp_create(device_id, C.byref(h))
+        if st != _lib.OK:
+            raise IcpError(st, lib.mi355_icp_last_error(None).decode())
+        self._h = h
+        self.n_targets = 0
+        self.n_sources = 0
+        self._source_sizes: list[int] = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.mi355_icp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, st: int):
+        if st != _lib.OK:
+            raise IcpError(st, lib.mi355_icp_last_error(self._h).decode())
+
+    def last_error(self) -> str:
+        return lib.mi355_icp_last_error(self._h).decode()
+
+    # -- clouds
+    def set_targets(self, clouds: Sequence[np.ndarray]):
+        keep, p, n, stride = _cloud_ptrs(clouds)
+        self._check(lib.mi355_icp_set_targets(self._h, len(keep), p, n, stride))
+        self.n_targets = len(keep)
+
+    def set_sources(self, clouds: Sequence[np.ndarray]):
+        keep, p, n, stride = _cloud_ptrs(clouds)
+        self._check(lib.mi355_icp_set_sources(self._h, len(keep), p, n, stride))
+        self.n_sources = len(keep)
+        self._source_sizes = [a.shape[0] for a in keep]
+
+    # -- alignment
+    @staticmethod
+    def _ids(ids, n_jobs):
+        a = np.zeros(n_jobs, dtype=np.int32) if ids is None else np.ascontiguousarray(ids, dtype=np.int32)
+        assert a.shape == (n_jobs,)
+        return a
+
+    def align(self, init_poses: np.ndarray, params: Params, source_ids=None, target_ids=None) -> AlignResult:
+        poses = np.ascontiguousarray(init_poses, dtype=np.float64).reshape(-1, 16)
+        n = poses.shape[0]
+        sid, tid = self._ids(source_ids, n), self._ids(target_ids, n)
+        out_p = np.empty((n, 16), dtype=np.float64)
+        out_r = np.empty(n, dtype=np.float64)
+        out_i = np.empty(n, dtype=np.int32)
+        out_s = np.empty(n, dtype=np.int32)
+        out_c = np.empty(n, dtype=np.int32)
+        self._check(lib.mi355_icp_align(self._h, n, sid.ctypes.data, tid.ctypes.data, poses.ctypes.data,
+                                        C.byref(params), out_p.ctypes.data, out_r.ctypes.data, out_i.ctypes.data,
+                                        out_s.ctypes.data, out_c.ctypes.data))
+        return AlignResult(out_p.reshape(n, 4, 4), out_r, out_i, out_s, out_c)
+
+    def correspond(self, poses: np.ndarray, max_correspondence_distance: float = 0.0, source_ids=None,
+                   target_ids=None, want_pairs: bool = True):
+        """One correspondence pass. Returns (index int32 [sum Ns], dist2 float32 [sum Ns], sums [n_jobs, 17])."""
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 16)
+        n = poses.shape[0]
+        sid, tid = self._ids(source_ids, n), self._ids(target_ids, n)
+        total = int(sum(self._source_sizes[s] for s in sid))
+        idx = np.empty(total, dtype=np.int32) if want_pairs else None
+        d2 = np.empty(total, dtype=np.float32) if want_pairs else None
+        sums = np.empty((n, NSUMS), dtype=np.float64)
+        self._check(lib.mi355_icp_correspond(self._h, n, sid.ctypes.data, tid.ctypes.data, poses.ctypes.data,
+                                             float(max_correspondence_distance),
+                                             idx.ctypes.data if want_pairs else None,
+                                             d2.ctypes.data if want_pairs else None, sums.ctypes.data))
+        return idx, d2, sums
+
+    # -- multi-GPU
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (C.c_ubyte * _lib.UNIQUE_ID_BYTES)()
+        st = lib.mi355_icp_comm_unique_id(buf)
+        if st != _lib.OK:
+            raise IcpError(st, lib.mi355_icp_last_error(None).decode())
+        return bytes(buf)
+
+    def comm_attach(self, unique_id: bytes, rank: int, n_ranks: int):
+        assert len(unique_id) == _lib.UNIQUE_ID_BYTES
+        buf = (C.c_ubyte * _lib.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(lib.mi355_icp_comm_attach(self._h, buf, rank, n_ranks))
+
+    def comm_detach(self):
+        self._check(lib.mi355_icp_comm_detach(self._h))
+
+    # -- measurement
+    def profile(self) -> Profile:
+        p = Profile()
+        self._check(lib.mi355_icp_get_profile(self._h, C.byref(p)))
+        return p
+
+    def reset_profile(self):
+        self._check(lib.mi355_icp_reset_profile(self._h))
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(128)
+        cu, mem = C.c_int(), C.c_size_t()
+        self._check(lib.mi355_icp_device_info(self._h, name, 128, C.byref(cu), C.byref(mem)))
+        return {"name": name.value.decode(), "compute_units": cu.value, "total_mem": mem.value}
