@@ -1,0 +1,91 @@
+"""The C-ABI library loads, exports every symbol include/mi355_icp.h declares, and refuses to
+compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import pose_estimation_amd as pa
+from pose_estimation_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mi355_icp.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi355_icp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (mi355_icp_[a-z0-9_]+)", out))
+    assert set(syms) <= exported, sorted(set(syms) - exported)
+    assert set(syms) == set(_lib.SIGNATURES), (sorted(set(syms) ^ set(_lib.SIGNATURES)))
+    assert exported == set(syms), "library exports undeclared mi355_icp_* symbols"
+
+
+def test_header_compiles_as_c_and_struct_layout_matches_ctypes(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include <stdio.h>\n#include "mi355_icp.h"\nint main(void){printf("%zu %zu %d %d\\n",'
+                   'sizeof(mi355_icp_params),sizeof(mi355_icp_profile),MI355_ICP_NSUMS,MI355_ICP_UNIQUE_ID_BYTES);return 0;}\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    a, b, n, u = map(int, subprocess.check_output([str(exe)], text=True).split())
+    assert a == C.sizeof(_lib.Params) and b == C.sizeof(_lib.Profile) and n == _lib.NSUMS and u == _lib.UNIQUE_ID_BYTES
+
+
+def test_library_has_gfx950_code_object_and_no_oracle_dependency():
+    out = subprocess.check_output(["readelf", "-d", _lib.LIB_PATH], text=True)
+    assert "libamdhip64" in out and "oracle" not in out
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"nn_scan_kernel" in blob
+
+
+def test_product_sources_never_touch_the_oracle():
+    pkg = os.path.join(ROOT, "pose_estimation_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", ".c", "Makefile")):
+                text = open(os.path.join(dp, f), errors="ignore").read()
+                # comments may cite the oracle as the arithmetic contract; code may not include/import/load it
+                assert "oracle_lib" not in text and "libicp_oracle" not in text, f
+                assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', text), f
+                assert not re.search(r"^\s*(from|import)\s+\S*oracle", text, flags=re.M), f
+                assert not re.search(r"oracle_[a-z_]+\s*\(", text), f
+
+
+def test_host_entry_points_validate_arguments():
+    assert _lib.lib.mi355_icp_abi_version() == 1
+    assert _lib.lib.mi355_icp_solve_rigid(None, None) == _lib.ERR_INVALID_ARGUMENT
+    b, c = C.c_size_t(), C.c_size_t()
+    assert _lib.lib.mi355_icp_slab_range(10, 3, 2, C.byref(b), C.byref(c)) == _lib.ERR_INVALID_ARGUMENT
+    p = _lib.Params()
+    assert _lib.lib.mi355_icp_params_from_reference(0, 0.1, 2.5, 8, C.byref(p)) == _lib.ERR_INVALID_ARGUMENT
+    assert _lib.lib.mi355_icp_align(None, 1, None, None, None, None, None, None, None, None, None) == _lib.ERR_INVALID_ARGUMENT
+    assert _lib.lib.mi355_icp_last_error(None) is not None
+
+
+def _gpu_visible():
+    try:
+        out = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=20).stdout
+        return "gfx9" in out
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_gpu_visible(), reason="a GPU is visible: the no-device path cannot be observed")
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    with pytest.raises(pa.IcpError) as e:
+        pa.IcpEngine(0)
+    assert e.value.status == _lib.ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
+    icp = pa.ICP(250, 0.005, 2.5, 8)
+    pts = np.zeros((10, 3), dtype=np.float32)
+    with pytest.raises(pa.IcpError):
+        icp.registerModelToScene(pts, pts, [pa.Pose3D()])

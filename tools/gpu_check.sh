@@ -1,0 +1,20 @@
+#!/bin/bash
+# Runs on the GPU box via gpurun: micro-benchmark (optional), GPU parity tests, smoke, short bench.
+# A step that is killed by its timeout ends the script (no further GPU work after a hang).
+set -u
+mkdir -p gpurun_out
+step() {  # step <seconds> <logfile> <cmd...>
+  local secs=$1 log=$2; shift 2
+  echo "== $* (limit ${secs}s)" | tee -a gpurun_out/steps.log
+  timeout -k 10 "$secs" "$@" > "gpurun_out/$log" 2>&1
+  local rc=$?
+  echo "rc=$rc $log" | tee -a gpurun_out/steps.log
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $log: stopping" | tee -a gpurun_out/steps.log; exit 99; fi
+  return $rc
+}
+: > gpurun_out/steps.log
+if [ "${UBENCH:-0}" = "1" ]; then step 120 ubench.txt ./build/ubench_valu; fi
+step 900 pytest_gpu.txt python -m pytest tests -m gpu -x -q
+step 300 smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
+step 400 bench.txt python bench.py --steps "${STEPS:-3}" --warmup 1
+tail -5 gpurun_out/pytest_gpu.txt; tail -2 gpurun_out/smoke.txt; tail -1 gpurun_out/bench.txt
