@@ -85,6 +85,7 @@ struct mi355_icp_ctx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   mi355_icp_profile prof{};
 
+  int scan_ppl = 4;                  // source points per lane in the scan kernel (2, 4 or 8)
   uint32_t target_blocks = 6144;     // planner: aim for about this many scan workgroups per launch
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
 };
@@ -195,12 +196,13 @@ int make_plan(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* ta
   if (c->sources.clouds.empty()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "no source clouds uploaded (mi355_icp_set_sources)");
   plan = Plan{};
   plan.jobs.resize(static_cast<size_t>(n_jobs));
+  const uint32_t scan_src = static_cast<uint32_t>(kBlockThreads * c->scan_ppl);
   uint64_t total_src_blocks = 0;
   for (int k = 0; k < n_jobs; ++k) {
     const int s = source_ids ? source_ids[k] : 0, t = target_ids ? target_ids[k] : 0;
     if (s < 0 || static_cast<size_t>(s) >= c->sources.clouds.size()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "source id out of range");
     if (t < 0 || static_cast<size_t>(t) >= c->targets.clouds.size()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "target id out of range");
-    total_src_blocks += c->sources.clouds[s].padded / kSrcPerBlock;
+    total_src_blocks += (c->sources.clouds[s].n + scan_src - 1) / scan_src;
   }
   float max_d2 = std::numeric_limits<float>::infinity();
   if (max_corr > 0.0f) max_d2 = max_corr * max_corr;  // float32 product, as the oracle
@@ -214,7 +216,8 @@ int make_plan(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* ta
     std::memset(&J, 0, sizeof(J));
     J.src_off = S.off;
     J.src_n = S.n;
-    J.src_blocks = S.padded / kSrcPerBlock;
+    J.src_blocks = (S.n + kSrcPerBlock - 1) / kSrcPerBlock;
+    J.scan_blocks = (S.n + scan_src - 1) / scan_src;
     J.tgt_off = T.off;
     J.tgt_n = T.n;
     J.tgt_tiles = T.padded / kTile;
@@ -229,7 +232,7 @@ int make_plan(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* ta
     partial_off += J.src_blocks;
     if (out_off > 0xFFFF0000ull) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "batch too large");
     plan.max_split = std::max(plan.max_split, J.n_split);
-    plan.max_blocks_x = std::max(plan.max_blocks_x, J.src_blocks * J.n_split);
+    plan.max_blocks_x = std::max(plan.max_blocks_x, J.scan_blocks * J.n_split);
     plan.max_src_blocks = std::max(plan.max_src_blocks, J.src_blocks);
   }
   plan.out_total = static_cast<uint32_t>(out_off);
@@ -257,14 +260,14 @@ int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, boo
   double pairs = 0.0;
   for (int k = 0; k < n_active; ++k) {
     const JobDesc& J = c->jobs_host[k];
-    bx = std::max(bx, J.src_blocks * J.n_split);
+    bx = std::max(bx, J.scan_blocks * J.n_split);
     sbx = std::max(sbx, J.src_blocks);
     pairs += static_cast<double>(J.src_n) * static_cast<double>(J.tgt_n);
   }
   (void)plan;
   const DevicePlanes S = c->sources.view(), T = c->targets.view();
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-  if (bx) launch_nn_scan(c->stream, c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
+  if (bx) launch_nn_scan(c->stream, c->scan_ppl, c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
   if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
@@ -319,6 +322,10 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   mi355_icp_ctx* c = new (std::nothrow) mi355_icp_ctx();
   if (!c) return MI355_ICP_ERR_INTERNAL;
   c->device = device_id;
+  {
+    const uint32_t ppl = env_u32("MI355_ICP_SCAN_PPL", static_cast<uint32_t>(c->scan_ppl));
+    if (ppl == 2 || ppl == 4 || ppl == 8) c->scan_ppl = static_cast<int>(ppl);
+  }
   c->target_blocks = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks);
   c->min_tiles_per_split = env_u32("MI355_ICP_MIN_TILES_PER_SPLIT", c->min_tiles_per_split);
   auto bail = [&](const char* what, hipError_t err) {
@@ -369,7 +376,7 @@ int mi355_icp_set_targets(mi355_icp_ctx* ctx, int n_clouds, const float* const* 
 int mi355_icp_set_sources(mi355_icp_ctx* ctx, int n_clouds, const float* const* xyz, const size_t* n_points, size_t stride_bytes) {
   if (!ctx) return MI355_ICP_ERR_INVALID_ARGUMENT;
   ctx->err.clear();
-  return upload_clouds(ctx, ctx->sources, n_clouds, xyz, n_points, stride_bytes, kSrcPerBlock, 0.0f, true, "set_sources");
+  return upload_clouds(ctx, ctx->sources, n_clouds, xyz, n_points, stride_bytes, kSrcPad, 0.0f, true, "set_sources");
 }
 
 int mi355_icp_align(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* target_ids, const double* init_poses,

@@ -10,8 +10,10 @@ namespace mi355 {
 
 // ---- geometry of the scan (compile-time; the kernels and the host planner agree on these) ----
 constexpr int kBlockThreads = 256;                       // 4 wave64 per workgroup
-constexpr int kPointsPerLane = 4;                        // source points register-blocked per lane
-constexpr int kSrcPerBlock = kBlockThreads * kPointsPerLane;  // 1024 source points per workgroup
+constexpr int kResolvePointsPerLane = 4;                 // resolve/accumulate: source points per lane
+constexpr int kSrcPerBlock = kBlockThreads * kResolvePointsPerLane;  // 1024: resolve workgroup / partial-sum granule
+constexpr int kMaxScanPointsPerLane = 8;                 // the scan register-blocks 2, 4 or 8 source points per lane
+constexpr int kSrcPad = kBlockThreads * kMaxScanPointsPerLane;       // source clouds are padded to 2048 points
 constexpr int kTile = 1024;                              // target points per LDS tile (12 KiB SoA, x2 buffers)
 constexpr int kChunk = 32;                               // granule at which the scan remembers "where the min fell"
 constexpr int kChunksPerTile = kTile / kChunk;
@@ -21,7 +23,7 @@ constexpr float kTargetPad = 3.0e38f;                    // coordinate of paddin
 struct JobDesc {
   uint32_t src_off;          // first point of the source cloud in the source planes (multiple of kSrcPerBlock)
   uint32_t src_n;            // real source points
-  uint32_t src_blocks;       // ceil(src_n / kSrcPerBlock)
+  uint32_t src_blocks;       // ceil(src_n / kSrcPerBlock): resolve workgroups / partial rows
   uint32_t tgt_off;          // first point of the target cloud in the target planes (multiple of kTile)
   uint32_t tgt_n;            // real target points
   uint32_t tgt_tiles;        // ceil(tgt_n / kTile)
@@ -30,7 +32,7 @@ struct JobDesc {
   uint32_t out_off;          // first slot of this job in the per-call outputs (keys, index, dist2)
   uint32_t partial_off;      // first per-block partial-sum slot of this job
   float max_d2;              // accept a pair iff d2 <= max_d2 (+inf keeps all)
-  uint32_t pad_;
+  uint32_t scan_blocks;      // ceil(src_n / (256 * points_per_lane)): scan workgroups along the source
   float pose[12];            // float32 rounding of the row-major 3x4 [R|t] the pass is evaluated under
 };
 static_assert(sizeof(JobDesc) == 96, "JobDesc layout");
@@ -46,8 +48,8 @@ struct DevicePlanes {
   const float* y;
   const float* z;
 };
-void launch_nn_scan(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
-                    DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride);
+void launch_nn_scan(void* stream, int points_per_lane, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x,
+                    DevicePlanes src, DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride);
 void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
                     DevicePlanes tgt, const unsigned long long* keys, uint32_t key_stride, int32_t* out_index,
                     float* out_dist2, double* partials, uint32_t* error_flag);

@@ -16,7 +16,7 @@
 // pair against 32 bytes of compulsory traffic per source point makes the scan
 // FP32-VALU-issue bound by four orders of magnitude, so the design
 // goal is "no VALU instruction that is not one of those nine":
-//   * a lane keeps kPointsPerLane source points in registers; the target tile is
+//   * a lane keeps 2, 4 or 8 source points in registers (template parameter); the target tile is
 //     SoA in LDS and is read with wave-uniform ds_read_b128 (a broadcast: 3 LDS
 //     instructions feed 4 targets x 4 sources x 64 lanes = 1024 pairs);
 //   * the inner loop tracks only the running minimum (v_min3_f32 folds two
@@ -61,8 +61,9 @@ __device__ __forceinline__ float min3(float a, float b, float c) { return __buil
 
 // ---------------------------------------------------------------------------------------------
 // N1: scan.  grid = (max_j src_blocks_j * n_split_j, n_jobs), block = 256.
-// Workgroup (sb, sp) of job j scans source points [sb*1024, +1024) against target tiles
+// Workgroup (sb, sp) of job j scans source points [sb*256*P, +256*P) against target tiles
 // [sp*tiles_per_split, +tiles_per_split) and writes one key per source point.
+template <int kPointsPerLane>
 __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* __restrict__ jobs,
                                                                  const float* __restrict__ sx,
                                                                  const float* __restrict__ sy,
@@ -79,7 +80,8 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
   const uint32_t n_split = J.n_split;
   const uint32_t sb = blockIdx.x / n_split;
   const uint32_t sp = blockIdx.x - sb * n_split;
-  if (sb >= J.src_blocks) return;
+  if (sb >= J.scan_blocks) return;
+  constexpr uint32_t kScanSrcPerBlock = kBlockThreads * kPointsPerLane;
   const uint32_t tile0 = sp * J.tiles_per_split;
   uint32_t tile1 = tile0 + J.tiles_per_split;
   if (tile1 > J.tgt_tiles) tile1 = J.tgt_tiles;
@@ -92,10 +94,10 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
   float qx[kPointsPerLane], qy[kPointsPerLane], qz[kPointsPerLane];
   float best[kPointsPerLane], prev[kPointsPerLane];
   uint32_t cid[kPointsPerLane];
-  const uint32_t src_base = J.src_off + sb * kSrcPerBlock + tid;
+  const uint32_t src_base = J.src_off + sb * kScanSrcPerBlock + tid;
 #pragma unroll
   for (int p = 0; p < kPointsPerLane; ++p) {
-    const uint32_t i = src_base + p * kBlockThreads;  // planes are padded to whole blocks: always in bounds
+    const uint32_t i = src_base + p * kBlockThreads;  // planes are padded to kSrcPad points: always in bounds
     transform_point(pose, sx[i], sy[i], sz[i], qx[p], qy[p], qz[p]);
     best[p] = __builtin_inff();
     prev[p] = __builtin_inff();
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
     cur ^= 1;
   }
 
-  const uint32_t out = sp * key_stride + J.out_off + sb * kSrcPerBlock + tid;
+  const uint32_t out = sp * key_stride + J.out_off + sb * kScanSrcPerBlock + tid;
 #pragma unroll
   for (int p = 0; p < kPointsPerLane; ++p) {
     const unsigned long long key =
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
   for (int k = 0; k < MI355_ICP_NSUMS; ++k) acc[k] = 0.0;
 
 #pragma unroll 1
-  for (int p = 0; p < kPointsPerLane; ++p) {
+  for (int p = 0; p < kResolvePointsPerLane; ++p) {
     const uint32_t local = sb * kSrcPerBlock + p * kBlockThreads + tid;
     if (local < J.src_n) {
       unsigned long long key = ~0ull;
@@ -314,11 +316,24 @@ __global__ __launch_bounds__(kBlockThreads) void final_reduce_kernel(const JobDe
 }
 
 // ---------------------------------------------------------------------------------------------
-void launch_nn_scan(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
-                    DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride) {
+void launch_nn_scan(void* stream, int points_per_lane, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x,
+                    DevicePlanes src, DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride) {
   dim3 grid(max_blocks_x, static_cast<uint32_t>(n_jobs));
-  hipLaunchKernelGGL(nn_scan_kernel, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x,
-                     src.y, src.z, tgt.x, tgt.y, tgt.z, keys, key_stride);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (points_per_lane) {
+    case 2:
+      hipLaunchKernelGGL(nn_scan_kernel<2>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tgt.x,
+                         tgt.y, tgt.z, keys, key_stride);
+      break;
+    case 8:
+      hipLaunchKernelGGL(nn_scan_kernel<8>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tgt.x,
+                         tgt.y, tgt.z, keys, key_stride);
+      break;
+    default:
+      hipLaunchKernelGGL(nn_scan_kernel<4>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tgt.x,
+                         tgt.y, tgt.z, keys, key_stride);
+      break;
+  }
 }
 
 void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
