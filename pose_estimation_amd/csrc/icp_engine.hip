@@ -45,6 +45,7 @@ struct Plan {
   uint32_t max_split = 1;
   uint32_t max_blocks_x = 0;   // scan grid.x
   uint32_t max_src_blocks = 0; // resolve grid.x
+  int scan_ppl = 8;            // source points per lane the scan kernel is launched with
 };
 
 uint32_t env_u32(const char* name, uint32_t dflt) {
@@ -85,8 +86,8 @@ struct mi355_icp_ctx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   mi355_icp_profile prof{};
 
-  int scan_ppl = 4;                  // source points per lane in the scan kernel (2, 4 or 8)
-  uint32_t target_blocks = 6144;     // planner: aim for about this many scan workgroups per launch
+  int scan_ppl = 0;                  // scan points-per-lane override (2, 4, 8); 0 = planner decides per call
+  uint32_t target_blocks = 12288;    // planner: aim for about this many scan workgroups per launch
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
 };
 
@@ -196,14 +197,21 @@ int make_plan(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* ta
   if (c->sources.clouds.empty()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "no source clouds uploaded (mi355_icp_set_sources)");
   plan = Plan{};
   plan.jobs.resize(static_cast<size_t>(n_jobs));
-  const uint32_t scan_src = static_cast<uint32_t>(kBlockThreads * c->scan_ppl);
-  uint64_t total_src_blocks = 0;
+  double total_pairs = 0.0;
   for (int k = 0; k < n_jobs; ++k) {
     const int s = source_ids ? source_ids[k] : 0, t = target_ids ? target_ids[k] : 0;
     if (s < 0 || static_cast<size_t>(s) >= c->sources.clouds.size()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "source id out of range");
     if (t < 0 || static_cast<size_t>(t) >= c->targets.clouds.size()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "target id out of range");
-    total_src_blocks += (c->sources.clouds[s].n + scan_src - 1) / scan_src;
+    total_pairs += static_cast<double>(c->sources.clouds[s].n) * static_cast<double>(c->targets.clouds[t].n);
   }
+  // Register blocking of the scan: 8 points per lane is the fastest steady state (fewest LDS reads per pair) but
+  // makes the coarsest workgroups; below ~4e11 pairs per launch the finer 2-point workgroups balance the 256 CUs
+  // better and win (profiles/r01b_scan_ab_sizes.txt: 1M<->1M 135 vs 141 ms; 64x50k<->50k 24.3 vs 21.5 ms).
+  plan.scan_ppl = c->scan_ppl ? c->scan_ppl : (total_pairs >= 4e11 ? 8 : 2);
+  const uint32_t scan_src = static_cast<uint32_t>(kBlockThreads * plan.scan_ppl);
+  uint64_t total_src_blocks = 0;
+  for (int k = 0; k < n_jobs; ++k)
+    total_src_blocks += (c->sources.clouds[source_ids ? source_ids[k] : 0].n + scan_src - 1) / scan_src;
   float max_d2 = std::numeric_limits<float>::infinity();
   if (max_corr > 0.0f) max_d2 = max_corr * max_corr;  // float32 product, as the oracle
   const uint32_t want_split = static_cast<uint32_t>(
@@ -223,8 +231,14 @@ int make_plan(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* ta
     J.tgt_tiles = T.padded / kTile;
     const uint32_t cap = std::max<uint32_t>(1, J.tgt_tiles / std::max<uint32_t>(1, c->min_tiles_per_split));
     uint32_t split = std::min(std::max<uint32_t>(want_split, 1), cap);
-    J.tiles_per_split = (J.tgt_tiles + split - 1) / split;
-    J.n_split = (J.tgt_tiles + J.tiles_per_split - 1) / J.tiles_per_split;
+    // XCD-aware: workgroups b and b+8 share an XCD (and its L2); with n_split in {1,2,4} or a multiple of 8 they
+    // also share the run of target tiles they stream
+    if (split >= 8) split -= split % 8;
+    else if (split >= 4) split = 4;
+    else if (split >= 2) split = 2;
+    J.n_split = split;
+    J.split_q = J.tgt_tiles / split;
+    J.split_r = J.tgt_tiles % split;
     J.out_off = static_cast<uint32_t>(out_off);
     J.partial_off = static_cast<uint32_t>(partial_off);
     J.max_d2 = max_d2;
@@ -267,7 +281,7 @@ int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, boo
   (void)plan;
   const DevicePlanes S = c->sources.view(), T = c->targets.view();
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-  if (bx) launch_nn_scan(c->stream, c->scan_ppl, c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
+  if (bx) launch_nn_scan(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
   if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
@@ -323,7 +337,7 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   if (!c) return MI355_ICP_ERR_INTERNAL;
   c->device = device_id;
   {
-    const uint32_t ppl = env_u32("MI355_ICP_SCAN_PPL", static_cast<uint32_t>(c->scan_ppl));
+    const uint32_t ppl = env_u32("MI355_ICP_SCAN_PPL", 0);
     if (ppl == 2 || ppl == 4 || ppl == 8) c->scan_ppl = static_cast<int>(ppl);
   }
   c->target_blocks = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks);

@@ -19,7 +19,7 @@ constexpr int kChunk = 32;                               // granule at which the
 constexpr int kChunksPerTile = kTile / kChunk;
 constexpr float kTargetPad = 3.0e38f;                    // coordinate of padding targets: d2 overflows to +inf
 
-// One alignment job as the kernels see it (read with scalar loads; 96 bytes).
+// One alignment job as the kernels see it (read with scalar loads; 112 bytes).
 struct JobDesc {
   uint32_t src_off;          // first point of the source cloud in the source planes (multiple of kSrcPerBlock)
   uint32_t src_n;            // real source points
@@ -27,15 +27,18 @@ struct JobDesc {
   uint32_t tgt_off;          // first point of the target cloud in the target planes (multiple of kTile)
   uint32_t tgt_n;            // real target points
   uint32_t tgt_tiles;        // ceil(tgt_n / kTile)
-  uint32_t n_split;          // the target range is cut into n_split runs of tiles_per_split tiles
-  uint32_t tiles_per_split;
+  uint32_t n_split;          // the target tiles are cut into n_split balanced, non-empty runs:
+  uint32_t split_q;          //   run sp starts at sp*split_q + min(sp, split_r) and holds split_q + (sp < split_r) tiles
+
   uint32_t out_off;          // first slot of this job in the per-call outputs (keys, index, dist2)
   uint32_t partial_off;      // first per-block partial-sum slot of this job
+  uint32_t split_r;
   float max_d2;              // accept a pair iff d2 <= max_d2 (+inf keeps all)
   uint32_t scan_blocks;      // ceil(src_n / (256 * points_per_lane)): scan workgroups along the source
   float pose[12];            // float32 rounding of the row-major 3x4 [R|t] the pass is evaluated under
+  uint32_t pad_[3];
 };
-static_assert(sizeof(JobDesc) == 96, "JobDesc layout");
+static_assert(sizeof(JobDesc) == 112, "JobDesc layout");
 
 // ---- host math (host_math.cpp) ----
 int solve_rigid(const double* sums, double* pose16);

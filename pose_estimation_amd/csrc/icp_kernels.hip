@@ -62,7 +62,7 @@ __device__ __forceinline__ float min3(float a, float b, float c) { return __buil
 // ---------------------------------------------------------------------------------------------
 // N1: scan.  grid = (max_j src_blocks_j * n_split_j, n_jobs), block = 256.
 // Workgroup (sb, sp) of job j scans source points [sb*256*P, +256*P) against target tiles
-// [sp*tiles_per_split, +tiles_per_split) and writes one key per source point.
+// run sp (JobDesc::split_q/split_r) and writes one key per source point.
 template <int kPointsPerLane>
 __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* __restrict__ jobs,
                                                                  const float* __restrict__ sx,
@@ -82,9 +82,11 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
   const uint32_t sp = blockIdx.x - sb * n_split;
   if (sb >= J.scan_blocks) return;
   constexpr uint32_t kScanSrcPerBlock = kBlockThreads * kPointsPerLane;
-  const uint32_t tile0 = sp * J.tiles_per_split;
-  uint32_t tile1 = tile0 + J.tiles_per_split;
-  if (tile1 > J.tgt_tiles) tile1 = J.tgt_tiles;
+  // balanced runs of tiles (all non-empty because n_split <= tgt_tiles); sp is the fast index of blockIdx.x and
+  // n_split is 1, 2, 4 or a multiple of 8, so workgroups b and b+8 (one XCD: MI355X_MICROARCH.md "Workgroup
+  // dispatch") walk the same run of target tiles at about the same time and that XCD's L2 serves the re-reads
+  const uint32_t tile0 = sp * J.split_q + (sp < J.split_r ? sp : J.split_r);
+  const uint32_t tile1 = tile0 + J.split_q + (sp < J.split_r ? 1u : 0u);
 
   const uint32_t tid = threadIdx.x;
   float pose[12];

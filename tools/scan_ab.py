@@ -23,10 +23,11 @@ def main():
     ap.add_argument("--n", type=int, default=1 << 20)
     ap.add_argument("--nt", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=4)
+    ap.add_argument("--jobs", type=int, default=1, help="batched: this many objects, each n x nt (BASELINE config[3] style)")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     nt = a.nt or a.n
-    src, tgt, gt = st.make_pair(pa.synth_cloud, a.n, nt)
+    pairs = [st.make_pair(pa.synth_cloud, a.n, nt, object_index=(k if a.jobs > 1 else -1)) for k in range(a.jobs)]
     engines = []
     for v in a.variants:
         for k in KEYS.values():
@@ -35,24 +36,30 @@ def main():
             k, val = kv.split("=")
             os.environ[KEYS[k]] = val
         e = pa.IcpEngine(0)
-        e.set_targets([tgt])
-        e.set_sources([src])
+        e.set_targets([p[1] for p in pairs])
+        e.set_sources([p[0] for p in pairs])
         engines.append(e)
     p = pa.default_params(max_iterations=1, flags=pa._lib.FLAG_PROFILE)
     times = [[] for _ in engines]
+    other = [[] for _ in engines]
     ref = None
     for r in range(a.rounds + 1):
         for k, e in enumerate(engines):
             e.reset_profile()
-            res = e.align(np.eye(4)[None], p)
+            ids = list(range(a.jobs))
+            res = e.align(np.stack([np.eye(4)] * a.jobs), p, source_ids=ids, target_ids=ids)
             if ref is None:
-                ref = res.poses[0]
-            assert np.array_equal(res.poses[0], ref), "variants disagree"
+                ref = res.poses.copy()
+            assert np.array_equal(res.poses, ref), "variants disagree"
             if r:  # round 0 = warm-up
-                times[k].append(e.profile().nn_scan_ms)
-    for v, t in zip(a.variants, times):
+                pr = e.profile()
+                times[k].append(pr.nn_scan_ms)
+                other[k].append(pr.resolve_ms + pr.reduce_ms)
+    print(f"# {a.jobs} job(s) x {a.n} source x {nt} target")
+    for v, t, o in zip(a.variants, times, other):
         med = statistics.median(t)
-        print(f"{v:40s} scan median {med:9.3f} ms  min {min(t):9.3f}  -> {a.n * nt / med / 1e9:8.1f} Gpairs/s  ({len(t)} rounds)")
+        print(f"{v:44s} scan median {med:9.3f} ms  min {min(t):9.3f}  -> {a.jobs * a.n * nt / med / 1e9:8.3f} Tpairs/s"
+              f"  resolve+reduce {statistics.median(o):7.3f} ms  ({len(t)} rounds)")
 
 
 if __name__ == "__main__":
