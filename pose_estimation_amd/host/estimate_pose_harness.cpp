@@ -1,0 +1,82 @@
+// estimate_pose_harness.cpp — ROS-free stand-in for the EstimatePose request path
+// (pose_estimation_interface/srv/EstimatePose.srv:1-7 -> PoseEstimation::estimate_pose_service_handler,
+// pose_estimation.cpp:65-95 -> OpenCVSurfaceMatch::find_object_in_scene, opencv_surface_match.cpp:53-148),
+// driving the refine half through the C++ mirror.  PPF matching is not part of this path, so candidate
+// poses are synthesised around the known alignment the way PPF votes would deliver them.
+//
+//   estimate_pose_harness <n_model> <n_scene> [n_candidates]    prints the 7-float pose and per-candidate results
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "mi355_icp.hpp"
+
+namespace {
+
+// twin of EstimatePose.srv (request fields :1-5, response :7)
+struct EstimatePoseRequest {
+  std::string object;
+  long long num_planes = 0;
+  std::string filter_out;
+  float filter_radius = 0.f;
+  bool store_filter_pose = false;
+};
+struct EstimatePoseResponse {
+  bool success = false;
+};
+
+mi355::Pose rotation_about(double ax, double ay, double az, double deg, double tx, double ty, double tz) {
+  const double n = std::sqrt(ax * ax + ay * ay + az * az), x = ax / n, y = ay / n, z = az / n;
+  const double th = deg * 3.14159265358979323846 / 180.0, c = std::cos(th), s = std::sin(th), C = 1 - c;
+  return mi355::Pose{c + x * x * C,     x * y * C - z * s, x * z * C + y * s, tx,
+                     y * x * C + z * s, c + y * y * C,     y * z * C - x * s, ty,
+                     z * x * C - y * s, z * y * C + x * s, c + z * z * C,     tz,
+                     0, 0, 0, 1};
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  const size_t n_model = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 1000;
+  const size_t n_scene = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 1000;
+  const int n_cand = argc > 3 ? std::atoi(argv[3]) : 7;
+  EstimatePoseRequest req;
+  req.object = "bumpy_sphere";
+  EstimatePoseResponse resp;
+  try {
+    // scene = target sample; model = independent noisy sample moved by a known 5 degree perturbation
+    const mi355::Pose T = rotation_about(1, 2, 3, 5.0, 0.02, -0.01, 0.03);
+    std::vector<float> scene(3 * n_scene), model(3 * n_model);
+    mi355_icp_synth_cloud(0x5EED0001ull, 0, 0.0, nullptr, 0, n_scene, scene.data());
+    mi355_icp_synth_cloud(0x5EED0002ull, 0x5EED0003ull, 1e-3, T.data(), 0, n_model, model.data());
+
+    mi355::ppf_match_3d::ICP icp(250, 0.005f, 2.5f, 8);  // the reference's constructor arguments
+    std::vector<mi355::ppf_match_3d::Pose3DPtr> results;
+    const size_t votes[] = {300, 900, 500, 450, 100, 420, 50, 10};
+    for (int k = 0; k < n_cand; ++k) {
+      auto p = std::make_shared<mi355::ppf_match_3d::Pose3D>();
+      p->numVotes = votes[k % 8];
+      p->updatePose(rotation_about(0.2, 1, -0.4, 1.0 + k, 0.01, -0.02, 0.015));
+      results.push_back(p);
+    }
+    size_t best = 0;
+    const std::vector<float> pose = mi355::ppf_match_3d::refine_candidates(
+        icp, mi355::CloudView{model.data(), n_model, 12}, mi355::CloudView{scene.data(), n_scene, 12}, results, true, &best);
+    for (size_t k = 0; k < results.size(); ++k)
+      std::printf("candidate %zu votes %zu residual %.17g iterations %d\n", k, results[k]->numVotes, results[k]->residual,
+                  k < icp.last_result().iterations.size() ? icp.last_result().iterations[k] : 0);
+    std::printf("best %zu\n", best);
+    std::printf("pose7 %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", pose[0], pose[1], pose[2], pose[3], pose[4], pose[5], pose[6]);
+    for (size_t k = 0; k < results.size(); ++k) {
+      std::printf("pose %zu", k);
+      for (double v : results[k]->pose) std::printf(" %.17g", v);
+      std::printf("\n");
+    }
+    resp.success = true;  // pose_estimation.cpp:178 reports success unconditionally on this path
+  } catch (const mi355::Error& e) {
+    std::fprintf(stderr, "%s (object %s)\n", e.what(), req.object.c_str());
+    resp.success = false;
+  }
+  return resp.success ? 0 : 1;
+}

@@ -89,3 +89,14 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
     pts = np.zeros((10, 3), dtype=np.float32)
     with pytest.raises(pa.IcpError):
         icp.registerModelToScene(pts, pts, [pa.Pose3D()])
+
+
+def test_cpp_harness_builds_against_the_abi_and_fails_loudly_without_gpu():
+    exe = os.path.join(ROOT, "build", "estimate_pose_harness")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "pose_estimation_amd", "csrc"), "harness"],
+                              stdout=subprocess.DEVNULL)
+    assert os.path.exists(exe)
+    if not _gpu_visible():
+        r = subprocess.run([exe, "100", "100"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and "no CPU fallback" in r.stderr

@@ -268,3 +268,64 @@ def test_full_size_1m_properties(engine):
     engine.set_sources([src[b0:b0 + c0], src[b1:b1 + c1]])
     _, _, s2 = engine.correspond(np.stack([pose, pose]), source_ids=[0, 1], target_ids=[0, 0], want_pairs=False)
     np.testing.assert_allclose(s2[0] + s2[1], sums[0], rtol=1e-12, atol=1e-9)        # (c)
+
+
+def test_cpp_host_mirror_harness_matches_python_engine(engine):
+    """The C++ host side (pose_estimation_amd/host/mi355_icp.hpp) drives the same C-ABI: its refined
+    candidates must equal the Python mirror's on the same inputs, and the oracle's."""
+    import subprocess
+    import pose_estimation_amd as pa
+    from pose_estimation_amd.icp import select_best_pose
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build", "estimate_pose_harness")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "pose_estimation_amd", "csrc"), "harness"])
+    out = subprocess.run([exe, "2500", "3000", "7"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    poses, best, pose7 = {}, None, None
+    for line in out.stdout.splitlines():
+        f = line.split()
+        if f[0] == "pose":
+            poses[int(f[1])] = np.array([float(v) for v in f[2:]]).reshape(4, 4)
+        elif f[0] == "best":
+            best = int(f[1])
+        elif f[0] == "pose7":
+            pose7 = np.array([float(v) for v in f[1:]], dtype=np.float32)
+    model, scene, gt = st.make_pair(pa.synth_cloud, 2500, 3000)
+    icp = pa.ICP(250, 0.005, 2.5, 8, engine=engine)
+    votes = [300, 900, 500, 450, 100, 420, 50, 10]
+    cands = []
+    for k in range(7):
+        p = pa.Pose3D(numVotes=votes[k])
+        p.updatePose(st.rigid_transform(1.0 + k, (0.2, 1, -0.4), (0.01, -0.02, 0.015)))
+        cands.append(p)
+    init = [c.pose.copy() for c in cands]
+    icp.registerModelToScene(model, scene, cands[:6])
+    for k in range(6):
+        assert np.linalg.norm(poses[k] - cands[k].pose) <= 1e-9, k     # cos/sin of the candidate builders differ in the last ulp
+        o = ora.icp(model, scene, init[k], ora.params_from(icp.params))
+        assert np.linalg.norm(poses[k] - o["pose"]) <= POSE_TOL
+    assert np.linalg.norm(poses[6] - init[6]) <= 1e-12   # 7th candidate is not refined (opencv_surface_match.cpp:89-92)
+    assert best == select_best_pose(cands[:6], 7)
+    np.testing.assert_allclose(pose7, pa.pose_to_pose7(poses[best], True), atol=1e-6)
+
+
+def test_rccl_single_rank_communicator(engine):
+    """N5 plumbing on one GPU: dlopen RCCL, unique id, ncclCommInitRank(size 1), one ncclAllReduce per
+    iteration inside mi355_icp_align; results must equal the run without a communicator bit for bit."""
+    import pose_estimation_amd as pa
+    src, tgt, gt = st.make_pair(st.synth_cloud_np, 4000, 3000)
+    engine.set_targets([tgt])
+    engine.set_sources([src])
+    p = pa.default_params(max_iterations=6)
+    ref = engine.align(np.eye(4)[None], p)
+    uid = pa.IcpEngine.comm_unique_id()
+    assert len(uid) == 128
+    engine.comm_attach(uid, 0, 1)
+    try:
+        got = engine.align(np.eye(4)[None], p)
+        with pytest.raises(pa.IcpError):
+            engine.comm_attach(uid, 0, 1)   # already attached
+    finally:
+        engine.comm_detach()
+    assert np.array_equal(got.poses, ref.poses) and np.array_equal(got.residual, ref.residual)
