@@ -47,7 +47,8 @@ def cpu_baseline(src, tgt, iters):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as ora
-    threads = ora.max_threads()
+    # the GPU box gives a 1-GPU job a 16-core share of its host (more threads than that would be borrowed)
+    threads = max(1, min(ora.max_threads(), len(os.sched_getaffinity(0)), 16))
     p = ora.params(max_iterations=iters)
     t0 = time.perf_counter()
     r = ora.icp(src, tgt, np.eye(4), p, use_kdtree=True, nthreads=threads)
@@ -117,7 +118,8 @@ def main():
             collective = "torch.distributed"
 
     def run(iters, profile):
-        p = pa.default_params(max_iterations=iters, flags=(pa._lib.FLAG_PROFILE if profile else 0))
+        eng.set_profiling(profile)
+        p = pa.default_params(max_iterations=iters)
         if collective == "torch.distributed":
             return pd.align_external_collective(pd.engine_pass(eng, [0], [0]), pd.torch_allreduce(device="cuda"),
                                                 np.eye(4)[None], p)

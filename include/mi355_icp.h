@@ -220,6 +220,9 @@ int mi355_icp_comm_detach(mi355_icp_ctx* ctx);
 
 /* ---- measurement ---------------------------------------------------------- */
 
+/* Turns event timing on (1) or off (0) for EVERY pass of this context, including mi355_icp_correspond
+ * (mi355_icp_align additionally honours MI355_ICP_FLAG_PROFILE per call). */
+int mi355_icp_set_profiling(mi355_icp_ctx* ctx, int enabled);
 int mi355_icp_get_profile(const mi355_icp_ctx* ctx, mi355_icp_profile* out);
 int mi355_icp_reset_profile(mi355_icp_ctx* ctx);
 

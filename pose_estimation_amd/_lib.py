@@ -81,6 +81,7 @@ SIGNATURES = {
     "mi355_icp_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mi355_icp_comm_attach": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
     "mi355_icp_comm_detach": (C.c_int, [_ctx]),
+    "mi355_icp_set_profiling": (C.c_int, [_ctx, C.c_int]),
     "mi355_icp_get_profile": (C.c_int, [_ctx, _P(Profile)]),
     "mi355_icp_reset_profile": (C.c_int, [_ctx]),
     "mi355_icp_device_info": (C.c_int, [_ctx, C.c_char_p, C.c_size_t, _P(C.c_int), _P(C.c_size_t)]),

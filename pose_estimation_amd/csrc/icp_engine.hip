@@ -85,6 +85,7 @@ struct mi355_icp_ctx {
 
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   mi355_icp_profile prof{};
+  bool profile_always = false;
 
   int scan_ppl = 0;                  // scan points-per-lane override (2, 4, 8); 0 = planner decides per call
   uint32_t target_blocks = 12288;    // planner: aim for about this many scan workgroups per launch
@@ -416,7 +417,7 @@ int mi355_icp_align(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const i
     if (!pose_to_f32(js[k].pose, tmp)) return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "align: non-finite initial pose");
     active.push_back(k);
   }
-  const bool profile = (params->flags & MI355_ICP_FLAG_PROFILE) != 0;
+  const bool profile = c->profile_always || (params->flags & MI355_ICP_FLAG_PROFILE) != 0;
 
   for (int it = 0; it < params->max_iterations && !active.empty(); ++it) {
     for (size_t a = 0; a < active.size(); ++a) {
@@ -468,7 +469,7 @@ int mi355_icp_correspond(mi355_icp_ctx* c, int n_jobs, const int* source_ids, co
     if (!pose_to_f32(poses + 16 * static_cast<size_t>(k), J.pose)) return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "correspond: non-finite pose");
     c->jobs_host[k] = J;
   }
-  if ((st = run_pass(c, plan, n_jobs, false, true)) != MI355_ICP_OK) return st;
+  if ((st = run_pass(c, plan, n_jobs, c->profile_always, true)) != MI355_ICP_OK) return st;
   if (out_sums) std::memcpy(out_sums, c->sums_host, static_cast<size_t>(n_jobs) * MI355_ICP_NSUMS * sizeof(double));
   size_t cursor = 0;
   for (int k = 0; k < n_jobs; ++k) {
@@ -514,6 +515,12 @@ int mi355_icp_comm_detach(mi355_icp_ctx* c) {
     c->comm_rank = 0;
     c->comm_size = 1;
   }
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_set_profiling(mi355_icp_ctx* c, int enabled) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  c->profile_always = enabled != 0;
   return MI355_ICP_OK;
 }
 

@@ -230,6 +230,9 @@ class IcpEngine:
         self._check(lib.mi355_icp_comm_detach(self._h))
 
     # -- measurement
+    def set_profiling(self, enabled: bool):
+        self._check(lib.mi355_icp_set_profiling(self._h, int(enabled)))
+
     def profile(self) -> Profile:
         p = Profile()
         self._check(lib.mi355_icp_get_profile(self._h, C.byref(p)))

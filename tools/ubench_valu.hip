@@ -156,6 +156,31 @@ static void run_clock_probe(int n_cu, float* out, long long* cyc) {
   }
 }
 
+// Same probe as a train of short kernels (~1.5 ms each, host sync in between) - the shape of a 100k<->100k ICP loop.
+static void run_short_probe(int n_cu, float* out, long long* cyc) {
+  const int grid = n_cu * 4, iters = 1500;
+  for (int rep = 0; rep < 60; ++rep) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    clock_probe<<<grid, 256>>>(out, cyc, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (rep % 10 == 9) {
+      std::vector<long long> h(grid * 2);
+      hipMemcpy(h.data(), cyc, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+      double sc = 0, rt = 0, rtmax = 0;
+      for (int i = 0; i < grid; ++i) { sc += double(h[2 * i]); rt += double(h[2 * i + 1]); if (h[2*i+1] > rtmax) rtmax = double(h[2*i+1]); }
+      const double pairs = double(grid) * 256.0 * iters * 16.0 * 2.0;
+      printf("short probe launch %2d: %.3f ms event time, in-kernel span mean %.3f ms max %.3f ms, shader clock %.3f GHz, %.3e pairs/s\n",
+             rep, ms, rt / grid * 1e-5, rtmax * 1e-5, sc / rt * 0.1, pairs / (ms * 1e-3));
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+}
+
 int main() {
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, 0);
@@ -166,6 +191,7 @@ int main() {
   hipMalloc(&out, sizeof(float) * n_cu * 8 * 256);
   hipMalloc(&cyc, sizeof(long long) * n_cu * 8 * 4);
   const int iters = 20000;
+  run_short_probe(n_cu, out, cyc);
   run_clock_probe(n_cu, out, cyc);
   if (getenv("UBENCH_CLOCK_ONLY")) return 0;
   for (int w : {1, 2, 4, 8}) {
