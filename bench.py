@@ -145,6 +145,13 @@ def main():
     assert int(res.iterations[0]) == a.steps and int(res.status[0]) == 0, (res.iterations, res.status)
 
     prof = eng.profile()
+    traffic, traffic_note = None, None
+    try:  # PMC counters cannot be read from inside this process; use the committed rocprofv3 pass of this same command
+        tj = json.load(open(os.path.join(ROOT, "profiles", "scan_traffic.json")))
+        if ns_local == (1 << 20) and nt == (1 << 20):
+            traffic, traffic_note = tj["traffic_bytes_per_launch"], f"profiles/scan_traffic.json ({tj['tag']}): {tj['method']}"
+    except Exception:
+        pass
     if rank == 0:
         pairs_step = float(ns_total) * float(nt)
         scan_ms = prof.nn_scan_ms / max(prof.nn_scan_launches, 1)
@@ -164,13 +171,15 @@ def main():
                 "bound": "valu", "kernel": "nn_scan_kernel",
                 "achieved": FLOP_PER_PAIR * pairs_launch / (scan_ms * 1e-3) / 1e12, "peak": FP32_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": FLOP_PER_PAIR * pairs_launch / (scan_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
-                "traffic": None, "avg_launch_ms": scan_ms, "launches": int(prof.nn_scan_launches),
+                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_note,
+                "algorithmic_flop_per_launch": FLOP_PER_PAIR * pairs_launch,
+                "avg_launch_ms": scan_ms, "launches": int(prof.nn_scan_launches),
                 "note": "FP32 vector ALU bound (8 FLOP/pair, no FMA allowed by the bit-exact contract, so 9 issue slots "
                         "per 8 FLOP: attainable ceiling is 8/18 = 44% of the FMA-counted 157.3 TFLOP/s peak); DESIGN.md",
             },
             "roofline_hbm": {
                 "bound": "hbm", "kernel": "nn_scan_kernel", "achieved": alg_bytes / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": alg_bytes / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": alg_bytes / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "north_star asks for the HBM figure; the scan is compute-bound by ~4 orders of magnitude (DESIGN.md)",
             },

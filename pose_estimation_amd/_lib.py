@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmi355_icp.so")
+# MI355_ICP_LIB: developer override used by tools/ to load the diagnostic build (make -C csrc diag)
+LIB_PATH = os.environ.get("MI355_ICP_LIB") or os.path.join(_HERE, "lib", "libmi355_icp.so")
 
 NSUMS = 17
 UNIQUE_ID_BYTES = 128

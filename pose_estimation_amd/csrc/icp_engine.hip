@@ -88,6 +88,7 @@ struct mi355_icp_ctx {
   bool profile_always = false;
 
   int scan_ppl = 0;                  // scan points-per-lane override (2, 4, 8); 0 = planner decides per call
+  bool scan_sgpr = false;            // experimental scalar-load scan (MI355_ICP_SCAN_MODE=sgpr)
   uint32_t target_blocks = 12288;    // planner: aim for about this many scan workgroups per launch
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
 };
@@ -282,7 +283,7 @@ int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, boo
   (void)plan;
   const DevicePlanes S = c->sources.view(), T = c->targets.view();
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-  if (bx) launch_nn_scan(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
+  if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
   if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
@@ -340,6 +341,10 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   {
     const uint32_t ppl = env_u32("MI355_ICP_SCAN_PPL", 0);
     if (ppl == 2 || ppl == 4 || ppl == 8) c->scan_ppl = static_cast<int>(ppl);
+  }
+  {
+    const char* mode = std::getenv("MI355_ICP_SCAN_MODE");
+    c->scan_sgpr = mode && std::string(mode) == "sgpr";
   }
   c->target_blocks = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks);
   c->min_tiles_per_split = env_u32("MI355_ICP_MIN_TILES_PER_SPLIT", c->min_tiles_per_split);

@@ -37,6 +37,12 @@
 
 namespace mi355 {
 
+#ifdef MI355_ICP_DIAG
+// Diagnostic build only (make diag): per-workgroup start/end stamps of the scan, 100 MHz realtime counter.
+// Never compiled into the shipped library; stamps leave the kernel through this buffer alone.
+__device__ unsigned long long* g_diag_stamps = nullptr;
+#endif
+
 namespace {
 
 __device__ __forceinline__ void transform_point(const float* __restrict__ m, float x, float y, float z, float& ox,
@@ -76,6 +82,10 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
   // [buffer][plane][tile/4] float4: 2 x 12 KiB
   __shared__ float4 lds[2][3][kTile / 4];
 
+#ifdef MI355_ICP_DIAG
+  const unsigned long long diag_t0 = wall_clock64();
+  const unsigned long long diag_c0 = clock64();
+#endif
   const JobDesc& J = jobs[blockIdx.y];
   const uint32_t n_split = J.n_split;
   const uint32_t sb = blockIdx.x / n_split;
@@ -165,6 +175,100 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
     cur ^= 1;
   }
 
+  const uint32_t out = sp * key_stride + J.out_off + sb * kScanSrcPerBlock + tid;
+#pragma unroll
+  for (int p = 0; p < kPointsPerLane; ++p) {
+    const unsigned long long key =
+        (static_cast<unsigned long long>(__float_as_uint(best[p])) << 32) | static_cast<unsigned long long>(cid[p]);
+    keys[out + p * kBlockThreads] = key;
+  }
+#ifdef MI355_ICP_DIAG
+  if (g_diag_stamps && threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    const size_t slot = (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4;
+    g_diag_stamps[slot + 0] = diag_t0;
+    g_diag_stamps[slot + 1] = wall_clock64();
+    g_diag_stamps[slot + 2] = (static_cast<unsigned long long>(xcc & 0xf) << 32) | hwid;
+    g_diag_stamps[slot + 3] = clock64() - diag_c0;  // shader-clock cycles this workgroup lived
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// N1, experimental variant: the target is not staged through LDS; every wave reads it with SCALAR loads
+// (uniform address, constant address space -> s_load_dwordx8 into SGPRs) and the VALU ops take the target
+// coordinate as their one scalar operand.  No LDS, no barriers.  Same arithmetic, same keys.
+// Selected with MI355_ICP_SCAN_MODE=sgpr (A/B only; the LDS kernel above is the default).
+typedef const __attribute__((address_space(4))) float* const_f32_ptr;
+
+template <int kPointsPerLane>
+__global__ __launch_bounds__(kBlockThreads) void nn_scan_sgpr_kernel(const JobDesc* __restrict__ jobs,
+                                                                      const float* __restrict__ sx,
+                                                                      const float* __restrict__ sy,
+                                                                      const float* __restrict__ sz,
+                                                                      const float* __restrict__ tx,
+                                                                      const float* __restrict__ ty,
+                                                                      const float* __restrict__ tz,
+                                                                      unsigned long long* __restrict__ keys,
+                                                                      uint32_t key_stride) {
+  const JobDesc& J = jobs[blockIdx.y];
+  const uint32_t n_split = J.n_split;
+  const uint32_t sb = blockIdx.x / n_split;
+  const uint32_t sp = blockIdx.x - sb * n_split;
+  if (sb >= J.scan_blocks) return;
+  constexpr uint32_t kScanSrcPerBlock = kBlockThreads * kPointsPerLane;
+  const uint32_t tile0 = sp * J.split_q + (sp < J.split_r ? sp : J.split_r);
+  const uint32_t tile1 = tile0 + J.split_q + (sp < J.split_r ? 1u : 0u);
+  const uint32_t tid = threadIdx.x;
+  float pose[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
+  float qx[kPointsPerLane], qy[kPointsPerLane], qz[kPointsPerLane];
+  float best[kPointsPerLane], prev[kPointsPerLane];
+  uint32_t cid[kPointsPerLane];
+  const uint32_t src_base = J.src_off + sb * kScanSrcPerBlock + tid;
+#pragma unroll
+  for (int p = 0; p < kPointsPerLane; ++p) {
+    const uint32_t i = src_base + p * kBlockThreads;
+    transform_point(pose, sx[i], sy[i], sz[i], qx[p], qy[p], qz[p]);
+    best[p] = __builtin_inff();
+    prev[p] = __builtin_inff();
+    cid[p] = tile0 * kChunksPerTile;
+  }
+  const_f32_ptr cx = (const_f32_ptr)(tx + J.tgt_off);
+  const_f32_ptr cy = (const_f32_ptr)(ty + J.tgt_off);
+  const_f32_ptr cz = (const_f32_ptr)(tz + J.tgt_off);
+  const uint32_t chunk0 = tile0 * kChunksPerTile, chunk1 = tile1 * kChunksPerTile;
+  for (uint32_t chunk = chunk0; chunk < chunk1; ++chunk) {
+#pragma unroll
+    for (uint32_t g = 0; g < kChunk / 8; ++g) {
+      const uint32_t base = chunk * kChunk + g * 8;
+      float X[8], Y[8], Z[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        X[e] = cx[base + e];
+        Y[e] = cy[base + e];
+        Z[e] = cz[base + e];
+      }
+#pragma unroll
+      for (int p = 0; p < kPointsPerLane; ++p) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const float d0 = dist2(qx[p], qy[p], qz[p], X[e], Y[e], Z[e]);
+          const float d1 = dist2(qx[p], qy[p], qz[p], X[e + 1], Y[e + 1], Z[e + 1]);
+          best[p] = min3(best[p], d0, d1);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < kPointsPerLane; ++p) {
+      if (best[p] < prev[p]) cid[p] = chunk;
+      prev[p] = best[p];
+    }
+  }
   const uint32_t out = sp * key_stride + J.out_off + sb * kScanSrcPerBlock + tid;
 #pragma unroll
   for (int p = 0; p < kPointsPerLane; ++p) {
@@ -322,6 +426,18 @@ void launch_nn_scan(void* stream, int points_per_lane, const JobDesc* jobs_dev, 
                     DevicePlanes src, DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride) {
   dim3 grid(max_blocks_x, static_cast<uint32_t>(n_jobs));
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (points_per_lane >= 100) {  // experimental scalar-load variant: 100 + P
+    if (points_per_lane == 108)
+      hipLaunchKernelGGL(nn_scan_sgpr_kernel<8>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tgt.x,
+                         tgt.y, tgt.z, keys, key_stride);
+    else if (points_per_lane == 104)
+      hipLaunchKernelGGL(nn_scan_sgpr_kernel<4>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tgt.x,
+                         tgt.y, tgt.z, keys, key_stride);
+    else
+      hipLaunchKernelGGL(nn_scan_sgpr_kernel<2>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tgt.x,
+                         tgt.y, tgt.z, keys, key_stride);
+    return;
+  }
   switch (points_per_lane) {
     case 2:
       hipLaunchKernelGGL(nn_scan_kernel<2>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tgt.x,
@@ -346,6 +462,21 @@ void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t 
                      jobs_dev, src.x, src.y, src.z, tgt.x, tgt.y, tgt.z, keys, key_stride, out_index, out_dist2,
                      partials, error_flag);
 }
+
+#ifdef MI355_ICP_DIAG
+extern "C" int mi355_icp_diag_begin(size_t n_slots) {
+  unsigned long long* buf = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&buf), n_slots * 4 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (hipMemset(buf, 0, n_slots * 4 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+extern "C" int mi355_icp_diag_read(unsigned long long* out, size_t n_slots) {
+  unsigned long long* buf = nullptr;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(&buf, HIP_SYMBOL(g_diag_stamps), sizeof(buf)) != hipSuccess || !buf) return 1;
+  return hipMemcpy(out, buf, n_slots * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
 
 void launch_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums) {
   hipLaunchKernelGGL(final_reduce_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0,
