@@ -102,8 +102,8 @@ void mi355_icp_destroy(mi355_icp_ctx* ctx);
  * returns the text of the last failed mi355_icp_create on this thread. */
 const char* mi355_icp_last_error(const mi355_icp_ctx* ctx); /* [host] */
 
-/* Fills the defaults of the design: 50 iterations, no rejection, criterion A
- * off, criterion B 1e-9 off by default (<=0).  [host] */
+/* Fills the defaults of the design: 50 iterations, no rejection, criteria A and B off
+ * (rotation_epsilon preset to 1e-5 for when A is switched on).  [host] */
 void mi355_icp_default_params(mi355_icp_params* p);
 
 /* Maps the reference's constructor arguments ICP(iterations, tolerance,
@@ -177,6 +177,46 @@ int mi355_icp_correspond(mi355_icp_ctx* ctx, int n_jobs, const int* source_ids, 
                          const double* poses, float max_correspondence_distance, int32_t* out_index,
                          float* out_dist2, double* out_sums);
 
+/* ---- reference mode: what cv::ppf_match_3d::ICP really runs ---------- */
+
+/* The constructor arguments of the reference call site, cv::ppf_match_3d::ICP(iterations, tolerance,
+ * rejectionScale, numLevels) (opencv_surface_match.cpp:85), all live in this mode:
+ * resolution pyramid (level l subsamples both clouds with step 2^l, at most round(iterations/(l+1))
+ * passes, stop when fval/fval_old is inside 1 +- tolerance*(l+1)^2), exact 1-NN, median + MAD
+ * rejection (rejection_scale <= 0 keeps all), "picky" one-to-one dedupe, linearised point-to-plane
+ * least squares on the TARGET (scene) normals.  Numeric definition: oracle/icp_oracle.c, second half.
+ * Needs targets uploaded as rows of >= 6 float32 (xyz + normal, stride_bytes >= 24). */
+typedef struct mi355_icp_reference_params {
+  int32_t iterations;      /* reference passes 250 */
+  float   tolerance;       /* reference passes 0.005f */
+  float   rejection_scale; /* reference passes 2.5f */
+  int32_t num_levels;      /* reference passes 8 */
+  int32_t flags;           /* MI355_ICP_FLAG_* */
+} mi355_icp_reference_params;
+
+#define MI355_ICP_NREFSUMS 29 /* 21 upper-triangle A^T A (row-major), 6 A^T b, sum |p-q|^2, number of pairs */
+
+/* Batched like mi355_icp_align.  out_residual[k] is the smallest fval = sqrt(sum |p-q|^2)/n_level of the
+ * finest level that ran (cloud units; upstream reports it in its pre-normalised units), out_passes[k] the
+ * number of correspondence passes over all levels.  A job whose level ends early (< 6 pairs, degenerate
+ * solve) keeps what it has, as upstream does.  Single-GPU only (not with a communicator attached).
+ * Replaces: ICP::registerModelToScene(model, scene, poses) with the reference's parameters. */
+int mi355_icp_align_reference(mi355_icp_ctx* ctx, int n_jobs, const int* source_ids, const int* target_ids,
+                              const double* init_poses, const mi355_icp_reference_params* params, double* out_poses,
+                              double* out_residual, int* out_passes, int* out_status);
+
+/* One reference-mode pass on pyramid level `level` of (source_id, target_id), for parity checks:
+ * pose_start defines the point the plane equations are written for, pose_cur the pose the NN search runs under.
+ * Outputs are level-local (n_source >> level entries): target index, float32 d2, selected mask (after rejection
+ * and picky), the rejection threshold, and the MI355_ICP_NREFSUMS sums.  Any output may be NULL. */
+int mi355_icp_reference_pass(mi355_icp_ctx* ctx, int source_id, int target_id, int level, const double* pose_start,
+                             const double* pose_cur, float rejection_scale, int32_t* out_index, float* out_dist2,
+                             uint8_t* out_selected, float* out_threshold, double* out_sums);
+
+/* Minimum-norm least-squares solution x = (rx, ry, rz, tx, ty, tz) of the 6x6 normal equations packed in
+ * sums (symmetric eigen-decomposition in double).  [host] */
+int mi355_icp_solve_point_to_plane(const double* sums29, double out_x[6]);
+
 /* ---- host arithmetic (no GPU needed) ------------------------------------- */
 
 /* Kabsch: the rigid transform minimising sum |R s0 + t - t_j|^2 over the pairs
@@ -240,6 +280,12 @@ int mi355_icp_device_info(const mi355_icp_ctx* ctx, char* name, size_t name_len,
  * before rounding to float32.  [host] */
 int mi355_icp_synth_cloud(uint64_t seed, uint64_t noise_seed, double sigma, const double* transform12,
                           size_t first_index, size_t count, float* out_xyz);
+
+/* Same sample as rows of 6 float32: xyz then the unit outward normal of the noise-free surface (rotated
+ * with the transform) - the N x 6 layout of the reference's clouds with normals
+ * (opencv_surface_match.cpp:22,57-59).  [host] */
+int mi355_icp_synth_cloud6(uint64_t seed, uint64_t noise_seed, double sigma, const double* transform12,
+                           size_t first_index, size_t count, float* out_xyz_normal);
 
 #ifdef __cplusplus
 }

@@ -542,3 +542,254 @@ int oracle_omp_max_threads(void) {
   return 1;
 #endif
 }
+
+/* ======================================================================== */
+/* "Reference mode": the structure of what the reference really runs through
+ * cv::ppf_match_3d::ICP(iterations, tolerance, rejectionScale, numLevels)
+ * (pose_estimation/src/opencv_surface_match.cpp:85,94):
+ * resolution pyramid, exact 1-NN, median+MAD rejection, "picky" one-to-one
+ * dedupe, linearised point-to-plane least squares on the scene normals, and the
+ * error-ratio stop rule.  The upstream source is NOT available offline, so this
+ * restates the published structure as recalled; every numeric choice upstream
+ * leaves to its implementation is pinned here (PARITY UNPINNED, see header):
+ *   level l = L-1..0: both clouds subsampled with step 2^l (rows 0, step, 2*step, ...;
+ *     floor(n/step) rows), at most round(iterations/(l+1)) passes, stop when
+ *     fval/fval_old lies in (1 - tol*(l+1)^2, 1 + tol*(l+1)^2)
+ *   pass: pose_cur = PoseX * pose; s' = transform_f32(pose_cur, s); exact NN -> (j, d2)
+ *     rejection (scale > 0): med = lower median of d2 (rank (n-1)/2), dev_i = (float)|d2_i - med|
+ *       (difference in double), thr = scale*(1.48257968f*median(dev)) + med in float32; keep d2 < thr
+ *     picky: a target hit by several kept sources keeps the one with the smallest d2 (lowest source index on ties)
+ *     fewer than 6 pairs: leave the level
+ *     p = transform_f32(pose, s) (the LEVEL-START point), q, n = target point and normal:
+ *       row a = [p x n, n], b = (q - p).n; x = least-squares solution (normal equations in double,
+ *       symmetric-eigen pseudo-inverse); PoseX = [Rx(x0) Ry(x1) Rz(x2) | x3..5]
+ *     fval = sqrt(sum |p - q|^2) / n_level
+ *   after the level: pose = PoseX * pose, residual = smallest fval of the level
+ * Deviations from upstream, on purpose: no pre-normalisation of the clouds (the iterates are
+ * scale-invariant in exact arithmetic; the residual is therefore in cloud units), fval over xyz only.   */
+
+#define NREF 29 /* 21 upper-triangle A^T A, 6 A^T b, sum |p-q|^2, count */
+
+typedef struct oracle_ref_params {
+  int32_t iterations;
+  float tolerance;
+  float rejection_scale;
+  int32_t num_levels;
+} oracle_ref_params;
+
+static int cmp_f32(const void* a, const void* b) {
+  float x = *(const float*)a, y = *(const float*)b;
+  return (x > y) - (x < y);
+}
+
+/* element of 0-based rank k in sorted order (test oracle: full sort is fine) */
+float oracle_select_rank(const float* v, size_t n, size_t k) {
+  float* t = (float*)malloc(n * sizeof(float));
+  memcpy(t, v, n * sizeof(float));
+  qsort(t, n, sizeof(float), cmp_f32);
+  float r = t[k];
+  free(t);
+  return r;
+}
+
+float oracle_rejection_threshold(const float* d2, size_t n, float scale) {
+  float med = oracle_select_rank(d2, n, (n - 1) / 2);
+  float* dev = (float*)malloc(n * sizeof(float));
+  for (size_t i = 0; i < n; ++i) dev[i] = (float)fabs((double)d2[i] - (double)med);
+  float s = 1.48257968f * oracle_select_rank(dev, n, (n - 1) / 2);
+  free(dev);
+  float thr = scale * s;
+  return thr + med;
+}
+
+static void jacobi_eig_n(double* A, double* V, int n) { /* symmetric A (n x n, row-major) -> eigenvalues on diag, V columns */
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) V[i * n + j] = (i == j);
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < n; ++i) {
+      diag += fabs(A[i * n + i]);
+      for (int j = i + 1; j < n; ++j) off += fabs(A[i * n + j]);
+    }
+    if (off <= 1e-300 || off <= 1e-30 * diag) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        double apq = A[p * n + q];
+        if (apq == 0.0) continue;
+        double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; ++k) {
+          double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = c * akp - s * akq;
+          A[k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {
+          double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = c * apk - s * aqk;
+          A[q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          double vkp = V[k * n + p], vkq = V[k * n + q];
+          V[k * n + p] = c * vkp - s * vkq;
+          V[k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+}
+
+/* x = pinv(N) g for the 6x6 normal equations packed in sums (upper triangle row-major, then g) */
+int oracle_solve_point_to_plane(const double sums[NREF], double x[6]) {
+  for (int k = 0; k < NREF; ++k)
+    if (!isfinite(sums[k])) return OR_NUMERIC;
+  double N[36], V[36], g[6];
+  int k = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j) { N[i * 6 + j] = N[j * 6 + i] = sums[k++]; }
+  for (int i = 0; i < 6; ++i) g[i] = sums[21 + i];
+  jacobi_eig_n(N, V, 6);
+  double wmax = 0;
+  for (int i = 0; i < 6; ++i)
+    if (fabs(N[i * 6 + i]) > wmax) wmax = fabs(N[i * 6 + i]);
+  for (int i = 0; i < 6; ++i) x[i] = 0.0;
+  for (int e = 0; e < 6; ++e) {
+    double w = N[e * 6 + e];
+    if (!(w > 1e-12 * wmax)) continue; /* rank-deficient direction: minimum-norm solution */
+    double proj = 0;
+    for (int i = 0; i < 6; ++i) proj += V[i * 6 + e] * g[i];
+    for (int i = 0; i < 6; ++i) x[i] += V[i * 6 + e] * proj / w;
+  }
+  for (int i = 0; i < 6; ++i)
+    if (!isfinite(x[i])) return OR_NUMERIC;
+  return OR_OK;
+}
+
+void oracle_euler_pose(const double x[6], double P[16]) { /* R = Rx(x0) * (Ry(x1) * Rz(x2)), t = x3..5 */
+  double c0 = cos(x[0]), s0 = sin(x[0]), c1 = cos(x[1]), s1 = sin(x[1]), c2 = cos(x[2]), s2 = sin(x[2]);
+  double Rx[9] = {1, 0, 0, 0, c0, -s0, 0, s0, c0};
+  double Ry[9] = {c1, 0, s1, 0, 1, 0, -s1, 0, c1};
+  double Rz[9] = {c2, -s2, 0, s2, c2, 0, 0, 0, 1};
+  double T[9], R[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) T[3 * i + j] = Ry[3 * i] * Rz[j] + Ry[3 * i + 1] * Rz[3 + j] + Ry[3 * i + 2] * Rz[6 + j];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[3 * i + j] = Rx[3 * i] * T[j] + Rx[3 * i + 1] * T[3 + j] + Rx[3 * i + 2] * T[6 + j];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) P[4 * i + j] = R[3 * i + j];
+    P[4 * i + 3] = x[3 + i];
+  }
+  P[12] = P[13] = P[14] = 0;
+  P[15] = 1;
+}
+
+static void mat4_mul(const double A[16], const double B[16], double C[16]) {
+  double T[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double acc = 0;
+      for (int k = 0; k < 4; ++k) acc += A[4 * i + k] * B[4 * k + j];
+      T[4 * i + j] = acc;
+    }
+  memcpy(C, T, sizeof(T));
+}
+
+/* one reference-mode pass on already subsampled clouds; returns the number of selected pairs.
+ * src_xyz: level source (ns x 3), tgt6: level target (nt x 6, xyz + normal).  Outputs optional. */
+size_t oracle_ref_pass(const float* src_xyz, size_t ns, const float* tgt6, size_t nt, const double pose_start[16],
+                       const double pose_cur[16], float rejection_scale, int nthreads, double sums[NREF],
+                       int32_t* out_idx, float* out_d2, uint8_t* out_selected, float* out_threshold) {
+  float *tgt_xyz = (float*)malloc(nt * 3 * sizeof(float)), *moved = (float*)malloc(ns * 3 * sizeof(float));
+  float* start = (float*)malloc(ns * 3 * sizeof(float));
+  int32_t* idx = (int32_t*)malloc(ns * sizeof(int32_t));
+  float* d2 = (float*)malloc(ns * sizeof(float));
+  for (size_t j = 0; j < nt; ++j) memcpy(&tgt_xyz[3 * j], &tgt6[6 * j], 3 * sizeof(float));
+  float pf[12];
+  oracle_pose_to_f32(pose_cur, pf);
+  oracle_transform(pf, src_xyz, ns, moved);
+  oracle_pose_to_f32(pose_start, pf);
+  oracle_transform(pf, src_xyz, ns, start);
+  oracle_kdtree* tree = oracle_kdtree_build(tgt_xyz, nt);
+  oracle_kdtree_query(tree, moved, ns, idx, d2, nthreads);
+  oracle_kdtree_free(tree);
+  float thr = INFINITY;
+  if (rejection_scale > 0.0f) thr = oracle_rejection_threshold(d2, ns, rejection_scale);
+  /* picky: per target the kept source with the smallest d2, lowest index on ties */
+  int32_t* owner = (int32_t*)malloc(nt * sizeof(int32_t));
+  for (size_t j = 0; j < nt; ++j) owner[j] = -1;
+  for (size_t i = 0; i < ns; ++i) {
+    if (!(d2[i] < thr)) continue;
+    int32_t j = idx[i];
+    if (owner[j] < 0 || d2[i] < d2[owner[j]]) owner[j] = (int32_t)i; /* ascending i: ties keep the lower index */
+  }
+  for (int k = 0; k < NREF; ++k) sums[k] = 0.0;
+  size_t nsel = 0;
+  for (size_t i = 0; i < ns; ++i) {
+    int sel = (d2[i] < thr) && owner[idx[i]] == (int32_t)i;
+    if (out_selected) out_selected[i] = (uint8_t)sel;
+    if (!sel) continue;
+    ++nsel;
+    const float* p = &start[3 * i];
+    const float* q = &tgt6[6 * (size_t)idx[i]];
+    double P[3] = {p[0], p[1], p[2]}, Q[3] = {q[0], q[1], q[2]}, Nn[3] = {q[3], q[4], q[5]};
+    double a[6] = {P[1] * Nn[2] - P[2] * Nn[1], P[2] * Nn[0] - P[0] * Nn[2], P[0] * Nn[1] - P[1] * Nn[0], Nn[0], Nn[1], Nn[2]};
+    double dx = Q[0] - P[0], dy = Q[1] - P[1], dz = Q[2] - P[2];
+    double b = dx * Nn[0] + dy * Nn[1] + dz * Nn[2];
+    int k = 0;
+    for (int r = 0; r < 6; ++r)
+      for (int c = r; c < 6; ++c) sums[k++] += a[r] * a[c];
+    for (int r = 0; r < 6; ++r) sums[21 + r] += a[r] * b;
+    sums[27] += dx * dx + dy * dy + dz * dz;
+    sums[28] += 1.0;
+  }
+  if (out_idx) memcpy(out_idx, idx, ns * sizeof(int32_t));
+  if (out_d2) memcpy(out_d2, d2, ns * sizeof(float));
+  if (out_threshold) *out_threshold = thr;
+  free(tgt_xyz); free(moved); free(start); free(idx); free(d2); free(owner);
+  return nsel;
+}
+
+/* host controller of one level (shared shape with the product's): returns 1 when the level loop must stop */
+int oracle_icp_reference(const float* src_xyz, size_t ns, const float* tgt6, size_t nt, const double init_pose[16],
+                         const oracle_ref_params* rp, int nthreads, double out_pose[16], double* out_residual,
+                         int* out_passes) {
+  if (!rp || rp->iterations < 1 || rp->num_levels < 1 || !ns || !nt) return OR_INVALID;
+  double pose[16];
+  memcpy(pose, init_pose, sizeof(pose));
+  double residual = 0.0;
+  int passes = 0;
+  for (int level = rp->num_levels - 1; level >= 0; --level) {
+    const size_t step = (size_t)1 << level;
+    const size_t ns_l = ns / step, nt_l = nt / step;
+    if (ns_l < 6 || nt_l < 1) continue;
+    float* s_l = (float*)malloc(ns_l * 3 * sizeof(float));
+    float* t_l = (float*)malloc(nt_l * 6 * sizeof(float));
+    for (size_t i = 0; i < ns_l; ++i) memcpy(&s_l[3 * i], &src_xyz[3 * i * step], 3 * sizeof(float));
+    for (size_t j = 0; j < nt_l; ++j) memcpy(&t_l[6 * j], &tgt6[6 * j * step], 6 * sizeof(float));
+    const double tolp = (double)rp->tolerance * (double)(level + 1) * (double)(level + 1);
+    const int maxit = (int)floor((double)rp->iterations / (double)(level + 1) + 0.5);
+    double posex[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double fval_old = 9999999999.0, fval_perc = 0.0, fval_min = 9999999999.0;
+    int i = 0;
+    while (!(fval_perc < 1.0 + tolp && fval_perc > 1.0 - tolp) && i < maxit) {
+      double cur[16], sums[NREF], x[6];
+      mat4_mul(posex, pose, cur);
+      size_t nsel = oracle_ref_pass(s_l, ns_l, t_l, nt_l, pose, cur, rp->rejection_scale, nthreads, sums, NULL, NULL, NULL, NULL);
+      ++passes;
+      if (nsel < 6) break;
+      if (oracle_solve_point_to_plane(sums, x) != OR_OK) break;
+      oracle_euler_pose(x, posex);
+      double fval = sqrt(sums[27]) / (double)ns_l;
+      fval_perc = fval / fval_old;
+      fval_old = fval;
+      if (fval < fval_min) fval_min = fval;
+      ++i;
+    }
+    mat4_mul(posex, pose, pose);
+    residual = fval_min;
+    free(s_l); free(t_l);
+  }
+  memcpy(out_pose, pose, sizeof(pose));
+  if (out_residual) *out_residual = residual;
+  if (out_passes) *out_passes = passes;
+  return OR_OK;
+}

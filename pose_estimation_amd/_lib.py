@@ -44,6 +44,20 @@ class Params(C.Structure):
     ]
 
 
+class ReferenceParams(C.Structure):
+    """mi355_icp_reference_params"""
+    _fields_ = [
+        ("iterations", C.c_int32),
+        ("tolerance", C.c_float),
+        ("rejection_scale", C.c_float),
+        ("num_levels", C.c_int32),
+        ("flags", C.c_int32),
+    ]
+
+
+NREFSUMS = 29
+
+
 class Profile(C.Structure):
     """mi355_icp_profile"""
     _fields_ = [
@@ -75,6 +89,11 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355_icp_correspond": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    "mi355_icp_align_reference": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _P(ReferenceParams),
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_icp_reference_pass": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_float), C.c_void_p]),
+    "mi355_icp_solve_point_to_plane": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi355_icp_solve_rigid": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi355_icp_host_update": (C.c_int, [_P(Params), C.c_void_p, C.c_int, C.c_void_p, _P(C.c_double), _P(C.c_int),
                                         _P(C.c_int)]),
@@ -88,6 +107,8 @@ SIGNATURES = {
     "mi355_icp_device_info": (C.c_int, [_ctx, C.c_char_p, C.c_size_t, _P(C.c_int), _P(C.c_size_t)]),
     "mi355_icp_synth_cloud": (C.c_int, [C.c_uint64, C.c_uint64, C.c_double, C.c_void_p, C.c_size_t, C.c_size_t,
                                         C.c_void_p]),
+    "mi355_icp_synth_cloud6": (C.c_int, [C.c_uint64, C.c_uint64, C.c_double, C.c_void_p, C.c_size_t, C.c_size_t,
+                                         C.c_void_p]),
 }
 
 

@@ -162,6 +162,93 @@ int host_update(const mi355_icp_params* p, const double* sums, int iteration, do
   return MI355_ICP_OK;
 }
 
+// ---- reference mode: 6x6 point-to-plane normal equations -------------------------------------------------
+// Minimum-norm least-squares solution through the eigen-decomposition of the symmetric 6x6 (cyclic Jacobi),
+// which is what cv::solve(A, b, x, DECOMP_SVD) returns for A^T A x = A^T b up to rounding (upstream solves the
+// tall system; reference call site opencv_surface_match.cpp:94).
+int solve_point_to_plane(const double* sums, double* x) {
+  for (int k = 0; k < kRefSums; ++k)
+    if (!std::isfinite(sums[k])) return MI355_ICP_ERR_NUMERIC;
+  constexpr int n = 6;
+  double M[n][n], E[n][n], g[n];
+  int k = 0;
+  for (int i = 0; i < n; ++i)
+    for (int j = i; j < n; ++j) M[i][j] = M[j][i] = sums[k++];
+  for (int i = 0; i < n; ++i) {
+    g[i] = sums[21 + i];
+    for (int j = 0; j < n; ++j) E[i][j] = (i == j) ? 1.0 : 0.0;
+  }
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < n; ++i) {
+      diag += std::fabs(M[i][i]);
+      for (int j = i + 1; j < n; ++j) off += std::fabs(M[i][j]);
+    }
+    if (off <= 1e-300 || off <= 1e-30 * diag) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        if (M[p][q] == 0.0) continue;
+        const double theta = (M[q][q] - M[p][p]) / (2.0 * M[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int r = 0; r < n; ++r) {
+          const double a = M[r][p], b = M[r][q];
+          M[r][p] = c * a - s * b;
+          M[r][q] = s * a + c * b;
+        }
+        for (int r = 0; r < n; ++r) {
+          const double a = M[p][r], b = M[q][r];
+          M[p][r] = c * a - s * b;
+          M[q][r] = s * a + c * b;
+        }
+        for (int r = 0; r < n; ++r) {
+          const double a = E[r][p], b = E[r][q];
+          E[r][p] = c * a - s * b;
+          E[r][q] = s * a + c * b;
+        }
+      }
+  }
+  double wmax = 0.0;
+  for (int i = 0; i < n; ++i) wmax = std::fmax(wmax, std::fabs(M[i][i]));
+  for (int i = 0; i < n; ++i) x[i] = 0.0;
+  for (int e = 0; e < n; ++e) {
+    const double w = M[e][e];
+    if (!(w > 1e-12 * wmax)) continue;  // rank-deficient direction: leave it out (minimum-norm solution)
+    double proj = 0.0;
+    for (int i = 0; i < n; ++i) proj += E[i][e] * g[i];
+    for (int i = 0; i < n; ++i) x[i] += E[i][e] * proj / w;
+  }
+  for (int i = 0; i < n; ++i)
+    if (!std::isfinite(x[i])) return MI355_ICP_ERR_NUMERIC;
+  return MI355_ICP_OK;
+}
+
+// R = Rx(x0) * (Ry(x1) * Rz(x2)), t = (x3, x4, x5): upstream's getTransformMat / eulerToDCM convention as recalled.
+void euler_pose(const double* x, double* P) {
+  const double c0 = std::cos(x[0]), s0 = std::sin(x[0]), c1 = std::cos(x[1]), s1 = std::sin(x[1]), c2 = std::cos(x[2]),
+               s2 = std::sin(x[2]);
+  const double RyRz[9] = {c1 * c2, -c1 * s2, s1, s2, c2, 0.0, -s1 * c2, s1 * s2, c1};
+  const double Rx[9] = {1, 0, 0, 0, c0, -s0, 0, s0, c0};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j)
+      P[4 * i + j] = Rx[3 * i] * RyRz[j] + Rx[3 * i + 1] * RyRz[3 + j] + Rx[3 * i + 2] * RyRz[6 + j];
+    P[4 * i + 3] = x[3 + i];
+  }
+  P[12] = P[13] = P[14] = 0.0;
+  P[15] = 1.0;
+}
+
+void mat4_mul(const double* a, const double* b, double* c) {
+  double t[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 4; ++k) acc += a[4 * i + k] * b[4 * k + j];
+      t[4 * i + j] = acc;
+    }
+  std::memcpy(c, t, sizeof(t));
+}
+
 // 0.5 * copysign(1, sign_arg) * sqrt(a - b - c + 1) with float arithmetic inside,
 // as the reference evaluates it on xt::xarray<float>
 // (chessboard_pose_estimator.cpp:196-207).  Deviation: the sqrt argument is

@@ -31,11 +31,21 @@ struct CloudEntry {
   uint32_t padded;  // slots occupied
 };
 
-struct CloudSet {
-  float* planes = nullptr;  // x | y | z, each `stride` floats
+struct LevelPlanes {  // compacted copy of every cloud of a set at pyramid level l >= 1 (rows 0, step, 2*step, ...)
+  float* planes = nullptr;
   size_t stride = 0;
   std::vector<CloudEntry> clouds;
   DevicePlanes view() const { return DevicePlanes{planes, planes + stride, planes + 2 * stride}; }
+};
+
+struct CloudSet {
+  float* planes = nullptr;   // x | y | z, each `stride` floats
+  float* normals = nullptr;  // nx | ny | nz in the same layout, only when uploaded with rows of >= 6 floats
+  size_t stride = 0;
+  std::vector<CloudEntry> clouds;
+  std::vector<LevelPlanes> levels;  // levels[l - 1] = level l, built on demand by reference mode
+  DevicePlanes view() const { return DevicePlanes{planes, planes + stride, planes + 2 * stride}; }
+  DevicePlanes normal_view() const { return DevicePlanes{normals, normals + stride, normals + 2 * stride}; }
 };
 
 struct Plan {
@@ -79,6 +89,17 @@ struct mi355_icp_ctx {
   JobDesc* jobs_host = nullptr;  // pinned
   double* sums_host = nullptr;   // pinned
   uint32_t* flag_host = nullptr; // pinned
+
+  // reference-mode work buffers
+  unsigned long long* owner = nullptr; size_t owner_cap = 0;
+  uint8_t* selected = nullptr;         size_t selected_cap = 0;
+  double* ref_partials = nullptr;      size_t ref_partials_cap = 0;
+  double* ref_sums_dev = nullptr;      size_t ref_jobs_cap = 0;
+  float* thr_dev = nullptr;
+  RefJobDesc* rjobs_dev = nullptr;
+  RefJobDesc* rjobs_host = nullptr;    // pinned
+  double* ref_sums_host = nullptr;     // pinned
+  float* thr_host = nullptr;           // pinned
 
   void* comm = nullptr;
   int comm_rank = 0, comm_size = 1;
@@ -127,6 +148,8 @@ int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* co
   const size_t stride = static_cast<size_t>(std::max<uint64_t>(total, pad_multiple));
   std::vector<float> host(3 * stride, pad_value);
   const size_t fstride = stride_bytes / 4;
+  const bool with_normals = fstride >= 6;  // rows of xyz + normal (N x 6), opencv_surface_match.cpp:22,57-59
+  std::vector<float> host_n(with_normals ? 3 * stride : 0, 0.0f);
   for (int k = 0; k < n_clouds; ++k) {
     const float* src = xyz[k];
     float* px = host.data() + entries[k].off;
@@ -137,6 +160,12 @@ int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* co
       const float x = src[i * fstride], y = src[i * fstride + 1], z = src[i * fstride + 2];
       finite = finite && std::isfinite(x) && std::isfinite(y) && std::isfinite(z);
       px[i] = x; py[i] = y; pz[i] = z;
+      if (with_normals) {
+        float* pn = host_n.data() + entries[k].off + i;
+        const float a = src[i * fstride + 3], b = src[i * fstride + 4], cc = src[i * fstride + 5];
+        finite = finite && std::isfinite(a) && std::isfinite(b) && std::isfinite(cc);
+        pn[0] = a; pn[stride] = b; pn[2 * stride] = cc;
+      }
     }
     if (!finite)
       return fail(c, MI355_ICP_ERR_NONFINITE_INPUT,
@@ -145,9 +174,17 @@ int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* co
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (set.planes) { HIP_TRY(c, hipFree(set.planes)); set.planes = nullptr; }
+  if (set.normals) { HIP_TRY(c, hipFree(set.normals)); set.normals = nullptr; }
+  for (auto& lv : set.levels)
+    if (lv.planes) HIP_TRY(c, hipFree(lv.planes));
+  set.levels.clear();
   set.clouds.clear();
   HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.planes), 3 * stride * sizeof(float)));
   HIP_TRY(c, hipMemcpy(set.planes, host.data(), 3 * stride * sizeof(float), hipMemcpyHostToDevice));
+  if (with_normals) {
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.normals), 3 * stride * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(set.normals, host_n.data(), 3 * stride * sizeof(float), hipMemcpyHostToDevice));
+  }
   set.stride = stride;
   set.clouds = std::move(entries);
   return MI355_ICP_OK;
@@ -194,17 +231,18 @@ int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs) {
 
 // Lays the jobs out and decides how finely to cut each target: enough scan workgroups to keep
 // 256 CUs x 4 resident workgroups busy for several rounds, never finer than min_tiles_per_split.
-int make_plan(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* target_ids, float max_corr, Plan& plan) {
-  if (c->targets.clouds.empty()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "no target clouds uploaded (mi355_icp_set_targets)");
-  if (c->sources.clouds.empty()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "no source clouds uploaded (mi355_icp_set_sources)");
+int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, const std::vector<CloudEntry>& tgt_clouds,
+                 int n_jobs, const int* source_ids, const int* target_ids, float max_corr, Plan& plan) {
+  if (tgt_clouds.empty()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "no target clouds uploaded (mi355_icp_set_targets)");
+  if (src_clouds.empty()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "no source clouds uploaded (mi355_icp_set_sources)");
   plan = Plan{};
   plan.jobs.resize(static_cast<size_t>(n_jobs));
   double total_pairs = 0.0;
   for (int k = 0; k < n_jobs; ++k) {
     const int s = source_ids ? source_ids[k] : 0, t = target_ids ? target_ids[k] : 0;
-    if (s < 0 || static_cast<size_t>(s) >= c->sources.clouds.size()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "source id out of range");
-    if (t < 0 || static_cast<size_t>(t) >= c->targets.clouds.size()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "target id out of range");
-    total_pairs += static_cast<double>(c->sources.clouds[s].n) * static_cast<double>(c->targets.clouds[t].n);
+    if (s < 0 || static_cast<size_t>(s) >= src_clouds.size()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "source id out of range");
+    if (t < 0 || static_cast<size_t>(t) >= tgt_clouds.size()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "target id out of range");
+    total_pairs += static_cast<double>(src_clouds[s].n) * static_cast<double>(tgt_clouds[t].n);
   }
   // Register blocking of the scan: 8 points per lane is the fastest steady state (fewest LDS reads per pair) but
   // makes the coarsest workgroups; below ~4e11 pairs per launch the finer 2-point workgroups balance the 256 CUs
@@ -213,15 +251,15 @@ int make_plan(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* ta
   const uint32_t scan_src = static_cast<uint32_t>(kBlockThreads * plan.scan_ppl);
   uint64_t total_src_blocks = 0;
   for (int k = 0; k < n_jobs; ++k)
-    total_src_blocks += (c->sources.clouds[source_ids ? source_ids[k] : 0].n + scan_src - 1) / scan_src;
+    total_src_blocks += (src_clouds[source_ids ? source_ids[k] : 0].n + scan_src - 1) / scan_src;
   float max_d2 = std::numeric_limits<float>::infinity();
   if (max_corr > 0.0f) max_d2 = max_corr * max_corr;  // float32 product, as the oracle
   const uint32_t want_split = static_cast<uint32_t>(
       std::max<uint64_t>(1, (c->target_blocks + std::max<uint64_t>(total_src_blocks, 1) - 1) / std::max<uint64_t>(total_src_blocks, 1)));
   uint64_t out_off = 0, partial_off = 0;
   for (int k = 0; k < n_jobs; ++k) {
-    const CloudEntry& S = c->sources.clouds[source_ids ? source_ids[k] : 0];
-    const CloudEntry& T = c->targets.clouds[target_ids ? target_ids[k] : 0];
+    const CloudEntry& S = src_clouds[source_ids ? source_ids[k] : 0];
+    const CloudEntry& T = tgt_clouds[target_ids ? target_ids[k] : 0];
     JobDesc& J = plan.jobs[k];
     std::memset(&J, 0, sizeof(J));
     J.src_off = S.off;
@@ -255,6 +293,10 @@ int make_plan(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* ta
   plan.partial_total = static_cast<uint32_t>(partial_off);
   if (static_cast<uint64_t>(plan.max_split) * plan.out_total > 0xFFFF0000ull) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "batch too large");
   return MI355_ICP_OK;
+}
+
+int make_plan(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* target_ids, float max_corr, Plan& plan) {
+  return make_plan_on(c, c->sources.clouds, c->targets.clouds, n_jobs, source_ids, target_ids, max_corr, plan);
 }
 
 bool pose_to_f32(const double* pose16, float* out12) {
@@ -315,6 +357,123 @@ int check_error_flag(mi355_icp_ctx* c) {
   return MI355_ICP_OK;
 }
 
+
+// =====================================================================================================
+// Reference mode: pyramid + MAD rejection + picky + point-to-plane, batched over jobs.
+
+// Builds (once per upload) the compacted planes of pyramid level `level` >= 1 for every cloud of `set`.
+int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multiple, float pad_value) {
+  while (static_cast<int>(set.levels.size()) < level) {
+    const int l = static_cast<int>(set.levels.size()) + 1;
+    const uint32_t step = 1u << l;
+    LevelPlanes lv;
+    uint64_t total = 0;
+    for (const CloudEntry& e : set.clouds) {
+      const uint32_t n = e.n / step;
+      const uint64_t padded = (static_cast<uint64_t>(n) + pad_multiple - 1) / pad_multiple * pad_multiple;
+      lv.clouds.push_back(CloudEntry{static_cast<uint32_t>(total), n, static_cast<uint32_t>(padded)});
+      total += padded;
+    }
+    lv.stride = static_cast<size_t>(std::max<uint64_t>(total, pad_multiple));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&lv.planes), 3 * lv.stride * sizeof(float)));
+    if (total == 0) HIP_TRY(c, hipMemsetAsync(lv.planes, 0, 3 * lv.stride * sizeof(float), c->stream));
+    for (size_t k = 0; k < set.clouds.size(); ++k)
+      launch_subsample(c->stream, set.planes, set.stride, set.clouds[k].off, lv.planes, lv.stride, lv.clouds[k].off,
+                       lv.clouds[k].n, lv.clouds[k].padded, step, pad_value);
+    HIP_TRY(c, hipGetLastError());
+    set.levels.push_back(lv);
+  }
+  return MI355_ICP_OK;
+}
+
+const std::vector<CloudEntry>& level_clouds(const CloudSet& set, int level) { return level ? set.levels[level - 1].clouds : set.clouds; }
+DevicePlanes level_view(const CloudSet& set, int level) { return level ? set.levels[level - 1].view() : set.view(); }
+
+int ensure_ref_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs, size_t owner_total) {
+  int st;
+  if ((st = grow(c, c->owner, c->owner_cap, std::max<size_t>(owner_total, 1))) != MI355_ICP_OK) return st;
+  if ((st = grow(c, c->selected, c->selected_cap, std::max<size_t>(plan.out_total, 1))) != MI355_ICP_OK) return st;
+  if ((st = grow(c, c->ref_partials, c->ref_partials_cap, static_cast<size_t>(std::max<uint32_t>(plan.partial_total, 1)) * kRefSums)) != MI355_ICP_OK) return st;
+  if (n_jobs > c->ref_jobs_cap) {
+    if (c->ref_sums_dev) { HIP_TRY(c, hipFree(c->ref_sums_dev)); c->ref_sums_dev = nullptr; }
+    if (c->thr_dev) { HIP_TRY(c, hipFree(c->thr_dev)); c->thr_dev = nullptr; }
+    if (c->rjobs_dev) { HIP_TRY(c, hipFree(c->rjobs_dev)); c->rjobs_dev = nullptr; }
+    if (c->rjobs_host) { HIP_TRY(c, hipHostFree(c->rjobs_host)); c->rjobs_host = nullptr; }
+    if (c->ref_sums_host) { HIP_TRY(c, hipHostFree(c->ref_sums_host)); c->ref_sums_host = nullptr; }
+    if (c->thr_host) { HIP_TRY(c, hipHostFree(c->thr_host)); c->thr_host = nullptr; }
+    c->ref_jobs_cap = 0;
+    const size_t want = std::max<size_t>(n_jobs, 8) * 2;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->ref_sums_dev), want * kRefSums * sizeof(double)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->thr_dev), want * sizeof(float)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->rjobs_dev), want * sizeof(RefJobDesc)));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->rjobs_host), want * sizeof(RefJobDesc), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->ref_sums_host), want * kRefSums * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->thr_host), want * sizeof(float), hipHostMallocDefault));
+    c->ref_jobs_cap = want;
+  }
+  return MI355_ICP_OK;
+}
+
+// One reference-mode pass for the first n_active descriptors of jobs_host / rjobs_host on pyramid level `level`.
+// Leaves the 29 sums per job in ref_sums_host and the thresholds in thr_host (synchronises the stream).
+int run_ref_pass(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, float rejection_scale, size_t owner_total,
+                 bool profile) {
+  HIP_TRY(c, hipMemcpyAsync(c->jobs_dev, c->jobs_host, static_cast<size_t>(n_active) * sizeof(JobDesc), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->rjobs_dev, c->rjobs_host, static_cast<size_t>(n_active) * sizeof(RefJobDesc), hipMemcpyHostToDevice, c->stream));
+  uint32_t bx = 0, sbx = 0;
+  double pairs = 0.0;
+  for (int k = 0; k < n_active; ++k) {
+    const JobDesc& J = c->jobs_host[k];
+    bx = std::max(bx, J.scan_blocks * J.n_split);
+    sbx = std::max(sbx, J.src_blocks);
+    pairs += static_cast<double>(J.src_n) * static_cast<double>(J.tgt_n);
+  }
+  const DevicePlanes S = level_view(c->sources, level), T = level_view(c->targets, level);
+  if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
+  if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
+  if (rejection_scale > 0.0f) {
+    launch_rejection_select(c->stream, c->jobs_dev, n_active, c->out_dist2, rejection_scale, c->thr_dev);
+  } else {
+    for (int k = 0; k < n_active; ++k) c->thr_host[k] = std::numeric_limits<float>::infinity();
+    HIP_TRY(c, hipMemcpyAsync(c->thr_dev, c->thr_host, static_cast<size_t>(n_active) * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  }
+  HIP_TRY(c, hipMemsetAsync(c->owner, 0xFF, std::max<size_t>(owner_total, 1) * sizeof(unsigned long long), c->stream));
+  if (sbx) {
+    launch_picky_scatter(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, c->out_index, c->out_dist2, c->thr_dev, c->owner);
+    launch_ref_accumulate(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, S, T, c->targets.normal_view(), c->out_index,
+                          c->out_dist2, c->thr_dev, c->owner, c->selected, c->ref_partials);
+  }
+  launch_ref_final_reduce(c->stream, c->jobs_dev, n_active, c->ref_partials, c->ref_sums_dev);
+  if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(c->ref_sums_host, c->ref_sums_dev, static_cast<size_t>(n_active) * kRefSums * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->thr_host, c->thr_dev, static_cast<size_t>(n_active) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->prof.iterations += 1;
+  c->prof.pairs_evaluated += pairs;
+  if (profile) {
+    float ms = 0.f;
+    if (bx) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->prof.nn_scan_ms += ms; c->prof.nn_scan_launches += 1; }
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->prof.resolve_ms += ms; c->prof.resolve_launches += 1;
+  }
+  return MI355_ICP_OK;
+}
+
+int check_reference_inputs(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* target_ids) {
+  if (c->targets.clouds.empty() || c->sources.clouds.empty()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference mode: upload clouds first");
+  if (!c->targets.normals)
+    return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT,
+                "reference mode needs target normals: upload the scene as rows of >= 6 float32 (xyz + normal, stride_bytes >= 24)");
+  for (int k = 0; k < n_jobs; ++k) {
+    const int s = source_ids ? source_ids[k] : 0, t = target_ids ? target_ids[k] : 0;
+    if (s < 0 || static_cast<size_t>(s) >= c->sources.clouds.size()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "source id out of range");
+    if (t < 0 || static_cast<size_t>(t) >= c->targets.clouds.size()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "target id out of range");
+  }
+  return MI355_ICP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -371,8 +530,20 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   if (c->comm) rccl_comm_destroy(c->comm);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
-  (void)hipFree(c->targets.planes);
-  (void)hipFree(c->sources.planes);
+  for (CloudSet* set : {&c->targets, &c->sources}) {
+    (void)hipFree(set->planes);
+    (void)hipFree(set->normals);
+    for (auto& lv : set->levels) (void)hipFree(lv.planes);
+  }
+  (void)hipFree(c->owner);
+  (void)hipFree(c->selected);
+  (void)hipFree(c->ref_partials);
+  (void)hipFree(c->ref_sums_dev);
+  (void)hipFree(c->thr_dev);
+  (void)hipFree(c->rjobs_dev);
+  if (c->rjobs_host) (void)hipHostFree(c->rjobs_host);
+  if (c->ref_sums_host) (void)hipHostFree(c->ref_sums_host);
+  if (c->thr_host) (void)hipHostFree(c->thr_host);
   (void)hipFree(c->keys);
   (void)hipFree(c->out_index);
   (void)hipFree(c->out_dist2);
@@ -486,6 +657,168 @@ int mi355_icp_correspond(mi355_icp_ctx* c, int n_jobs, const int* source_ids, co
     cursor += J.src_n;
   }
   return check_error_flag(c);
+}
+
+int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* target_ids,
+                              const double* init_poses, const mi355_icp_reference_params* rp, double* out_poses,
+                              double* out_residual, int* out_passes, int* out_status) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  c->err.clear();
+  if (n_jobs < 1 || !init_poses || !rp) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: bad arguments");
+  if (rp->iterations < 1 || rp->num_levels < 1 || rp->num_levels > 24) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: iterations >= 1 and 1 <= num_levels <= 24 required");
+  if (c->comm) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: not available on a slab-sharded context (the MAD threshold needs a global selection)");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int st = check_reference_inputs(c, n_jobs, source_ids, target_ids);
+  if (st != MI355_ICP_OK) return st;
+  HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+  const bool profile = c->profile_always || (rp->flags & MI355_ICP_FLAG_PROFILE) != 0;
+
+  struct JobState { double pose[16]; double residual = 0.0; int passes = 0; int status = MI355_ICP_OK; };
+  struct LevelState { double posex[16]; double start[16]; double fval_old, fval_perc, fval_min; int i; bool done; };
+  std::vector<JobState> js(static_cast<size_t>(n_jobs));
+  for (int k = 0; k < n_jobs; ++k) {
+    std::memcpy(js[k].pose, init_poses + 16 * static_cast<size_t>(k), sizeof(js[k].pose));
+    float tmp[12];
+    if (!pose_to_f32(js[k].pose, tmp)) return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "align_reference: non-finite initial pose");
+  }
+  auto sid = [&](int k) { return source_ids ? source_ids[k] : 0; };
+  auto tid = [&](int k) { return target_ids ? target_ids[k] : 0; };
+
+  for (int level = rp->num_levels - 1; level >= 0; --level) {
+    const uint32_t step = 1u << level;
+    std::vector<int> part, psid, ptid;
+    for (int k = 0; k < n_jobs; ++k) {
+      if (js[k].status != MI355_ICP_OK) continue;
+      const uint32_t ns_l = c->sources.clouds[sid(k)].n / step, nt_l = c->targets.clouds[tid(k)].n / step;
+      if (ns_l < 6 || nt_l < 1) continue;
+      part.push_back(k);
+      psid.push_back(sid(k));
+      ptid.push_back(tid(k));
+    }
+    if (part.empty()) continue;
+    if ((st = ensure_level(c, c->sources, level, kSrcPad, 0.0f)) != MI355_ICP_OK) return st;
+    if ((st = ensure_level(c, c->targets, level, kTile, kTargetPad)) != MI355_ICP_OK) return st;
+    Plan plan;
+    const int np = static_cast<int>(part.size());
+    if ((st = make_plan_on(c, level_clouds(c->sources, level), level_clouds(c->targets, level), np, psid.data(), ptid.data(), 0.0f, plan)) != MI355_ICP_OK) return st;
+    if ((st = ensure_buffers(c, plan, static_cast<size_t>(np))) != MI355_ICP_OK) return st;
+    std::vector<uint32_t> owner_off(static_cast<size_t>(np));
+    size_t owner_total = 0;
+    for (int a = 0; a < np; ++a) {
+      owner_off[a] = static_cast<uint32_t>(owner_total);
+      owner_total += level_clouds(c->targets, level)[ptid[a]].padded;
+    }
+    if ((st = ensure_ref_buffers(c, plan, static_cast<size_t>(np), owner_total)) != MI355_ICP_OK) return st;
+
+    const double tolp = static_cast<double>(rp->tolerance) * static_cast<double>(level + 1) * static_cast<double>(level + 1);
+    const int maxit = static_cast<int>(std::floor(static_cast<double>(rp->iterations) / static_cast<double>(level + 1) + 0.5));
+    std::vector<LevelState> ls(static_cast<size_t>(np));
+    for (int a = 0; a < np; ++a) {
+      const double I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      std::memcpy(ls[a].posex, I, sizeof(I));
+      std::memcpy(ls[a].start, js[part[a]].pose, sizeof(I));
+      ls[a].fval_old = 9999999999.0;
+      ls[a].fval_perc = 0.0;
+      ls[a].fval_min = 9999999999.0;
+      ls[a].i = 0;
+      ls[a].done = false;
+    }
+    for (;;) {
+      std::vector<int> active;
+      for (int a = 0; a < np; ++a) {
+        const LevelState& L = ls[a];
+        const bool in_band = L.fval_perc < 1.0 + tolp && L.fval_perc > 1.0 - tolp;
+        if (!L.done && !in_band && L.i < maxit) active.push_back(a);
+      }
+      if (active.empty()) break;
+      for (size_t q = 0; q < active.size(); ++q) {
+        const int a = active[q];
+        JobDesc J = plan.jobs[static_cast<size_t>(a)];
+        double cur[16];
+        mat4_mul(ls[a].posex, ls[a].start, cur);
+        RefJobDesc R{};
+        if (!pose_to_f32(cur, J.pose) || !pose_to_f32(ls[a].start, R.pose_start)) return fail(c, MI355_ICP_ERR_NUMERIC, "align_reference: pose overflowed float32");
+        R.owner_off = owner_off[a];
+        R.normal_off = c->targets.clouds[ptid[a]].off;
+        R.step = step;
+        c->jobs_host[q] = J;
+        c->rjobs_host[q] = R;
+      }
+      if ((st = run_ref_pass(c, plan, level, static_cast<int>(active.size()), rp->rejection_scale, owner_total, profile)) != MI355_ICP_OK) return st;
+      for (size_t q = 0; q < active.size(); ++q) {
+        const int a = active[q];
+        LevelState& L = ls[a];
+        const double* sums = c->ref_sums_host + q * kRefSums;
+        js[part[a]].passes += 1;
+        double x[6];
+        if (sums[28] < 6.0 || solve_point_to_plane(sums, x) != MI355_ICP_OK) {  // upstream: fewer than 6 pairs or a NaN solve leaves the level
+          L.done = true;
+          continue;
+        }
+        euler_pose(x, L.posex);
+        const double fval = std::sqrt(sums[27]) / static_cast<double>(plan.jobs[static_cast<size_t>(a)].src_n);
+        L.fval_perc = fval / L.fval_old;
+        L.fval_old = fval;
+        if (fval < L.fval_min) L.fval_min = fval;
+        L.i += 1;
+      }
+    }
+    for (int a = 0; a < np; ++a) {
+      JobState& S = js[part[a]];
+      mat4_mul(ls[a].posex, ls[a].start, S.pose);
+      S.residual = ls[a].fval_min;
+    }
+  }
+  if ((st = check_error_flag(c)) != MI355_ICP_OK) return st;
+  for (int k = 0; k < n_jobs; ++k) {
+    if (out_poses) std::memcpy(out_poses + 16 * static_cast<size_t>(k), js[k].pose, sizeof(js[k].pose));
+    if (out_residual) out_residual[k] = js[k].residual;
+    if (out_passes) out_passes[k] = js[k].passes;
+    if (out_status) out_status[k] = js[k].status;
+  }
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int level, const double* pose_start,
+                             const double* pose_cur, float rejection_scale, int32_t* out_index, float* out_dist2,
+                             uint8_t* out_selected, float* out_threshold, double* out_sums) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  c->err.clear();
+  if (!pose_start || !pose_cur || level < 0 || level > 23) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int st = check_reference_inputs(c, 1, &source_id, &target_id);
+  if (st != MI355_ICP_OK) return st;
+  if ((st = ensure_level(c, c->sources, level, kSrcPad, 0.0f)) != MI355_ICP_OK) return st;
+  if ((st = ensure_level(c, c->targets, level, kTile, kTargetPad)) != MI355_ICP_OK) return st;
+  Plan plan;
+  if ((st = make_plan_on(c, level_clouds(c->sources, level), level_clouds(c->targets, level), 1, &source_id, &target_id, 0.0f, plan)) != MI355_ICP_OK) return st;
+  if (plan.jobs[0].tgt_n < 1) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: the level has no target points");
+  if ((st = ensure_buffers(c, plan, 1)) != MI355_ICP_OK) return st;
+  const size_t owner_total = level_clouds(c->targets, level)[target_id].padded;
+  if ((st = ensure_ref_buffers(c, plan, 1, owner_total)) != MI355_ICP_OK) return st;
+  HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+  JobDesc J = plan.jobs[0];
+  RefJobDesc R{};
+  if (!pose_to_f32(pose_cur, J.pose) || !pose_to_f32(pose_start, R.pose_start)) return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "reference_pass: non-finite pose");
+  R.owner_off = 0;
+  R.normal_off = c->targets.clouds[target_id].off;
+  R.step = 1u << level;
+  c->jobs_host[0] = J;
+  c->rjobs_host[0] = R;
+  if ((st = run_ref_pass(c, plan, level, 1, rejection_scale, owner_total, c->profile_always)) != MI355_ICP_OK) return st;
+  if (out_sums) std::memcpy(out_sums, c->ref_sums_host, kRefSums * sizeof(double));
+  if (out_threshold) *out_threshold = c->thr_host[0];
+  if (J.src_n) {
+    if (out_index) HIP_TRY(c, hipMemcpy(out_index, c->out_index + J.out_off, J.src_n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (out_dist2) HIP_TRY(c, hipMemcpy(out_dist2, c->out_dist2 + J.out_off, J.src_n * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_selected) HIP_TRY(c, hipMemcpy(out_selected, c->selected + J.out_off, J.src_n * sizeof(uint8_t), hipMemcpyDeviceToHost));
+  }
+  return check_error_flag(c);
+}
+
+int mi355_icp_solve_point_to_plane(const double* sums29, double out_x[6]) {
+  if (!sums29 || !out_x) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  return solve_point_to_plane(sums29, out_x);
 }
 
 int mi355_icp_comm_unique_id(unsigned char out_id[MI355_ICP_UNIQUE_ID_BYTES]) {

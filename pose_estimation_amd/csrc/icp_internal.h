@@ -40,6 +40,21 @@ struct JobDesc {
 };
 static_assert(sizeof(JobDesc) == 112, "JobDesc layout");
 
+// ---- reference mode (point-to-plane / rejection / picky / pyramid): icp_ref_kernels.hip ----
+constexpr int kRefSums = 29;  // 21 upper-triangle A^T A + 6 A^T b + sum |p-q|^2 + count
+struct RefJobDesc {
+  uint32_t owner_off;    // first slot of this job's target in the picky owner table
+  uint32_t normal_off;   // first point of the job's target cloud in the LEVEL-0 normal planes
+  uint32_t step;         // level stride: level point j is level-0 point j * step
+  uint32_t pad_;
+  float pose_start[12];  // float32 pose the level started from (defines the point the plane equation is written for)
+};
+static_assert(sizeof(RefJobDesc) == 64, "RefJobDesc layout");
+
+int solve_point_to_plane(const double* sums29, double* x6);
+void euler_pose(const double* x6, double* pose16);
+void mat4_mul(const double* a, const double* b, double* c);
+
 // ---- host math (host_math.cpp) ----
 int solve_rigid(const double* sums, double* pose16);
 int host_update(const mi355_icp_params* p, const double* sums, int iteration, double* pose16, double* prev_mse,
@@ -57,6 +72,19 @@ void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t 
                     DevicePlanes tgt, const unsigned long long* keys, uint32_t key_stride, int32_t* out_index,
                     float* out_dist2, double* partials, uint32_t* error_flag);
 void launch_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums);
+
+void launch_subsample(void* stream, const float* in, size_t in_stride, uint32_t in_off, float* out, size_t out_stride,
+                      uint32_t out_off, uint32_t n_level, uint32_t n_padded, uint32_t step, float pad);
+void launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, const float* dist2, float scale,
+                             float* thr);
+void launch_picky_scatter(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
+                          uint32_t max_src_blocks, const int32_t* index, const float* dist2, const float* thr,
+                          unsigned long long* owner);
+void launch_ref_accumulate(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
+                           uint32_t max_src_blocks, DevicePlanes src, DevicePlanes tgt, DevicePlanes normals,
+                           const int32_t* index, const float* dist2, const float* thr, const unsigned long long* owner,
+                           uint8_t* selected, double* partials);
+void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums);
 
 // ---- RCCL, bound at run time (rccl_dyn.cpp) ----
 struct RcclApi;

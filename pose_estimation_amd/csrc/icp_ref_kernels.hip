@@ -1,0 +1,273 @@
+// icp_ref_kernels.hip — gfx950 kernels of the "reference mode" pass: what
+// cv::ppf_match_3d::ICP(iterations, tolerance, rejectionScale, numLevels) adds around the exact NN scan —
+// resolution pyramid (strided subsampling), median + MAD rejection, "picky" one-to-one dedupe and the
+// linearised point-to-plane normal equations (reference call site: opencv_surface_match.cpp:85,94).
+// The NN scan itself is nn_scan_kernel / resolve_accumulate_kernel of icp_kernels.hip, run on the level's
+// compacted planes.  Arithmetic contract: oracle/icp_oracle.c, second half (bit-exact threshold, mask and
+// winners; sums in double).  Compile with -ffp-contract=off like icp_kernels.hip.
+//
+//   subsample_kernel          level planes:  out[i] = in[i * step], padded
+//   rejection_select_kernel   per job, ONE workgroup: exact rank select (3-pass 11/11/10-bit radix on the
+//                             float bits, LDS histograms) of d2, then of |d2 - med|  ->  threshold
+//   picky_scatter_kernel      accepted pairs: atomicMin(owner[target], d2 bits << 32 | source index)
+//   ref_accumulate_kernel     winners: 21 + 6 normal-equation sums, sum |p-q|^2, count (29 doubles)
+//   ref_final_reduce_kernel   fixed-order reduction of the per-workgroup partials
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "icp_internal.h"
+
+namespace mi355 {
+
+namespace {
+
+__device__ __forceinline__ void transform_point(const float* __restrict__ m, float x, float y, float z, float& ox,
+                                                float& oy, float& oz) {
+  float a, b;
+  a = m[0] * x; b = m[1] * y; a = a + b; b = m[2] * z; a = a + b; ox = a + m[3];
+  a = m[4] * x; b = m[5] * y; a = a + b; b = m[6] * z; a = a + b; oy = a + m[7];
+  a = m[8] * x; b = m[9] * y; a = a + b; b = m[10] * z; a = a + b; oz = a + m[11];
+}
+
+template <int NV>
+__device__ __forceinline__ double block_sum(double (&v)[NV], double (*scratch)[NV]) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double x = v[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    v[k] = x;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) scratch[wave][k] = v[k];
+  }
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x < NV) {
+    r = scratch[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kBlockThreads / 64; ++w) r += scratch[w][threadIdx.x];
+  }
+  return r;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlockThreads) void subsample_kernel(const float* __restrict__ in, size_t in_stride,
+                                                                   uint32_t in_off, float* __restrict__ out,
+                                                                   size_t out_stride, uint32_t out_off, uint32_t n_level,
+                                                                   uint32_t n_padded, uint32_t step, float pad) {
+  const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
+  if (i >= n_padded) return;
+#pragma unroll
+  for (int plane = 0; plane < 3; ++plane) {
+    const float v = i < n_level ? in[plane * in_stride + in_off + static_cast<size_t>(i) * step] : pad;
+    out[plane * out_stride + out_off + i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact rank select of non-negative float32 values by their bit pattern (monotone for x >= 0).
+// kSelThreads threads cooperate; `value_of(i)` yields element i.  Returns the element of 0-based rank k.
+constexpr int kSelThreads = 1024;
+
+template <typename F>
+__device__ uint32_t radix_select(uint32_t n, uint32_t k, uint32_t* hist /* 2048 */, uint32_t* bcast /* 2 */, F value_of) {
+  uint32_t prefix = 0, mask = 0;
+  const int shifts[3] = {21, 10, 0};
+  const int widths[3] = {11, 11, 10};
+#pragma unroll 1
+  for (int pass = 0; pass < 3; ++pass) {
+    const int shift = shifts[pass];
+    const uint32_t nb = 1u << widths[pass];
+    for (uint32_t b = threadIdx.x; b < 2048; b += kSelThreads) hist[b] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += kSelThreads) {
+      const uint32_t bits = __float_as_uint(value_of(i));
+      if ((bits & mask) == prefix) atomicAdd(&hist[(bits >> shift) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // 2048 bins: a serial walk is a few microseconds
+      uint32_t acc = 0, d = 0;
+      for (; d < nb; ++d) {
+        const uint32_t c = hist[d];
+        if (acc + c > k) break;
+        acc += c;
+      }
+      bcast[0] = d;
+      bcast[1] = k - acc;
+    }
+    __syncthreads();
+    prefix |= bcast[0] << shift;
+    mask |= (nb - 1) << shift;
+    k = bcast[1];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+// grid = n_jobs, block = kSelThreads.  thr[job] = scale * (1.48257968f * median|d2 - med|) + med, float32 ops as the oracle.
+__global__ __launch_bounds__(kSelThreads) void rejection_select_kernel(const JobDesc* __restrict__ jobs,
+                                                                        const float* __restrict__ dist2, float scale,
+                                                                        float* __restrict__ thr_out) {
+  __shared__ uint32_t hist[2048];
+  __shared__ uint32_t bcast[2];
+  const JobDesc& J = jobs[blockIdx.x];
+  const uint32_t n = J.src_n;
+  if (n == 0) {
+    if (threadIdx.x == 0) thr_out[blockIdx.x] = __builtin_inff();
+    return;
+  }
+  const float* __restrict__ d = dist2 + J.out_off;
+  const uint32_t k = (n - 1) / 2;
+  const float med = __uint_as_float(radix_select(n, k, hist, bcast, [&](uint32_t i) { return d[i]; }));
+  const float mad = __uint_as_float(radix_select(n, k, hist, bcast, [&](uint32_t i) {
+    return static_cast<float>(__builtin_fabs(static_cast<double>(d[i]) - static_cast<double>(med)));
+  }));
+  if (threadIdx.x == 0) {
+    const float s = 1.48257968f * mad;
+    const float t = scale * s;
+    thr_out[blockIdx.x] = t + med;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// grid = (max src_blocks, n_jobs).  owner[] was set to ~0 before the launch.
+__global__ __launch_bounds__(kBlockThreads) void picky_scatter_kernel(const JobDesc* __restrict__ jobs,
+                                                                       const RefJobDesc* __restrict__ rjobs,
+                                                                       const int32_t* __restrict__ index,
+                                                                       const float* __restrict__ dist2,
+                                                                       const float* __restrict__ thr,
+                                                                       unsigned long long* __restrict__ owner) {
+  const JobDesc& J = jobs[blockIdx.y];
+  if (blockIdx.x >= J.src_blocks) return;
+  const float t = thr[blockIdx.y];
+  const uint32_t owner_off = rjobs[blockIdx.y].owner_off;
+#pragma unroll
+  for (int p = 0; p < kResolvePointsPerLane; ++p) {
+    const uint32_t local = blockIdx.x * kSrcPerBlock + p * kBlockThreads + threadIdx.x;
+    if (local < J.src_n) {
+      const float d = dist2[J.out_off + local];
+      if (d < t) {
+        const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | local;
+        atomicMin(&owner[owner_off + static_cast<uint32_t>(index[J.out_off + local])], key);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// grid = (max src_blocks, n_jobs).  src/tgt are the LEVEL planes; normals are the level-0 normal planes.
+__global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
+    const JobDesc* __restrict__ jobs, const RefJobDesc* __restrict__ rjobs, const float* __restrict__ sx,
+    const float* __restrict__ sy, const float* __restrict__ sz, const float* __restrict__ tx,
+    const float* __restrict__ ty, const float* __restrict__ tz, const float* __restrict__ nx,
+    const float* __restrict__ ny, const float* __restrict__ nz, const int32_t* __restrict__ index,
+    const float* __restrict__ dist2, const float* __restrict__ thr, const unsigned long long* __restrict__ owner,
+    uint8_t* __restrict__ selected, double* __restrict__ partials) {
+  __shared__ double scratch[kBlockThreads / 64][kRefSums];
+  const JobDesc& J = jobs[blockIdx.y];
+  const uint32_t sb = blockIdx.x;
+  if (sb >= J.src_blocks) return;
+  const RefJobDesc& RJ = rjobs[blockIdx.y];
+  float pose[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) pose[k] = RJ.pose_start[k];
+  const float t = thr[blockIdx.y];
+  double acc[kRefSums];
+#pragma unroll
+  for (int k = 0; k < kRefSums; ++k) acc[k] = 0.0;
+#pragma unroll 1
+  for (int p = 0; p < kResolvePointsPerLane; ++p) {
+    const uint32_t local = sb * kSrcPerBlock + p * kBlockThreads + threadIdx.x;
+    if (local < J.src_n) {
+      const float d = dist2[J.out_off + local];
+      const uint32_t j = static_cast<uint32_t>(index[J.out_off + local]);
+      const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | local;
+      const bool sel = (d < t) && owner[RJ.owner_off + j] == key;
+      selected[J.out_off + local] = sel ? 1 : 0;
+      if (sel) {
+        const uint32_t i = J.src_off + local;
+        float px, py, pz;
+        transform_point(pose, sx[i], sy[i], sz[i], px, py, pz);  // the level-start point
+        const uint32_t tj = J.tgt_off + j;
+        const size_t nj = static_cast<size_t>(RJ.normal_off) + static_cast<size_t>(j) * RJ.step;
+        const double P0 = px, P1 = py, P2 = pz, Q0 = tx[tj], Q1 = ty[tj], Q2 = tz[tj];
+        const double N0 = nx[nj], N1 = ny[nj], N2 = nz[nj];
+        const double a[6] = {P1 * N2 - P2 * N1, P2 * N0 - P0 * N2, P0 * N1 - P1 * N0, N0, N1, N2};
+        const double dx = Q0 - P0, dy = Q1 - P1, dz = Q2 - P2;
+        const double b = dx * N0 + dy * N1 + dz * N2;
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = r; c < 6; ++c) acc[k++] += a[r] * a[c];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[21 + r] += a[r] * b;
+        acc[27] += dx * dx + dy * dy + dz * dz;
+        acc[28] += 1.0;
+      }
+    }
+  }
+  const double r = block_sum<kRefSums>(acc, scratch);
+  if (threadIdx.x < kRefSums) partials[static_cast<size_t>(J.partial_off + sb) * kRefSums + threadIdx.x] = r;
+}
+
+__global__ __launch_bounds__(kBlockThreads) void ref_final_reduce_kernel(const JobDesc* __restrict__ jobs,
+                                                                          const double* __restrict__ partials,
+                                                                          double* __restrict__ sums) {
+  __shared__ double scratch[kBlockThreads / 64][kRefSums];
+  const JobDesc& J = jobs[blockIdx.x];
+  double acc[kRefSums];
+#pragma unroll
+  for (int k = 0; k < kRefSums; ++k) acc[k] = 0.0;
+  for (uint32_t b = threadIdx.x; b < J.src_blocks; b += kBlockThreads) {
+    const double* __restrict__ row = partials + static_cast<size_t>(J.partial_off + b) * kRefSums;
+#pragma unroll
+    for (int k = 0; k < kRefSums; ++k) acc[k] += row[k];
+  }
+  const double r = block_sum<kRefSums>(acc, scratch);
+  if (threadIdx.x < kRefSums) sums[static_cast<size_t>(blockIdx.x) * kRefSums + threadIdx.x] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+void launch_subsample(void* stream, const float* in, size_t in_stride, uint32_t in_off, float* out, size_t out_stride,
+                      uint32_t out_off, uint32_t n_level, uint32_t n_padded, uint32_t step, float pad) {
+  if (!n_padded) return;
+  hipLaunchKernelGGL(subsample_kernel, dim3((n_padded + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0,
+                     static_cast<hipStream_t>(stream), in, in_stride, in_off, out, out_stride, out_off, n_level, n_padded,
+                     step, pad);
+}
+
+void launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, const float* dist2, float scale,
+                             float* thr) {
+  hipLaunchKernelGGL(rejection_select_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kSelThreads), 0,
+                     static_cast<hipStream_t>(stream), jobs_dev, dist2, scale, thr);
+}
+
+void launch_picky_scatter(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
+                          uint32_t max_src_blocks, const int32_t* index, const float* dist2, const float* thr,
+                          unsigned long long* owner) {
+  hipLaunchKernelGGL(picky_scatter_kernel, dim3(max_src_blocks, static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0,
+                     static_cast<hipStream_t>(stream), jobs_dev, rjobs_dev, index, dist2, thr, owner);
+}
+
+void launch_ref_accumulate(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
+                           uint32_t max_src_blocks, DevicePlanes src, DevicePlanes tgt, DevicePlanes normals,
+                           const int32_t* index, const float* dist2, const float* thr, const unsigned long long* owner,
+                           uint8_t* selected, double* partials) {
+  hipLaunchKernelGGL(ref_accumulate_kernel, dim3(max_src_blocks, static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0,
+                     static_cast<hipStream_t>(stream), jobs_dev, rjobs_dev, src.x, src.y, src.z, tgt.x, tgt.y, tgt.z,
+                     normals.x, normals.y, normals.z, index, dist2, thr, owner, selected, partials);
+}
+
+void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums) {
+  hipLaunchKernelGGL(ref_final_reduce_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0,
+                     static_cast<hipStream_t>(stream), jobs_dev, partials, sums);
+}
+
+}  // namespace mi355

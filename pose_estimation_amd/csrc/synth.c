@@ -31,8 +31,25 @@ static inline double u01(uint64_t seed, uint64_t ctr) {
   return (double)(x >> 11) * (1.0 / 9007199254740992.0);
 }
 
+static int synth_rows(uint64_t seed, uint64_t noise_seed, double sigma, const double* T, size_t first_index,
+                      size_t count, float* out, int with_normals);
+
 int mi355_icp_synth_cloud(uint64_t seed, uint64_t noise_seed, double sigma, const double* T, size_t first_index,
                           size_t count, float* out_xyz) {
+  return synth_rows(seed, noise_seed, sigma, T, first_index, count, out_xyz, 0);
+}
+
+/* Same sample as rows of 6 floats: xyz, then the unit outward normal of the noise-free surface at that sample
+ * (gradient of F(p) = |p| - r(p/|p|)), rotated with the transform.  The layout of the reference's model and
+ * scene clouds with normals (N x 6 CV_32F: opencv_surface_match.cpp:22,57-59). */
+int mi355_icp_synth_cloud6(uint64_t seed, uint64_t noise_seed, double sigma, const double* T, size_t first_index,
+                           size_t count, float* out_xyz_normal) {
+  return synth_rows(seed, noise_seed, sigma, T, first_index, count, out_xyz_normal, 1);
+}
+
+static int synth_rows(uint64_t seed, uint64_t noise_seed, double sigma, const double* T, size_t first_index,
+                      size_t count, float* out_xyz, int with_normals) {
+  const size_t row = with_normals ? 6 : 3;
   if (!out_xyz && count) return MI355_ICP_ERR_INVALID_ARGUMENT;
   const double sqrt3 = sqrt(3.0);
   for (size_t n = 0; n < count; ++n) {
@@ -53,6 +70,14 @@ int mi355_icp_synth_cloud(uint64_t seed, uint64_t noise_seed, double sigma, cons
     rad = rad + 0.10 * ((uy * uy) * uy);
     rad = rad - 0.08 * uz;
     double p[3] = {rad * ux, rad * uy, rad * uz};
+    double nrm[3] = {0, 0, 0};
+    if (with_normals) {
+      const double g0 = 0.25 * uy + 0.15 * (uz * uz), g1 = 0.25 * ux + 0.30 * (uy * uy), g2 = 0.30 * (uz * ux) - 0.08;
+      const double gu = (g0 * ux + g1 * uy) + g2 * uz;
+      double m0 = ux - (g0 - gu * ux) / rad, m1 = uy - (g1 - gu * uy) / rad, m2 = uz - (g2 - gu * uz) / rad;
+      const double ml = sqrt((m0 * m0 + m1 * m1) + m2 * m2);
+      nrm[0] = m0 / ml; nrm[1] = m1 / ml; nrm[2] = m2 / ml;
+    }
     if (sigma > 0.0) {
       for (int d = 0; d < 3; ++d) {
         uint64_t base = (i * 4 + (uint64_t)d) * 4;
@@ -66,10 +91,21 @@ int mi355_icp_synth_cloud(uint64_t seed, uint64_t noise_seed, double sigma, cons
       double q1 = ((T[4] * p[0] + T[5] * p[1]) + T[6] * p[2]) + T[7];
       double q2 = ((T[8] * p[0] + T[9] * p[1]) + T[10] * p[2]) + T[11];
       p[0] = q0; p[1] = q1; p[2] = q2;
+      if (with_normals) {
+        double r0 = (T[0] * nrm[0] + T[1] * nrm[1]) + T[2] * nrm[2];
+        double r1 = (T[4] * nrm[0] + T[5] * nrm[1]) + T[6] * nrm[2];
+        double r2 = (T[8] * nrm[0] + T[9] * nrm[1]) + T[10] * nrm[2];
+        nrm[0] = r0; nrm[1] = r1; nrm[2] = r2;
+      }
     }
-    out_xyz[3 * n + 0] = (float)p[0];
-    out_xyz[3 * n + 1] = (float)p[1];
-    out_xyz[3 * n + 2] = (float)p[2];
+    out_xyz[row * n + 0] = (float)p[0];
+    out_xyz[row * n + 1] = (float)p[1];
+    out_xyz[row * n + 2] = (float)p[2];
+    if (with_normals) {
+      out_xyz[row * n + 3] = (float)nrm[0];
+      out_xyz[row * n + 4] = (float)nrm[1];
+      out_xyz[row * n + 5] = (float)nrm[2];
+    }
   }
   return MI355_ICP_OK;
 }

@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import lib, Params, Profile, NSUMS
+from ._lib import lib, Params, Profile, ReferenceParams, NSUMS, NREFSUMS
 
 
 class IcpError(RuntimeError):
@@ -71,6 +71,16 @@ def host_update(params: Params, sums: np.ndarray, iteration: int, pose: np.ndarr
     return st, p.reshape(4, 4), mse.value, bool(done.value), bool(conv.value)
 
 
+def solve_point_to_plane(sums: np.ndarray) -> np.ndarray:
+    sums = np.ascontiguousarray(sums, dtype=np.float64)
+    assert sums.shape == (NREFSUMS,)
+    x = np.empty(6, dtype=np.float64)
+    st = lib.mi355_icp_solve_point_to_plane(sums.ctypes.data, x.ctypes.data)
+    if st != _lib.OK:
+        raise IcpError(st, "solve_point_to_plane")
+    return x
+
+
 def pose_to_pose7(pose: np.ndarray, reference_packing: bool = False) -> np.ndarray:
     p = np.ascontiguousarray(pose, dtype=np.float64).reshape(16)
     out = np.zeros(7, dtype=np.float32)
@@ -81,17 +91,26 @@ def pose_to_pose7(pose: np.ndarray, reference_packing: bool = False) -> np.ndarr
 
 
 def synth_cloud(seed: int, count: int, first_index: int = 0, noise_seed: int = 0, sigma: float = 0.0,
-                transform: Optional[np.ndarray] = None) -> np.ndarray:
-    """Deterministic synthetic surface sample (csrc/synth.c), float32 [count, 3]."""
-    out = np.empty((count, 3), dtype=np.float32)
+                transform: Optional[np.ndarray] = None, normals: bool = False) -> np.ndarray:
+    """Deterministic synthetic surface sample (csrc/synth.c), float32 [count, 3] (or [count, 6] with normals)."""
+    out = np.empty((count, 6 if normals else 3), dtype=np.float32)
     t = None
     if transform is not None:
         t = np.ascontiguousarray(np.asarray(transform, dtype=np.float64)[:3, :4]).reshape(12)
-    st = lib.mi355_icp_synth_cloud(seed, noise_seed, float(sigma), t.ctypes.data if t is not None else None,
-                                   first_index, count, out.ctypes.data)
+    fn = lib.mi355_icp_synth_cloud6 if normals else lib.mi355_icp_synth_cloud
+    st = fn(seed, noise_seed, float(sigma), t.ctypes.data if t is not None else None, first_index, count,
+            out.ctypes.data)
     if st != _lib.OK:
         raise IcpError(st, "synth_cloud")
     return out
+
+
+@dataclass
+class ReferenceResult:
+    poses: np.ndarray     # [n_jobs, 4, 4]
+    residual: np.ndarray  # [n_jobs] smallest fval of the finest level that ran (cloud units)
+    passes: np.ndarray    # [n_jobs] correspondence passes over all pyramid levels
+    status: np.ndarray    # [n_jobs]
 
 
 @dataclass
@@ -211,6 +230,39 @@ class IcpEngine:
                                              idx.ctypes.data if want_pairs else None,
                                              d2.ctypes.data if want_pairs else None, sums.ctypes.data))
         return idx, d2, sums
+
+    # -- reference mode (pyramid + MAD rejection + picky + point-to-plane)
+    def align_reference(self, init_poses: np.ndarray, iterations: int = 250, tolerance: float = 0.005,
+                        rejection_scale: float = 2.5, num_levels: int = 8, source_ids=None, target_ids=None,
+                        flags: int = 0) -> ReferenceResult:
+        poses = np.ascontiguousarray(init_poses, dtype=np.float64).reshape(-1, 16)
+        n = poses.shape[0]
+        sid, tid = self._ids(source_ids, n), self._ids(target_ids, n)
+        rp = ReferenceParams(iterations, tolerance, rejection_scale, num_levels, flags)
+        out_p = np.empty((n, 16), dtype=np.float64)
+        out_r = np.empty(n, dtype=np.float64)
+        out_i = np.empty(n, dtype=np.int32)
+        out_s = np.empty(n, dtype=np.int32)
+        self._check(lib.mi355_icp_align_reference(self._h, n, sid.ctypes.data, tid.ctypes.data, poses.ctypes.data,
+                                                  C.byref(rp), out_p.ctypes.data, out_r.ctypes.data, out_i.ctypes.data,
+                                                  out_s.ctypes.data))
+        return ReferenceResult(out_p.reshape(n, 4, 4), out_r, out_i, out_s)
+
+    def reference_pass(self, pose_start: np.ndarray, pose_cur: np.ndarray, level: int = 0, rejection_scale: float = 2.5,
+                       source_id: int = 0, target_id: int = 0):
+        """One reference-mode pass: (index, dist2, selected mask, threshold, sums[29]) on pyramid level `level`."""
+        n = self._source_sizes[source_id] >> level
+        ps = np.ascontiguousarray(pose_start, dtype=np.float64).reshape(16)
+        pc = np.ascontiguousarray(pose_cur, dtype=np.float64).reshape(16)
+        idx = np.empty(n, dtype=np.int32)
+        d2 = np.empty(n, dtype=np.float32)
+        sel = np.empty(n, dtype=np.uint8)
+        thr = C.c_float()
+        sums = np.empty(NREFSUMS, dtype=np.float64)
+        self._check(lib.mi355_icp_reference_pass(self._h, source_id, target_id, level, ps.ctypes.data, pc.ctypes.data,
+                                                 float(rejection_scale), idx.ctypes.data, d2.ctypes.data, sel.ctypes.data,
+                                                 C.byref(thr), sums.ctypes.data))
+        return idx, d2, sel.astype(bool), thr.value, sums
 
     # -- multi-GPU
     @staticmethod

@@ -11,9 +11,11 @@ and then reads ``pose``, ``residual``, ``numVotes``, ``t`` and ``q`` off each Po
 in-place update behaviour, so code (and tests) written against the reference read the same;
 the arithmetic runs on the GPU through IcpEngine (C-ABI, include/mi355_icp.h).
 
-Not mirrored ("next"): upstream's point-to-plane error metric, MAD
-rejection (``rejectionScale``) and the resolution pyramid (``numLevels``).  They are accepted
-and recorded so call sites do not change, but this engine runs exact point-to-point ICP.
+Two modes.  ``mode="point_to_point"`` (default) is the engine BASELINE.json specifies: exact NN,
+Kabsch, ``iterations``/``tolerence`` only.  ``mode="reference"`` runs what upstream's class really
+does with all four constructor arguments live — resolution pyramid (``numLevels``), median+MAD
+rejection (``rejectionScale``), picky dedupe and point-to-plane least squares on the scene normals
+(numeric definition in oracle/icp_oracle.c) — and needs the scene as N x 6.
 """
 from __future__ import annotations
 
@@ -111,7 +113,10 @@ class ICP:
 
     def __init__(self, iterations: int = 250, tolerence: float = 0.05, rejectionScale: float = 2.5,
                  numLevels: int = 6, sampleType: int = 0, numMaxCorr: int = 1, device_id: int = 0,
-                 engine: Optional[IcpEngine] = None):
+                 engine: Optional[IcpEngine] = None, mode: str = "point_to_point"):
+        if mode not in ("point_to_point", "reference"):
+            raise ValueError("mode must be 'point_to_point' or 'reference'")
+        self.mode = mode
         self.iterations = int(iterations)
         self.tolerence = float(tolerence)
         self.rejectionScale = float(rejectionScale)
@@ -141,8 +146,12 @@ class ICP:
         if not plist:
             return 0
         init = np.stack([p.pose for p in plist])
-        res = self.engine.align(init, self.params, source_ids=[source_id] * len(plist),
-                                target_ids=[target_id] * len(plist))
+        if self.mode == "reference":
+            res = self.engine.align_reference(init, self.iterations, self.tolerence, self.rejectionScale, self.numLevels,
+                                              source_ids=[source_id] * len(plist), target_ids=[target_id] * len(plist))
+        else:
+            res = self.engine.align(init, self.params, source_ids=[source_id] * len(plist),
+                                    target_ids=[target_id] * len(plist))
         for k, p in enumerate(plist):
             # a failed job leaves the candidate unrefined (the reference swallows the exception:
             # opencv_surface_match.cpp:144-147); res.poses[k] is then the last valid pose

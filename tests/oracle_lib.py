@@ -180,3 +180,76 @@ def pose_to_pose7(pose, reference_packing=False):
 
 def max_threads() -> int:
     return lib.oracle_omp_max_threads()
+
+
+# ---- reference mode (point-to-plane / MAD rejection / picky / pyramid): oracle/icp_oracle.c, second half ----
+NREF = 29
+
+
+class OracleRefParams(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("tolerance", C.c_float), ("rejection_scale", C.c_float),
+                ("num_levels", C.c_int32)]
+
+
+lib.oracle_select_rank.restype = C.c_float
+lib.oracle_select_rank.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+lib.oracle_rejection_threshold.restype = C.c_float
+lib.oracle_rejection_threshold.argtypes = [C.c_void_p, C.c_size_t, C.c_float]
+lib.oracle_solve_point_to_plane.restype = C.c_int
+lib.oracle_solve_point_to_plane.argtypes = [C.c_void_p, C.c_void_p]
+lib.oracle_euler_pose.argtypes = [C.c_void_p, C.c_void_p]
+lib.oracle_ref_pass.restype = C.c_size_t
+lib.oracle_ref_pass.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+lib.oracle_icp_reference.restype = C.c_int
+lib.oracle_icp_reference.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(OracleRefParams),
+                                     C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+
+
+def rejection_threshold(d2, scale) -> float:
+    d2 = np.ascontiguousarray(d2, dtype=np.float32)
+    return float(lib.oracle_rejection_threshold(d2.ctypes.data, d2.shape[0], float(scale)))
+
+
+def solve_point_to_plane(sums):
+    sums = np.ascontiguousarray(sums, dtype=np.float64)
+    x = np.empty(6)
+    st = lib.oracle_solve_point_to_plane(sums.ctypes.data, x.ctypes.data)
+    return st, x
+
+
+def euler_pose(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    P = np.empty(16)
+    lib.oracle_euler_pose(x.ctypes.data, P.ctypes.data)
+    return P.reshape(4, 4)
+
+
+def ref_pass(src_xyz, tgt6, pose_start, pose_cur, rejection_scale, nthreads=1):
+    """One reference-mode pass on level clouds: (n_selected, sums[29], idx, d2, selected mask, threshold)."""
+    src = _f32(src_xyz)
+    tgt6 = np.ascontiguousarray(tgt6, dtype=np.float32)
+    assert tgt6.ndim == 2 and tgt6.shape[1] == 6
+    ps = np.ascontiguousarray(pose_start, dtype=np.float64).reshape(16)
+    pc = np.ascontiguousarray(pose_cur, dtype=np.float64).reshape(16)
+    sums = np.empty(NREF)
+    idx = np.empty(src.shape[0], dtype=np.int32)
+    d2 = np.empty(src.shape[0], dtype=np.float32)
+    sel = np.empty(src.shape[0], dtype=np.uint8)
+    thr = C.c_float()
+    n = lib.oracle_ref_pass(src.ctypes.data, src.shape[0], tgt6.ctypes.data, tgt6.shape[0], ps.ctypes.data, pc.ctypes.data,
+                            float(rejection_scale), nthreads, sums.ctypes.data, idx.ctypes.data, d2.ctypes.data,
+                            sel.ctypes.data, C.byref(thr))
+    return int(n), sums, idx, d2, sel.astype(bool), thr.value
+
+
+def icp_reference(src_xyz, tgt6, init_pose, iterations=250, tolerance=0.005, rejection_scale=2.5, num_levels=8, nthreads=1):
+    src = _f32(np.asarray(src_xyz)[:, :3])
+    tgt6 = np.ascontiguousarray(tgt6, dtype=np.float32)
+    init = np.ascontiguousarray(init_pose, dtype=np.float64).reshape(16)
+    rp = OracleRefParams(iterations, tolerance, rejection_scale, num_levels)
+    out = np.empty(16)
+    res, passes = C.c_double(), C.c_int()
+    st = lib.oracle_icp_reference(src.ctypes.data, src.shape[0], tgt6.ctypes.data, tgt6.shape[0], init.ctypes.data,
+                                  C.byref(rp), nthreads, out.ctypes.data, C.byref(res), C.byref(passes))
+    return {"status": st, "pose": out.reshape(4, 4), "residual": res.value, "passes": passes.value}

@@ -31,7 +31,7 @@ def _u01(seed: int, ctr: np.ndarray) -> np.ndarray:
     return (x >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
-def synth_cloud_np(seed, count, first_index=0, noise_seed=0, sigma=0.0, transform=None) -> np.ndarray:
+def synth_cloud_np(seed, count, first_index=0, noise_seed=0, sigma=0.0, transform=None, normals=False) -> np.ndarray:
     i = np.arange(first_index, first_index + count, dtype=np.uint64)
     a = np.ones(count)
     b = np.zeros(count)
@@ -60,6 +60,17 @@ def synth_cloud_np(seed, count, first_index=0, noise_seed=0, sigma=0.0, transfor
         rad = rad + 0.10 * ((uy * uy) * uy)
         rad = rad - 0.08 * uz
         p = np.stack([rad * ux, rad * uy, rad * uz], axis=1)
+        nrm = None
+        if normals:
+            g0 = 0.25 * uy + 0.15 * (uz * uz)
+            g1 = 0.25 * ux + 0.30 * (uy * uy)
+            g2 = 0.30 * (uz * ux) - 0.08
+            gu = (g0 * ux + g1 * uy) + g2 * uz
+            m0 = ux - (g0 - gu * ux) / rad
+            m1 = uy - (g1 - gu * uy) / rad
+            m2 = uz - (g2 - gu * uz) / rad
+            ml = np.sqrt((m0 * m0 + m1 * m1) + m2 * m2)
+            nrm = np.stack([m0 / ml, m1 / ml, m2 / ml], axis=1)
         if sigma > 0.0:
             sqrt3 = math.sqrt(3.0)
             for d in range(3):
@@ -73,6 +84,13 @@ def synth_cloud_np(seed, count, first_index=0, noise_seed=0, sigma=0.0, transfor
         for r in range(3):
             q[:, r] = ((T[r, 0] * p[:, 0] + T[r, 1] * p[:, 1]) + T[r, 2] * p[:, 2]) + T[r, 3]
         p = q
+        if nrm is not None:
+            qn = np.empty_like(nrm)
+            for r in range(3):
+                qn[:, r] = (T[r, 0] * nrm[:, 0] + T[r, 1] * nrm[:, 1]) + T[r, 2] * nrm[:, 2]
+            nrm = qn
+    if nrm is not None:
+        return np.concatenate([p, nrm], axis=1).astype(np.float32)
     return p.astype(np.float32)
 
 

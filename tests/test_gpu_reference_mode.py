@@ -1,0 +1,86 @@
+"""Reference mode on the GPU against the oracle: per-pass (index, d2, threshold, winners bit-exact; sums 1e-10),
+and whole alignments (pose <= 1e-5 Frobenius, same number of passes)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ora
+import synth_twin as st
+
+pytestmark = pytest.mark.gpu
+POSE_TOL = 1e-5
+
+
+def pair6(ns, nt, k=-1):
+    T = st.perturbation(k)
+    off = 0 if k < 0 else 16 * k
+    tgt = st.synth_cloud_np(st.TARGET_SEED + off, nt, normals=True)
+    src = st.synth_cloud_np(st.SOURCE_SEED + off, ns, noise_seed=st.NOISE_SEED + off, sigma=st.SIGMA, transform=T)
+    return src, tgt, np.linalg.inv(T)
+
+
+@pytest.mark.parametrize("ns,nt", [(3000, 2500), (1337, 777), (40000, 30000), (5000, 100)])
+def test_reference_pass_matches_oracle(engine, ns, nt):
+    src, tgt, gt = pair6(ns, nt)
+    engine.set_targets([tgt])
+    engine.set_sources([src])
+    start = st.rigid_transform(0.7, (0.1, 1, 0.3), (0.004, 0.001, -0.002))
+    cur = st.rigid_transform(0.2, (1, 0, 0), (0.001, 0, 0)) @ start
+    for level in (0, 2, 4):
+        step = 1 << level
+        if ns // step < 6 or nt // step < 1:
+            continue
+        for scale in (2.5, 0.0):
+            idx, d2, sel, thr, sums = engine.reference_pass(start, cur, level, scale)
+            n_o, s_o, idx_o, d2_o, sel_o, thr_o = ora.ref_pass(src[::step][:ns // step], tgt[::step][:nt // step], start, cur,
+                                                               scale, nthreads=ora.max_threads())
+            assert np.array_equal(idx, idx_o) and np.array_equal(d2.view(np.uint32), d2_o.view(np.uint32))
+            assert (thr == thr_o) or (np.isinf(thr) and np.isinf(thr_o))
+            assert np.array_equal(sel, sel_o)
+            assert sums[28] == n_o
+            np.testing.assert_allclose(sums, s_o, rtol=1e-10, atol=1e-12)
+
+
+def test_align_reference_matches_oracle_with_the_reference_parameters(engine):
+    import pose_estimation_amd as pa
+    src, tgt, gt = pair6(20000, 20000)
+    engine.set_targets([tgt])
+    engine.set_sources([src])
+    res = engine.align_reference(np.eye(4)[None], 250, 0.005, 2.5, 8)
+    o = ora.icp_reference(src, tgt, np.eye(4), 250, 0.005, 2.5, 8, nthreads=ora.max_threads())
+    assert res.status[0] == 0 and res.passes[0] == o["passes"]
+    assert np.linalg.norm(res.poses[0] - o["pose"]) <= POSE_TOL
+    assert abs(res.residual[0] - o["residual"]) <= 1e-9
+    assert np.linalg.norm(res.poses[0] - gt) < 2e-3
+    # the Python mirror of cv::ppf_match_3d::ICP in reference mode drives the same path
+    icp = pa.ICP(250, 0.005, 2.5, 8, engine=engine, mode="reference")
+    p = pa.Pose3D()
+    icp.registerModelToScene(src, tgt, [p])
+    assert np.array_equal(p.pose, res.poses[0]) and p.residual == res.residual[0]
+
+
+def test_batched_candidates_and_mixed_objects(engine):
+    pairs = [pair6(6000 + 500 * k, 5000 + 300 * k, k) for k in range(3)]
+    engine.set_targets([p[1] for p in pairs])
+    engine.set_sources([p[0] for p in pairs])
+    sid = [0, 1, 2, 1, 1, 1]
+    inits = [np.eye(4)] * 3 + [st.rigid_transform(a, (0.2, 1, -0.4), (0.01, -0.02, 0.015)) @ pairs[1][2] for a in (1.0, 3.0, 6.0)]
+    res = engine.align_reference(np.stack(inits), 60, 0.005, 2.5, 5, source_ids=sid, target_ids=sid)
+    for k in range(len(sid)):
+        o = ora.icp_reference(pairs[sid[k]][0], pairs[sid[k]][1], inits[k], 60, 0.005, 2.5, 5)
+        assert res.passes[k] == o["passes"], k
+        assert np.linalg.norm(res.poses[k] - o["pose"]) <= POSE_TOL, k
+        assert abs(res.residual[k] - o["residual"]) <= 1e-9
+
+
+def test_reference_mode_needs_scene_normals_and_skips_tiny_levels(engine):
+    import pose_estimation_amd as pa
+    src, tgt, gt = pair6(40, 60)
+    engine.set_targets([tgt[:, :3].copy()])
+    engine.set_sources([src])
+    with pytest.raises(pa.IcpError) as e:
+        engine.align_reference(np.eye(4)[None])
+    assert e.value.status == pa._lib.ERR_INVALID_ARGUMENT and "normals" in str(e.value)
+    engine.set_targets([tgt])
+    res = engine.align_reference(np.eye(4)[None], 50, 0.005, 2.5, 8)
+    o = ora.icp_reference(src, tgt, np.eye(4), 50, 0.005, 2.5, 8)
+    assert res.passes[0] == o["passes"] and np.linalg.norm(res.poses[0] - o["pose"]) <= POSE_TOL
