@@ -76,7 +76,8 @@ __global__ __launch_bounds__(kBlockThreads) void subsample_kernel(const float* _
 constexpr int kSelThreads = 1024;
 
 template <typename F>
-__device__ uint32_t radix_select(uint32_t n, uint32_t k, uint32_t* hist /* 2048 */, uint32_t* bcast /* 2 */, F value_of) {
+__device__ uint32_t radix_select(uint32_t n, uint32_t k, uint32_t* hist /* 2048 */, uint32_t* bcast /* 2 */,
+                                 uint32_t* wave_tot /* 16 */, F value_of) {
   uint32_t prefix = 0, mask = 0;
   const int shifts[3] = {21, 10, 0};
   const int widths[3] = {11, 11, 10};
@@ -91,15 +92,28 @@ __device__ uint32_t radix_select(uint32_t n, uint32_t k, uint32_t* hist /* 2048 
       if ((bits & mask) == prefix) atomicAdd(&hist[(bits >> shift) & (nb - 1)], 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {  // 2048 bins: a serial walk is a few microseconds
-      uint32_t acc = 0, d = 0;
-      for (; d < nb; ++d) {
-        const uint32_t c = hist[d];
-        if (acc + c > k) break;
-        acc += c;
+    // Which digit holds rank k?  Parallel scan over the 2048 bins (2 per thread): wave64 shuffle scan, wave totals
+    // through LDS.  (A serial walk by one lane costs ~100 us per pass: one dependent LDS read per bin.)
+    {
+      const uint32_t c0 = hist[2 * threadIdx.x], c1 = hist[2 * threadIdx.x + 1];
+      const uint32_t mine = c0 + c1;
+      uint32_t incl = mine;
+      const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if (lane >= static_cast<uint32_t>(off)) incl += up;
       }
-      bcast[0] = d;
-      bcast[1] = k - acc;
+      if (lane == 63) wave_tot[wave] = incl;
+      __syncthreads();
+      uint32_t base = 0;
+      for (uint32_t w = 0; w < wave; ++w) base += wave_tot[w];
+      const uint32_t excl = base + incl - mine;
+      if (mine && k >= excl && k < excl + mine) {  // exactly one thread
+        const bool second = k >= excl + c0;
+        bcast[0] = 2 * threadIdx.x + (second ? 1u : 0u);
+        bcast[1] = k - excl - (second ? c0 : 0u);
+      }
     }
     __syncthreads();
     prefix |= bcast[0] << shift;
@@ -116,6 +130,7 @@ __global__ __launch_bounds__(kSelThreads) void rejection_select_kernel(const Job
                                                                         float* __restrict__ thr_out) {
   __shared__ uint32_t hist[2048];
   __shared__ uint32_t bcast[2];
+  __shared__ uint32_t wave_tot[kSelThreads / 64];
   const JobDesc& J = jobs[blockIdx.x];
   const uint32_t n = J.src_n;
   if (n == 0) {
@@ -124,8 +139,8 @@ __global__ __launch_bounds__(kSelThreads) void rejection_select_kernel(const Job
   }
   const float* __restrict__ d = dist2 + J.out_off;
   const uint32_t k = (n - 1) / 2;
-  const float med = __uint_as_float(radix_select(n, k, hist, bcast, [&](uint32_t i) { return d[i]; }));
-  const float mad = __uint_as_float(radix_select(n, k, hist, bcast, [&](uint32_t i) {
+  const float med = __uint_as_float(radix_select(n, k, hist, bcast, wave_tot, [&](uint32_t i) { return d[i]; }));
+  const float mad = __uint_as_float(radix_select(n, k, hist, bcast, wave_tot, [&](uint32_t i) {
     return static_cast<float>(__builtin_fabs(static_cast<double>(d[i]) - static_cast<double>(med)));
   }));
   if (threadIdx.x == 0) {

@@ -4,7 +4,8 @@
 // driving the refine half through the C++ mirror.  PPF matching is not part of this path, so candidate
 // poses are synthesised around the known alignment the way PPF votes would deliver them.
 //
-//   estimate_pose_harness <n_model> <n_scene> [n_candidates]    prints the 7-float pose and per-candidate results
+//   estimate_pose_harness <n_model> <n_scene> [n_candidates] [reference]
+//     prints the 7-float pose and per-candidate results; "reference" selects Mode::Reference (scene with normals)
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -41,17 +42,21 @@ int main(int argc, char** argv) {
   const size_t n_model = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 1000;
   const size_t n_scene = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 1000;
   const int n_cand = argc > 3 ? std::atoi(argv[3]) : 7;
+  const bool reference_mode = argc > 4 && std::string(argv[4]) == "reference";
   EstimatePoseRequest req;
   req.object = "bumpy_sphere";
   EstimatePoseResponse resp;
   try {
     // scene = target sample; model = independent noisy sample moved by a known 5 degree perturbation
     const mi355::Pose T = rotation_about(1, 2, 3, 5.0, 0.02, -0.01, 0.03);
-    std::vector<float> scene(3 * n_scene), model(3 * n_model);
-    mi355_icp_synth_cloud(0x5EED0001ull, 0, 0.0, nullptr, 0, n_scene, scene.data());
+    const size_t scene_cols = reference_mode ? 6 : 3;
+    std::vector<float> scene(scene_cols * n_scene), model(3 * n_model);
+    if (reference_mode) mi355_icp_synth_cloud6(0x5EED0001ull, 0, 0.0, nullptr, 0, n_scene, scene.data());
+    else mi355_icp_synth_cloud(0x5EED0001ull, 0, 0.0, nullptr, 0, n_scene, scene.data());
     mi355_icp_synth_cloud(0x5EED0002ull, 0x5EED0003ull, 1e-3, T.data(), 0, n_model, model.data());
 
-    mi355::ppf_match_3d::ICP icp(250, 0.005f, 2.5f, 8);  // the reference's constructor arguments
+    using mi355::ppf_match_3d::ICP;
+    ICP icp(250, 0.005f, 2.5f, 8, 0, reference_mode ? ICP::Mode::Reference : ICP::Mode::PointToPoint);  // the reference's arguments
     std::vector<mi355::ppf_match_3d::Pose3DPtr> results;
     const size_t votes[] = {300, 900, 500, 450, 100, 420, 50, 10};
     for (int k = 0; k < n_cand; ++k) {
@@ -62,7 +67,7 @@ int main(int argc, char** argv) {
     }
     size_t best = 0;
     const std::vector<float> pose = mi355::ppf_match_3d::refine_candidates(
-        icp, mi355::CloudView{model.data(), n_model, 12}, mi355::CloudView{scene.data(), n_scene, 12}, results, true, &best);
+        icp, mi355::CloudView{model.data(), n_model, 12}, mi355::CloudView{scene.data(), n_scene, 4 * scene_cols}, results, true, &best);
     for (size_t k = 0; k < results.size(); ++k)
       std::printf("candidate %zu votes %zu residual %.17g iterations %d\n", k, results[k]->numVotes, results[k]->residual,
                   k < icp.last_result().iterations.size() ? icp.last_result().iterations[k] : 0);

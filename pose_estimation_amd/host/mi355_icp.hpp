@@ -146,14 +146,24 @@ struct Pose3D {
 };
 using Pose3DPtr = std::shared_ptr<Pose3D>;
 
-// Mirror of cv::ppf_match_3d::ICP: same constructor arguments as the reference call site.  numLevels and
-// rejectionScale are recorded but not used by this point-to-point engine.
+// Mirror of cv::ppf_match_3d::ICP: same constructor arguments as the reference call site.
+// Mode::PointToPoint (default) is the engine of BASELINE.json (exact NN + Kabsch; numLevels and rejectionScale are
+// recorded only).  Mode::Reference runs upstream's structure with all four arguments live (pyramid, MAD rejection,
+// picky, point-to-plane on the scene normals: mi355_icp_align_reference) and needs the scene as N x 6 rows.
 class ICP {
  public:
-  ICP(int iterations, float tolerence = 0.05f, float rejectionScale = 2.5f, int numLevels = 6, int device_id = 0)
-      : engine_(std::make_shared<Engine>(device_id)) {
+  enum class Mode { PointToPoint, Reference };
+
+  ICP(int iterations, float tolerence = 0.05f, float rejectionScale = 2.5f, int numLevels = 6, int device_id = 0,
+      Mode mode = Mode::PointToPoint)
+      : engine_(std::make_shared<Engine>(device_id)), mode_(mode) {
     const int st = mi355_icp_params_from_reference(iterations, tolerence, rejectionScale, numLevels, &params_);
     if (st != MI355_ICP_OK) throw Error(st, "mi355_icp_params_from_reference");
+    ref_params_.iterations = iterations;
+    ref_params_.tolerance = tolerence;
+    ref_params_.rejection_scale = rejectionScale;
+    ref_params_.num_levels = numLevels;
+    ref_params_.flags = 0;
   }
 
   // Refines every pose in place (pose, t, q, residual), returns 0 like upstream.  A candidate whose solve fails keeps
@@ -170,7 +180,21 @@ class ICP {
     std::vector<Pose> init;
     for (const auto& p : poses) init.push_back(p->pose);
     const std::vector<int> sid(poses.size(), source_id), tid(poses.size(), target_id);
-    last_ = engine_->align(sid, tid, init, params_);
+    if (mode_ == Mode::Reference) {
+      const int n = static_cast<int>(poses.size());
+      last_ = Engine::Result{};
+      last_.poses.resize(n);
+      last_.residual.resize(n);
+      last_.iterations.resize(n);
+      last_.status.resize(n);
+      last_.converged.assign(n, 0);
+      const int st = mi355_icp_align_reference(engine_->handle(), n, sid.data(), tid.data(), init[0].data(), &ref_params_,
+                                               last_.poses[0].data(), last_.residual.data(), last_.iterations.data(),
+                                               last_.status.data());
+      if (st != MI355_ICP_OK) throw Error(st, std::string("mi355_icp_align_reference: ") + mi355_icp_last_error(engine_->handle()));
+    } else {
+      last_ = engine_->align(sid, tid, init, params_);
+    }
     for (std::size_t k = 0; k < poses.size(); ++k) {
       poses[k]->updatePose(last_.poses[k]);
       poses[k]->residual = last_.residual[k];
@@ -184,7 +208,9 @@ class ICP {
 
  private:
   std::shared_ptr<Engine> engine_;
+  Mode mode_;
   mi355_icp_params params_{};
+  mi355_icp_reference_params ref_params_{};
   Engine::Result last_;
 };
 

@@ -31,8 +31,11 @@ inline CloudView view_of(const cv::Mat& m) {
 
 class ICP {
  public:
-  ICP(int iterations, float tolerence = 0.05f, float rejectionScale = 2.5f, int numLevels = 6)
-      : impl_(iterations, tolerence, rejectionScale, numLevels) {}
+  // Mode::Reference (default here) keeps all four arguments live like upstream; the scene must then be N x 6
+  // (pc_scene_normals at the call site is: opencv_surface_match.cpp:57-59).
+  ICP(int iterations, float tolerence = 0.05f, float rejectionScale = 2.5f, int numLevels = 6,
+      ppf_match_3d::ICP::Mode mode = ppf_match_3d::ICP::Mode::Reference)
+      : impl_(iterations, tolerence, rejectionScale, numLevels, 0, mode) {}
 
   int registerModelToScene(const cv::Mat& srcPC, const cv::Mat& dstPC, std::vector<cv::ppf_match_3d::Pose3DPtr>& poses) {
     std::vector<ppf_match_3d::Pose3DPtr> mine;
