@@ -170,6 +170,31 @@ def main():
         poses.append(P), p7.append(a), p7ref.append(b)
     np.savez_compressed(os.path.join(HERE, "pose7.npz"), poses=np.array(poses), pose7=np.array(p7), pose7_ref=np.array(p7ref))
 
+    # (7) reference mode (pyramid + MAD rejection + picky + point-to-plane), small enough to store the clouds
+    T = st.perturbation(-1)
+    tgt6 = st.synth_cloud_np(st.TARGET_SEED, 2500, normals=True)
+    srcr = st.synth_cloud_np(st.SOURCE_SEED, 2000, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T)
+    r = ora.icp_reference(srcr, tgt6, np.eye(4), 60, 0.005, 2.5, 5)
+    assert r["status"] == 0 and np.linalg.norm(r["pose"] - np.linalg.inv(T)) < 5e-3
+    start = st.rigid_transform(0.7, (0.1, 1, 0.3), (0.004, 0.001, -0.002))
+    cur = st.rigid_transform(0.2, (1, 0, 0), (0.001, 0, 0)) @ start
+    n_sel, sums, idx, d2, sel, thr = ora.ref_pass(srcr[::2][:1000], tgt6[::2][:1250], start, cur, 2.5)
+    # independent check of the pass: NN vs scipy, threshold vs numpy, least squares vs numpy.linalg.lstsq
+    check_nn_vs_scipy(ora.transform(cur, srcr[::2][:1000]), np.ascontiguousarray(tgt6[::2][:1250, :3]), idx, d2)
+    med = np.sort(d2)[(len(d2) - 1) // 2]
+    mad = np.sort(np.abs(d2.astype(np.float64) - np.float64(med)).astype(np.float32))[(len(d2) - 1) // 2]
+    assert thr == np.float32(2.5) * (np.float32(1.48257968) * mad) + med
+    pp = ora.transform(start, srcr[::2][:1000])[sel].astype(np.float64)
+    qq = tgt6[::2][:1250][idx[sel], :3].astype(np.float64)
+    nn = tgt6[::2][:1250][idx[sel], 3:].astype(np.float64)
+    A = np.concatenate([np.cross(pp, nn), nn], axis=1)
+    x_np = np.linalg.lstsq(A, ((qq - pp) * nn).sum(1), rcond=None)[0]
+    assert np.abs(ora.solve_point_to_plane(sums)[1] - x_np).max() < 1e-9
+    np.savez_compressed(os.path.join(HERE, "refmode_2k.npz"), src=srcr, tgt6=tgt6, final_pose=r["pose"], start=start, cur=cur,
+                        pass_idx=idx, pass_d2=d2, pass_sel=sel, pass_thr=np.float32(thr), pass_sums=sums)
+    meta["refmode_2k"] = {"params": [60, 0.005, 2.5, 5], "passes": int(r["passes"]), "residual": r["residual"],
+                          "pass_level": 1, "pass_selected": int(n_sel)}
+
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print(json.dumps(meta, indent=1, sort_keys=True)[:1500])

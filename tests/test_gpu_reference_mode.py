@@ -84,3 +84,43 @@ def test_reference_mode_needs_scene_normals_and_skips_tiny_levels(engine):
     res = engine.align_reference(np.eye(4)[None], 50, 0.005, 2.5, 8)
     o = ora.icp_reference(src, tgt, np.eye(4), 50, 0.005, 2.5, 8)
     assert res.passes[0] == o["passes"] and np.linalg.norm(res.poses[0] - o["pose"]) <= POSE_TOL
+
+
+def test_golden_reference_mode_fixture(engine):
+    import json
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "refmode_2k.npz"))
+    meta = json.load(open(os.path.join(gold, "golden.json")))["refmode_2k"]
+    it, tol, scale, levels = meta["params"]
+    engine.set_targets([g["tgt6"]])
+    engine.set_sources([g["src"]])
+    idx, d2, sel, thr, sums = engine.reference_pass(g["start"], g["cur"], meta["pass_level"], scale)
+    assert np.array_equal(idx, g["pass_idx"]) and np.array_equal(d2.view(np.uint32), g["pass_d2"].view(np.uint32))
+    assert np.array_equal(sel, g["pass_sel"]) and np.float32(thr) == g["pass_thr"]
+    np.testing.assert_allclose(sums, g["pass_sums"], rtol=1e-10, atol=1e-12)
+    res = engine.align_reference(np.eye(4)[None], it, tol, scale, levels)
+    assert res.passes[0] == meta["passes"] and abs(res.residual[0] - meta["residual"]) <= 1e-9
+    assert np.linalg.norm(res.poses[0] - g["final_pose"]) <= POSE_TOL
+
+
+def test_cpp_harness_reference_mode_matches_python_engine(engine):
+    import subprocess
+    import pose_estimation_amd as pa
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build", "estimate_pose_harness")
+    out = subprocess.run([exe, "2500", "3000", "4", "reference"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    poses = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]).reshape(4, 4)
+             for l in out.stdout.splitlines() if l.startswith("pose ")}
+    T = st.perturbation(-1)
+    scene = pa.synth_cloud(st.TARGET_SEED, 3000, normals=True)
+    model = pa.synth_cloud(st.SOURCE_SEED, 2500, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T)
+    engine.set_targets([scene])
+    engine.set_sources([model])
+    inits = np.stack([st.rigid_transform(1.0 + k, (0.2, 1, -0.4), (0.01, -0.02, 0.015)) for k in range(4)])
+    res = engine.align_reference(inits, 250, 0.005, 2.5, 8, source_ids=[0] * 4, target_ids=[0] * 4)
+    for k in range(4):
+        assert np.linalg.norm(poses[k] - res.poses[k]) <= 1e-7, k   # candidate builders differ in the last ulp of cos/sin
+        o = ora.icp_reference(model, scene, inits[k], 250, 0.005, 2.5, 8)
+        assert np.linalg.norm(poses[k] - o["pose"]) <= POSE_TOL

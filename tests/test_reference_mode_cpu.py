@@ -97,3 +97,18 @@ def test_tiny_clouds_skip_levels_instead_of_failing():
     src, tgt, gt = pair6(40, 60)
     r = ora.icp_reference(src, tgt, np.eye(4), 50, 0.005, 2.5, 8)
     assert r["status"] == 0 and np.isfinite(r["pose"]).all()   # levels with < 6 source points are skipped
+
+
+def test_golden_reference_mode_fixture_reproduced():
+    import json
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "refmode_2k.npz"))
+    meta = json.load(open(os.path.join(gold, "golden.json")))["refmode_2k"]
+    it, tol, scale, levels = meta["params"]
+    r = ora.icp_reference(g["src"], g["tgt6"], np.eye(4), it, tol, scale, levels)
+    assert r["passes"] == meta["passes"] and r["residual"] == meta["residual"]
+    assert np.array_equal(r["pose"], g["final_pose"])
+    n, sums, idx, d2, sel, thr = ora.ref_pass(g["src"][::2][:1000], g["tgt6"][::2][:1250], g["start"], g["cur"], scale)
+    assert n == meta["pass_selected"] and np.array_equal(idx, g["pass_idx"]) and np.array_equal(d2, g["pass_d2"])
+    assert np.array_equal(sel, g["pass_sel"]) and np.float32(thr) == g["pass_thr"] and np.array_equal(sums, g["pass_sums"])
