@@ -1,5 +1,7 @@
 """Reference mode on the GPU against the oracle: per-pass (index, d2, threshold, winners bit-exact; sums 1e-10),
 and whole alignments (pose <= 1e-5 Frobenius, same number of passes)."""
+import os
+
 import numpy as np
 import pytest
 
