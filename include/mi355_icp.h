@@ -87,6 +87,10 @@ typedef struct mi355_icp_profile {
   uint64_t reduce_launches;
   double   pairs_evaluated;  /* sum over nn_scan launches of Ns*Nt actually scanned */
   uint64_t iterations;       /* ICP iterations (correspondence passes) executed */
+  double   scene_filter_ms;  /* scene compaction kernel */
+  uint64_t scene_filter_launches;
+  uint64_t scene_points_in;  /* points read / written by those launches */
+  uint64_t scene_points_out;
 } mi355_icp_profile;
 
 /* ---- lifetime ------------------------------------------------------------ */
@@ -216,6 +220,45 @@ int mi355_icp_reference_pass(mi355_icp_ctx* ctx, int source_id, int target_id, i
 /* Minimum-norm least-squares solution x = (rx, ry, rz, tx, ty, tz) of the 6x6 normal equations packed in
  * sums (symmetric eigen-decomposition in double).  [host] */
 int mi355_icp_solve_point_to_plane(const double* sums29, double out_x[6]);
+
+/* ---- scene preparation: the reference's point filters as one-pass stream compaction ---- */
+
+/* The filters PoseEstimation::create_surface_match_pc applies before the ICP sees the scene
+ * (reference pose_estimation/src/pose_estimation.cpp): NaN removal (:248), the sphere filter filter_points
+ * (:347-372) and the distance band around a fitted plane in remove_planes (:310-333).  Arithmetic follows those
+ * lines (float32, their operation order, the band compared in double); kept points stay in their original order
+ * (the reference's loops emit indices in thread-arrival order under `omp critical`).  The RANSAC plane fit itself
+ * (:285-297) is PCL's and stays with the caller, who passes the coefficients in. */
+typedef enum mi355_scene_filter_kind {
+  MI355_SCENE_FILTER_FINITE = 0,               /* keep points whose x, y, z are all finite */
+  MI355_SCENE_FILTER_SPHERE_KEEP_INSIDE = 1,   /* p[0..2] centre, p[3] radius: keep d <= radius  (filter_out != "inliers") */
+  MI355_SCENE_FILTER_SPHERE_REMOVE_INSIDE = 2, /* same test, keep d > radius                      (filter_out == "inliers") */
+  MI355_SCENE_FILTER_PLANE_BAND_REMOVE = 3     /* p[0..3] = a, b, c, d of ax+by+cz+d=0, p[4] = band (reference: 0.005):
+                                                  remove |(x*a+y*b+z*c+d)/|p|| <= band */
+} mi355_scene_filter_kind;
+
+typedef struct mi355_scene_filter {
+  int32_t kind;
+  float   p[5];
+} mi355_scene_filter;
+
+#define MI355_SCENE_MAX_FILTERS 8
+
+/* Copies a raw scene (rows of >= 3 float32, stride_bytes apart; NaN/Inf allowed: an organised camera frame has
+ * them) to the GPU as the current scene.  Replaces: the PointCloud2 -> pcl cloud copy (pose_estimation.cpp:229-244). */
+int mi355_icp_scene_load(mi355_icp_ctx* ctx, const float* xyz, size_t n_points, size_t stride_bytes);
+
+/* Applies the AND of `n_filters` (<= MI355_SCENE_MAX_FILTERS) predicates in ONE pass over the current scene and
+ * compacts it on the device; *out_n_points (optional) receives the number of points kept. */
+int mi355_icp_scene_filter(mi355_icp_ctx* ctx, int n_filters, const mi355_scene_filter* filters, size_t* out_n_points);
+
+/* Copies the current scene back as packed xyz rows (for the host-side RANSAC between plane removals).
+ * Replaces: the pcl cloud -> cv::Mat N x 3 copy (pose_estimation.cpp:263-276). */
+int mi355_icp_scene_download(mi355_icp_ctx* ctx, float* out_xyz, size_t capacity_points, size_t* out_n_points);
+
+/* Makes the current scene target cloud 0 (replacing all targets) without leaving the device.  Fails with
+ * MI355_ICP_ERR_NONFINITE_INPUT if the scene still holds NaN/Inf. */
+int mi355_icp_scene_commit_target(mi355_icp_ctx* ctx);
 
 /* ---- host arithmetic (no GPU needed) ------------------------------------- */
 

@@ -793,3 +793,46 @@ int oracle_icp_reference(const float* src_xyz, size_t ns, const float* tgt6, siz
   if (out_passes) *out_passes = passes;
   return OR_OK;
 }
+
+/* ======================================================================== */
+/* Scene preparation filters, restated from the reference's OWN code
+ * (pose_estimation/src/pose_estimation.cpp):
+ *   kind 0  pcl::removeNaNFromPointCloud, :248  - keep points with finite x, y, z
+ *   kind 1/2 filter_points, :347-372            - float dx = point[0] - x ...; float d = std::sqrt(dx*dx + dy*dy + dz*dz);
+ *                                                 d <= filter_radius marks the point; ExtractIndices keeps the marked
+ *                                                 points (kind 1) or the others (kind 2, setNegative(true))
+ *   kind 3  remove_planes, :310-333             - float d = (x*a + y*b + z*c + dd) / std::sqrt(x*x + y*y + z*z);
+ *                                                 std::abs(d) <= 0.005 (double literal) marks the point; marked points
+ *                                                 are removed
+ * Output order: ascending original index (the reference's parallel loops are serialised by `omp critical` and push
+ * indices in arrival order; one thread gives this order).  The reference has no test for these lines either.      */
+typedef struct oracle_scene_filter {
+  int32_t kind;
+  float p[5];
+} oracle_scene_filter;
+
+size_t oracle_scene_filter_apply(const float* xyz, size_t n, const oracle_scene_filter* f, int nf, float* out) {
+  size_t kept = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    int keep = 1;
+    for (int k = 0; k < nf && keep; ++k) {
+      if (f[k].kind == 0) {
+        keep = isfinite(x) && isfinite(y) && isfinite(z);
+      } else if (f[k].kind == 1 || f[k].kind == 2) {
+        float dx = f[k].p[0] - x, dy = f[k].p[1] - y, dz = f[k].p[2] - z;
+        float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        int inside = d <= f[k].p[3];
+        keep = f[k].kind == 1 ? inside : !inside;
+      } else {
+        float d = (x * f[k].p[0] + y * f[k].p[1] + z * f[k].p[2] + f[k].p[3]) / sqrtf(x * x + y * y + z * z);
+        keep = !((double)fabsf(d) <= (double)f[k].p[4]);
+      }
+    }
+    if (keep) {
+      out[3 * kept] = x; out[3 * kept + 1] = y; out[3 * kept + 2] = z;
+      ++kept;
+    }
+  }
+  return kept;
+}

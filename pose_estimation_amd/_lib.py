@@ -69,7 +69,23 @@ class Profile(C.Structure):
         ("reduce_launches", C.c_uint64),
         ("pairs_evaluated", C.c_double),
         ("iterations", C.c_uint64),
+        ("scene_filter_ms", C.c_double),
+        ("scene_filter_launches", C.c_uint64),
+        ("scene_points_in", C.c_uint64),
+        ("scene_points_out", C.c_uint64),
     ]
+
+
+class SceneFilter(C.Structure):
+    """mi355_scene_filter"""
+    _fields_ = [("kind", C.c_int32), ("p", C.c_float * 5)]
+
+
+SCENE_FILTER_FINITE = 0
+SCENE_FILTER_SPHERE_KEEP_INSIDE = 1
+SCENE_FILTER_SPHERE_REMOVE_INSIDE = 2
+SCENE_FILTER_PLANE_BAND_REMOVE = 3
+SCENE_MAX_FILTERS = 8
 
 
 # every symbol include/mi355_icp.h declares: name -> (restype, argtypes)
@@ -94,6 +110,10 @@ SIGNATURES = {
     "mi355_icp_reference_pass": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                            C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_float), C.c_void_p]),
     "mi355_icp_solve_point_to_plane": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi355_icp_scene_load": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "mi355_icp_scene_filter": (C.c_int, [_ctx, C.c_int, C.c_void_p, _P(C.c_size_t)]),
+    "mi355_icp_scene_download": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
+    "mi355_icp_scene_commit_target": (C.c_int, [_ctx]),
     "mi355_icp_solve_rigid": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi355_icp_host_update": (C.c_int, [_P(Params), C.c_void_p, C.c_int, C.c_void_p, _P(C.c_double), _P(C.c_int),
                                         _P(C.c_int)]),

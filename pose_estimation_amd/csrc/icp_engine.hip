@@ -101,6 +101,13 @@ struct mi355_icp_ctx {
   double* ref_sums_host = nullptr;     // pinned
   float* thr_host = nullptr;           // pinned
 
+  // scene preparation (packed AoS xyz, ping-pong)
+  float* scene[2] = {nullptr, nullptr}; size_t scene_cap = 0;
+  uint32_t scene_n = 0; int scene_cur = 0; bool scene_loaded = false;
+  unsigned long long* scene_state = nullptr; size_t scene_state_cap = 0;
+  uint32_t* scene_counters = nullptr;       // device: ticket, kept total, error bits
+  uint32_t* scene_counters_host = nullptr;  // pinned
+
   void* comm = nullptr;
   int comm_rank = 0, comm_size = 1;
 
@@ -535,6 +542,11 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
     (void)hipFree(set->normals);
     for (auto& lv : set->levels) (void)hipFree(lv.planes);
   }
+  (void)hipFree(c->scene[0]);
+  (void)hipFree(c->scene[1]);
+  (void)hipFree(c->scene_state);
+  (void)hipFree(c->scene_counters);
+  if (c->scene_counters_host) (void)hipHostFree(c->scene_counters_host);
   (void)hipFree(c->owner);
   (void)hipFree(c->selected);
   (void)hipFree(c->ref_partials);
@@ -819,6 +831,130 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
 int mi355_icp_solve_point_to_plane(const double* sums29, double out_x[6]) {
   if (!sums29 || !out_x) return MI355_ICP_ERR_INVALID_ARGUMENT;
   return solve_point_to_plane(sums29, out_x);
+}
+
+// ---- scene preparation ---------------------------------------------------------------------------------------
+int mi355_icp_scene_load(mi355_icp_ctx* c, const float* xyz, size_t n_points, size_t stride_bytes) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  c->err.clear();
+  if ((n_points && !xyz) || stride_bytes < 12 || stride_bytes % 4 != 0) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_load: bad arguments");
+  if (n_points > 0xFFFF0000ull) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_load: too many points");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const size_t need = std::max<size_t>(n_points, 1) * 3 + 16;  // + slack: the kernel reads whole float4s
+  if (need > c->scene_cap) {
+    for (auto& b : c->scene)
+      if (b) { HIP_TRY(c, hipFree(b)); b = nullptr; }
+    c->scene_cap = 0;
+    const size_t want = need + need / 8;
+    for (auto& b : c->scene) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&b), want * sizeof(float)));
+    c->scene_cap = want;
+  }
+  if (!c->scene_counters) {
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->scene_counters), 4 * sizeof(uint32_t)));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->scene_counters_host), 4 * sizeof(uint32_t), hipHostMallocDefault));
+  }
+  if (n_points) {
+    if (stride_bytes == 12) {
+      HIP_TRY(c, hipMemcpy(c->scene[0], xyz, n_points * 12, hipMemcpyHostToDevice));
+    } else {
+      std::vector<float> packed(n_points * 3);
+      const size_t fs = stride_bytes / 4;
+      for (size_t i = 0; i < n_points; ++i) {
+        packed[3 * i] = xyz[i * fs];
+        packed[3 * i + 1] = xyz[i * fs + 1];
+        packed[3 * i + 2] = xyz[i * fs + 2];
+      }
+      HIP_TRY(c, hipMemcpy(c->scene[0], packed.data(), n_points * 12, hipMemcpyHostToDevice));
+    }
+  }
+  c->scene_n = static_cast<uint32_t>(n_points);
+  c->scene_cur = 0;
+  c->scene_loaded = true;
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_scene_filter(mi355_icp_ctx* c, int n_filters, const mi355_scene_filter* filters, size_t* out_n_points) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  c->err.clear();
+  if (!c->scene_loaded) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_filter: no scene loaded (mi355_icp_scene_load)");
+  if (n_filters < 0 || n_filters > MI355_SCENE_MAX_FILTERS || (n_filters && !filters)) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_filter: bad filter list");
+  SceneFilterSet F{};
+  F.n = n_filters;
+  for (int k = 0; k < n_filters; ++k) {
+    if (filters[k].kind < 0 || filters[k].kind > MI355_SCENE_FILTER_PLANE_BAND_REMOVE) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_filter: unknown filter kind");
+    F.f[k] = filters[k];
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t n = c->scene_n;
+  const uint32_t n_tiles = (n + kSceneTile - 1) / kSceneTile;
+  if (n_tiles) {
+    int st;
+    if ((st = grow(c, c->scene_state, c->scene_state_cap, static_cast<size_t>(n_tiles))) != MI355_ICP_OK) return st;
+    HIP_TRY(c, hipMemsetAsync(c->scene_state, 0, static_cast<size_t>(n_tiles) * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->scene_counters, 0, 4 * sizeof(uint32_t), c->stream));
+    if (c->profile_always) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    launch_scene_compact(c->stream, c->scene[c->scene_cur], n, F, c->scene[c->scene_cur ^ 1], c->scene_state, c->scene_counters, n_tiles);
+    if (c->profile_always) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->scene_counters_host, c->scene_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->scene_counters_host[2] & 1u) return fail(c, MI355_ICP_ERR_INTERNAL, "scene_filter: look-back timed out");
+    if (c->profile_always) {
+      float ms = 0.f;
+      HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+      c->prof.scene_filter_ms += ms;
+      c->prof.scene_filter_launches += 1;
+      c->prof.scene_points_in += n;
+      c->prof.scene_points_out += c->scene_counters_host[1];
+    }
+    c->scene_n = c->scene_counters_host[1];
+    c->scene_cur ^= 1;
+  }
+  if (out_n_points) *out_n_points = c->scene_n;
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_scene_download(mi355_icp_ctx* c, float* out_xyz, size_t capacity_points, size_t* out_n_points) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  c->err.clear();
+  if (!c->scene_loaded) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_download: no scene loaded");
+  if (out_n_points) *out_n_points = c->scene_n;
+  if (!out_xyz) return MI355_ICP_OK;
+  if (capacity_points < c->scene_n) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_download: buffer too small");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (c->scene_n) HIP_TRY(c, hipMemcpy(out_xyz, c->scene[c->scene_cur], static_cast<size_t>(c->scene_n) * 12, hipMemcpyDeviceToHost));
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_scene_commit_target(mi355_icp_ctx* c) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  c->err.clear();
+  if (!c->scene_loaded || c->scene_n == 0) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_commit_target: the scene is empty");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  CloudSet& set = c->targets;
+  const uint32_t n = c->scene_n;
+  const uint32_t padded = (n + kTile - 1) / kTile * kTile;
+  float* planes = nullptr;
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&planes), 3 * static_cast<size_t>(padded) * sizeof(float)));
+  HIP_TRY(c, hipMemsetAsync(c->scene_counters, 0, 4 * sizeof(uint32_t), c->stream));
+  launch_scene_to_planes(c->stream, c->scene[c->scene_cur], n, planes, padded, 0, padded, kTargetPad, c->scene_counters);
+  HIP_TRY(c, hipMemcpyAsync(c->scene_counters_host, c->scene_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->scene_counters_host[2] & 2u) {
+    (void)hipFree(planes);
+    return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "scene_commit_target: the scene still holds NaN/Inf (apply MI355_SCENE_FILTER_FINITE)");
+  }
+  if (set.planes) HIP_TRY(c, hipFree(set.planes));
+  if (set.normals) { HIP_TRY(c, hipFree(set.normals)); set.normals = nullptr; }
+  for (auto& lv : set.levels)
+    if (lv.planes) HIP_TRY(c, hipFree(lv.planes));
+  set.levels.clear();
+  set.planes = planes;
+  set.stride = padded;
+  set.clouds.assign(1, CloudEntry{0, n, padded});
+  return MI355_ICP_OK;
 }
 
 int mi355_icp_comm_unique_id(unsigned char out_id[MI355_ICP_UNIQUE_ID_BYTES]) {

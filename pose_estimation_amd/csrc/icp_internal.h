@@ -55,6 +55,18 @@ int solve_point_to_plane(const double* sums29, double* x6);
 void euler_pose(const double* x6, double* pose16);
 void mat4_mul(const double* a, const double* b, double* c);
 
+// ---- scene preparation (scene_kernels.hip) ----
+constexpr int kSceneTile = 1024;  // points per compaction workgroup (256 threads x 4)
+using SceneFilter = mi355_scene_filter;
+struct SceneFilterSet {
+  int32_t n;
+  SceneFilter f[MI355_SCENE_MAX_FILTERS];
+};
+void launch_scene_compact(void* stream, const float* in, uint32_t n, const SceneFilterSet& filters, float* out,
+                          unsigned long long* state, uint32_t* counters, uint32_t n_tiles);
+void launch_scene_to_planes(void* stream, const float* in, uint32_t n, float* planes, size_t stride, uint32_t off,
+                            uint32_t n_padded, float pad, uint32_t* counters);
+
 // ---- host math (host_math.cpp) ----
 int solve_rigid(const double* sums, double* pose16);
 int host_update(const mi355_icp_params* p, const double* sums, int iteration, double* pose16, double* prev_mse,

@@ -264,6 +264,38 @@ class IcpEngine:
                                                  C.byref(thr), sums.ctypes.data))
         return idx, d2, sel.astype(bool), thr.value, sums
 
+    # -- scene preparation (the reference's point filters as one-pass stream compaction)
+    def scene_load(self, xyz: np.ndarray):
+        a = np.asarray(xyz)
+        if a.dtype != np.float32 or a.ndim != 2 or a.shape[1] < 3:
+            raise TypeError("scene must be a float32 array of shape [N, >=3]")
+        if a.shape[0] and (a.strides[1] != 4 or a.strides[0] % 4 != 0 or a.strides[0] < 12):
+            a = np.ascontiguousarray(a)
+        stride = a.strides[0] if a.shape[0] else 12
+        self._check(lib.mi355_icp_scene_load(self._h, a.ctypes.data if a.shape[0] else None, a.shape[0], stride))
+
+    def scene_filter(self, filters) -> int:
+        """filters: sequence of (kind, params) with kind one of _lib.SCENE_FILTER_*; all applied in one pass."""
+        arr = (_lib.SceneFilter * max(len(filters), 1))()
+        for k, (kind, p) in enumerate(filters):
+            arr[k].kind = int(kind)
+            for j, v in enumerate(list(p) + [0.0] * (5 - len(p))):
+                arr[k].p[j] = float(v)
+        n = C.c_size_t()
+        self._check(lib.mi355_icp_scene_filter(self._h, len(filters), arr, C.byref(n)))
+        return n.value
+
+    def scene_download(self) -> np.ndarray:
+        n = C.c_size_t()
+        self._check(lib.mi355_icp_scene_download(self._h, None, 0, C.byref(n)))
+        out = np.empty((n.value, 3), dtype=np.float32)
+        self._check(lib.mi355_icp_scene_download(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    def scene_commit_target(self):
+        self._check(lib.mi355_icp_scene_commit_target(self._h))
+        self.n_targets = 1
+
     # -- multi-GPU
     @staticmethod
     def comm_unique_id() -> bytes:

@@ -253,3 +253,25 @@ def icp_reference(src_xyz, tgt6, init_pose, iterations=250, tolerance=0.005, rej
     st = lib.oracle_icp_reference(src.ctypes.data, src.shape[0], tgt6.ctypes.data, tgt6.shape[0], init.ctypes.data,
                                   C.byref(rp), nthreads, out.ctypes.data, C.byref(res), C.byref(passes))
     return {"status": st, "pose": out.reshape(4, 4), "residual": res.value, "passes": passes.value}
+
+
+# ---- scene preparation filters (reference pose_estimation.cpp:248, :310-333, :347-372) ----
+class OracleSceneFilter(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("p", C.c_float * 5)]
+
+
+lib.oracle_scene_filter_apply.restype = C.c_size_t
+lib.oracle_scene_filter_apply.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
+
+
+def scene_filter(xyz, filters):
+    """filters: list of (kind, [p0..p4]).  Returns the kept points in original order."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    arr = (OracleSceneFilter * max(len(filters), 1))()
+    for k, (kind, p) in enumerate(filters):
+        arr[k].kind = kind
+        for j, v in enumerate(list(p) + [0.0] * (5 - len(p))):
+            arr[k].p[j] = v
+    out = np.empty_like(xyz)
+    n = lib.oracle_scene_filter_apply(xyz.ctypes.data, xyz.shape[0], arr, len(filters), out.ctypes.data)
+    return out[:n].copy()
