@@ -12,7 +12,7 @@
 // kept points in their original order (the order the reference produces when run on one thread).
 // Plane coefficients come from the caller (the RANSAC fit, pose_estimation.cpp:285-297, is PCL's and stays on the host).
 //
-// One pass over HBM: 12 B read per point, 12 B written per kept point.  Each 1024-point tile evaluates the
+// One pass over HBM: 12 B read per point, 12 B written per kept point.  Each tile (kSceneTile points) evaluates the
 // predicates, scans its keep flags, and gets its output offset by DECOUPLED LOOK-BACK over 8-byte
 // {status, count} granules published with agent-scope atomics (one self-contained 64-bit word per tile, the only
 // cross-workgroup data; MI355X_MICROARCH.md "Workgroup dispatch ... inter-workgroup visibility", granule form R2).
@@ -28,7 +28,6 @@ namespace mi355 {
 
 namespace {
 
-constexpr uint32_t kTilePts = kSceneTile;  // 1024 = 256 threads x 4 points
 constexpr unsigned long long kFlagAggregate = 1ull << 62, kFlagPrefix = 2ull << 62, kValueMask = (1ull << 62) - 1;
 constexpr int kSpinLimit = 1 << 22;
 
@@ -71,59 +70,83 @@ __device__ __forceinline__ bool keep_point(float x, float y, float z, const Scen
 // in: packed AoS xyz (12 B / point).  out: packed AoS xyz, kept points in original order.
 // state: one u64 per tile, zeroed before the launch.  counters[0]: tile ticket, counters[1]: kept total (written
 // by the last tile), counters[2]: error flag.
-__global__ __launch_bounds__(kBlockThreads) void scene_compact_kernel(const float* __restrict__ in, uint32_t n,
+//
+// A tile is kSceneTile points (12 B each), held in LDS for the whole life of the workgroup.  All 12 sixteen-byte
+// loads of a thread (lane-contiguous, 1 KiB per wave-instruction) are issued up front and land in LDS in file order;
+// thread t then owns points t, t+256, ... (12-byte lane stride in LDS: 3 is coprime with the 32 banks, conflict-free).
+// Keep flags are ranked with wave ballots; ONE look-back per tile; kept points are re-read from LDS on the way out.
+__global__ __launch_bounds__(kSceneThreads) void scene_compact_kernel(const float* __restrict__ in, uint32_t n,
                                                                        SceneFilterSet F, float* __restrict__ out,
                                                                        unsigned long long* __restrict__ state,
                                                                        uint32_t* __restrict__ counters,
                                                                        uint32_t n_tiles) {
+  constexpr int kPer = kSceneTile / kSceneThreads;  // points per thread
+  constexpr int kWaves = kSceneThreads / 64;
+  constexpr int kF4 = kSceneTile * 3 / 4;           // float4s per tile
+  __shared__ float4 s_pts[kF4];
   __shared__ uint32_t s_tile, s_excl;
-  __shared__ uint32_t s_wave[kBlockThreads / 64];
+  __shared__ uint32_t s_cnt[kPer * kWaves];         // kept points per (k, wave), in point order
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (tid == 0) s_tile = atomicAdd(&counters[0], 1u);
   __syncthreads();
   const uint32_t tile = s_tile;
   if (tile >= n_tiles) return;
 
-  // 4 consecutive points per thread = 48 contiguous bytes = 3 x 16-byte loads
-  const uint32_t first = tile * kTilePts + tid * 4;
-  float v[12];
-  if (first + 4 <= n) {
-    const float4* p = reinterpret_cast<const float4*>(in + static_cast<size_t>(first) * 3);
-    const float4 a = p[0], b = p[1], c = p[2];
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
-  } else {
+  const size_t tile_first = static_cast<size_t>(tile) * kSceneTile;           // first point of the tile
+  const size_t n_f4 = (static_cast<size_t>(n) * 3 + 3) / 4;                   // float4s that hold real data
+  const float4* __restrict__ in4 = reinterpret_cast<const float4*>(in);       // scene buffers are 16-byte aligned
+  const size_t f4_first = tile_first * 3 / 4;
+  float4 r[kF4 / kSceneThreads];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      const size_t idx = static_cast<size_t>(first) * 3 + k;
-      v[k] = idx < static_cast<size_t>(n) * 3 ? in[idx] : 0.0f;
+  for (int j = 0; j < kF4 / kSceneThreads; ++j) {
+    const size_t g = f4_first + j * kSceneThreads + tid;
+    r[j] = g < n_f4 ? in4[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < kF4 / kSceneThreads; ++j) s_pts[j * kSceneThreads + tid] = r[j];
+  __syncthreads();
+
+  const float* __restrict__ f = reinterpret_cast<const float*>(s_pts);
+  uint32_t keep_mask = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const uint32_t q = k * kSceneThreads + tid;  // point within the tile
+    const bool keep = tile_first + q < n && keep_point(f[3 * q], f[3 * q + 1], f[3 * q + 2], F);
+    const unsigned long long m = __ballot(keep);
+    keep_mask |= (keep ? 1u : 0u) << k;
+    if (lane == 0) s_cnt[k * kWaves + wave] = static_cast<uint32_t>(__popcll(m));
+  }
+  __syncthreads();
+  // exclusive prefix of the kPer * kWaves (k, wave) counts, kEpl per lane: every wave computes the total, wave 0 stores
+  uint32_t total;
+  {
+    constexpr int kEpl = kPer * kWaves / 64;
+    static_assert(kEpl * 64 == kPer * kWaves && kEpl >= 1, "whole counts per lane");
+    uint32_t c[kEpl], mine = 0;
+#pragma unroll
+    for (int e = 0; e < kEpl; ++e) {
+      c[e] = s_cnt[kEpl * lane + e];
+      mine += c[e];
+    }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = __shfl_up(incl, off, 64);
+      if (lane >= static_cast<uint32_t>(off)) incl += up;
+    }
+    total = __shfl(incl, 63, 64);
+    __syncthreads();  // everyone has read s_cnt
+    if (wave == 0) {
+      uint32_t run = incl - mine;
+#pragma unroll
+      for (int e = 0; e < kEpl; ++e) {
+        s_cnt[kEpl * lane + e] = run;  // now the exclusive prefix
+        run += c[e];
+      }
     }
   }
-  bool keep[4];
-  uint32_t mine = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    keep[k] = (first + k < n) && keep_point(v[3 * k], v[3 * k + 1], v[3 * k + 2], F);
-    mine += keep[k] ? 1u : 0u;
-  }
-  // exclusive scan of `mine` over the 256 threads
-  uint32_t incl = mine;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t up = __shfl_up(incl, off, 64);
-    if (lane >= static_cast<uint32_t>(off)) incl += up;
-  }
-  if (lane == 63) s_wave[wave] = incl;
-  __syncthreads();
-  uint32_t base = 0, total = 0;
-#pragma unroll
-  for (uint32_t w = 0; w < kBlockThreads / 64; ++w) {
-    if (w < wave) base += s_wave[w];
-    total += s_wave[w];
-  }
-  const uint32_t offset_in_tile = base + incl - mine;
 
-  // decoupled look-back by wave 0: lane l inspects tile (tile - 1 - l) of the current 64-tile window
+  // decoupled look-back by wave 0: lane l inspects tile (window - l)
   if (wave == 0) {
     uint32_t exclusive = 0;
     bool failed = false;
@@ -135,19 +158,19 @@ __global__ __launch_bounds__(kBlockThreads) void scene_compact_kernel(const floa
       bool done = false;
       while (!done) {
         const int64_t j = window - lane;
-        unsigned long long s = kFlagPrefix;  // tiles before 0 count as an empty prefix
+        unsigned long long st = kFlagPrefix;  // tiles before 0 count as an empty prefix
         if (j >= 0) {
           int spins = 0;
           do {
-            s = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (s >> 62) break;
+            st = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (st >> 62) break;
             __builtin_amdgcn_s_sleep(1);
           } while (++spins < kSpinLimit);
-          if (!(s >> 62)) failed = true;
+          if (!(st >> 62)) failed = true;
         }
-        const unsigned long long has_prefix = __ballot((s >> 62) == 2ull);
+        const unsigned long long has_prefix = __ballot((st >> 62) == 2ull);
         const int stop = has_prefix ? __ffsll(static_cast<long long>(has_prefix)) - 1 : 63;
-        uint32_t contrib = (static_cast<int>(lane) <= stop && j >= 0) ? static_cast<uint32_t>(s & kValueMask) : 0u;
+        uint32_t contrib = (static_cast<int>(lane) <= stop && j >= 0) ? static_cast<uint32_t>(st & kValueMask) : 0u;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off, 64);
         exclusive += contrib;
@@ -165,15 +188,18 @@ __global__ __launch_bounds__(kBlockThreads) void scene_compact_kernel(const floa
     }
   }
   __syncthreads();
-  uint32_t o = s_excl + offset_in_tile;
+  const uint32_t excl = s_excl;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (keep[k]) {
+  for (int k = 0; k < kPer; ++k) {
+    const bool keep = (keep_mask >> k) & 1u;
+    const unsigned long long m = __ballot(keep);
+    if (keep) {
+      const uint32_t q = k * kSceneThreads + tid;
+      const uint32_t o = excl + s_cnt[k * kWaves + wave] + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
       float* dst = out + static_cast<size_t>(o) * 3;
-      dst[0] = v[3 * k];
-      dst[1] = v[3 * k + 1];
-      dst[2] = v[3 * k + 2];
-      ++o;
+      dst[0] = f[3 * q];
+      dst[1] = f[3 * q + 1];
+      dst[2] = f[3 * q + 2];
     }
   }
 }
@@ -201,7 +227,7 @@ __global__ __launch_bounds__(kBlockThreads) void scene_to_planes_kernel(const fl
 void launch_scene_compact(void* stream, const float* in, uint32_t n, const SceneFilterSet& filters, float* out,
                           unsigned long long* state, uint32_t* counters, uint32_t n_tiles) {
   if (!n_tiles) return;
-  hipLaunchKernelGGL(scene_compact_kernel, dim3(n_tiles), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), in, n,
+  hipLaunchKernelGGL(scene_compact_kernel, dim3(n_tiles), dim3(kSceneThreads), 0, static_cast<hipStream_t>(stream), in, n,
                      filters, out, state, counters, n_tiles);
 }
 
