@@ -87,6 +87,9 @@ typedef struct mi355_icp_profile {
   uint64_t reduce_launches;
   double   pairs_evaluated;  /* sum over nn_scan launches of Ns*Nt actually scanned */
   uint64_t iterations;       /* ICP iterations (correspondence passes) executed */
+  double   knn_scan_ms;      /* scene normals: k-NN scan kernel */
+  double   normals_ms;       /* scene normals: merge + PCA kernel */
+  uint64_t normals_launches;
   double   scene_filter_ms;  /* scene compaction kernel */
   uint64_t scene_filter_launches;
   uint64_t scene_points_in;  /* points read / written by those launches */
@@ -256,8 +259,21 @@ int mi355_icp_scene_filter(mi355_icp_ctx* ctx, int n_filters, const mi355_scene_
  * Replaces: the pcl cloud -> cv::Mat N x 3 copy (pose_estimation.cpp:263-276). */
 int mi355_icp_scene_download(mi355_icp_ctx* ctx, float* out_xyz, size_t capacity_points, size_t* out_n_points);
 
-/* Makes the current scene target cloud 0 (replacing all targets) without leaving the device.  Fails with
- * MI355_ICP_ERR_NONFINITE_INPUT if the scene still holds NaN/Inf. */
+/* Normals of the current scene by k-nearest-neighbour PCA.
+ * Replaces: cv::ppf_match_3d::computeNormalsPC3d(pc_scene, pc_scene_normals, 20, true, viewpoint)
+ * (opencv_surface_match.cpp:57-59): for every point its k nearest points of the scene (itself included, exact
+ * float32 distances, (d2, index) order), covariance accumulated as upstream does (float32 products in double),
+ * eigenvector of the smallest eigenvalue, flipped (flip_viewpoint != 0) so that (viewpoint - point) . n >= 0.
+ * 1 <= k <= 32 (clamped to the number of points).  The scene must be finite.  out_normals (n x 3 float32) and
+ * out_neighbors (n x min(k, n) int32, neighbour indices in (d2, index) order) are optional host buffers; the normals
+ * stay on the device and are adopted by mi355_icp_scene_commit_target, which makes reference mode usable on a
+ * scene that arrived without normals. */
+int mi355_icp_scene_normals(mi355_icp_ctx* ctx, int k, int flip_viewpoint, const float viewpoint[3], float* out_normals,
+                            int32_t* out_neighbors);
+
+/* Makes the current scene target cloud 0 (replacing all targets) without leaving the device, together with its
+ * normals if mi355_icp_scene_normals ran on it.  Fails with MI355_ICP_ERR_NONFINITE_INPUT if the scene still holds
+ * NaN/Inf. */
 int mi355_icp_scene_commit_target(mi355_icp_ctx* ctx);
 
 /* ---- host arithmetic (no GPU needed) ------------------------------------- */

@@ -836,3 +836,118 @@ size_t oracle_scene_filter_apply(const float* xyz, size_t n, const oracle_scene_
   }
   return kept;
 }
+
+/* ======================================================================== */
+/* Scene normals: the step right before the ICP in the reference,
+ *   cv::ppf_match_3d::computeNormalsPC3d(pc_scene, pc_scene_normals, 20, true, viewpoint)
+ *   (pose_estimation/src/opencv_surface_match.cpp:57-59; third-party, source absent: SURVEY.md 8a R4).
+ * Restated from upstream's published structure as recalled (PARITY UNPINNED): for every point the k nearest
+ * points of the same cloud (the point itself included; exact float32 d2 as in dist2; ordered by (d2, index)),
+ * covariance of those k points accumulated as upstream's meanCovLocalPCInd does - float32 products cloud[j]*cloud[k]
+ * added into doubles, divided by k, minus mean*mean^T - the eigenvector of the smallest eigenvalue (cyclic Jacobi
+ * here; upstream calls cv::eigen), cast to float32, and flipped so that (viewpoint - point) . normal >= 0
+ * (flipNormalViewpoint).  k is clamped to the number of points.                                                    */
+
+typedef struct knn_heap { int k, n; float* d; int32_t* i; } knn_heap;
+
+static inline void knn_offer(knn_heap* h, float d, int32_t j) {
+  /* list sorted ascending by (d, index) */
+  if (h->n == h->k) {
+    float wd = h->d[h->k - 1];
+    int32_t wi = h->i[h->k - 1];
+    if (!(d < wd || (d == wd && j < wi))) return;
+  }
+  int pos = h->n < h->k ? h->n++ : h->k - 1;
+  while (pos > 0 && (d < h->d[pos - 1] || (d == h->d[pos - 1] && j < h->i[pos - 1]))) {
+    h->d[pos] = h->d[pos - 1];
+    h->i[pos] = h->i[pos - 1];
+    --pos;
+  }
+  h->d[pos] = d;
+  h->i[pos] = j;
+}
+
+static void kd_knn_one(const oracle_kdtree* t, float qx, float qy, float qz, knn_heap* h) {
+  int32_t stack[128];
+  int sp = 0;
+  h->n = 0;
+  if (t->n) stack[sp++] = 0;
+  while (sp) {
+    const kd_node* nd = &t->nodes[stack[--sp]];
+    if (h->n == h->k && box_lb(nd, qx, qy, qz) > h->d[h->k - 1]) continue;
+    if (nd->left < 0) {
+      for (int32_t i = nd->begin; i < nd->end; ++i)
+        knn_offer(h, dist2(qx, qy, qz, t->pts[3 * (size_t)i], t->pts[3 * (size_t)i + 1], t->pts[3 * (size_t)i + 2]), t->perm[i]);
+    } else {
+      float ll = box_lb(&t->nodes[nd->left], qx, qy, qz), lr = box_lb(&t->nodes[nd->right], qx, qy, qz);
+      if (ll <= lr) { stack[sp++] = nd->right; stack[sp++] = nd->left; }
+      else { stack[sp++] = nd->left; stack[sp++] = nd->right; }
+    }
+  }
+}
+
+/* exact k-NN of every point of xyz within xyz: idx/d2 are n x k (k already clamped by the caller), (d2, index) order */
+void oracle_knn_self(const float* xyz, size_t n, int k, int32_t* idx, float* d2, int use_kdtree, int nthreads) {
+  oracle_kdtree* tree = use_kdtree ? oracle_kdtree_build(xyz, n) : NULL;
+#ifdef _OPENMP
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 64)
+#endif
+  for (long long q = 0; q < (long long)n; ++q) {
+    knn_heap h = {k, 0, &d2[(size_t)q * k], &idx[(size_t)q * k]};
+    float qx = xyz[3 * q], qy = xyz[3 * q + 1], qz = xyz[3 * q + 2];
+    if (tree) kd_knn_one(tree, qx, qy, qz, &h);
+    else
+      for (size_t j = 0; j < n; ++j) knn_offer(&h, dist2(qx, qy, qz, xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]), (int32_t)j);
+  }
+  (void)nthreads;
+  oracle_kdtree_free(tree);
+}
+
+/* smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi, fixed sweep order); v normalised */
+void oracle_smallest_eigvec3(const double C[9], double v[3]) {
+  double A[3][3], V[3][3], w[3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) A[i][j] = C[3 * i + j];
+  jacobi_eig3(A, V, w);
+  int m = 0;
+  if (w[1] < w[m]) m = 1;
+  if (w[2] < w[m]) m = 2;
+  double nrm = sqrt(V[0][m] * V[0][m] + V[1][m] * V[1][m] + V[2][m] * V[2][m]);
+  for (int i = 0; i < 3; ++i) v[i] = V[i][m] / nrm;
+}
+
+void oracle_normals(const float* xyz, size_t n, int k, int flip, const float viewpoint[3], float* out_normals,
+                    int32_t* out_idx /* n x k or NULL */, int use_kdtree, int nthreads) {
+  if (!n) return;
+  if ((size_t)k > n) k = (int)n;
+  int32_t* idx = out_idx ? out_idx : (int32_t*)malloc(n * (size_t)k * sizeof(int32_t));
+  float* d2 = (float*)malloc(n * (size_t)k * sizeof(float));
+  oracle_knn_self(xyz, n, k, idx, d2, use_kdtree, nthreads);
+  for (size_t q = 0; q < n; ++q) {
+    double cov[9] = {0}, mean[3] = {0};
+    for (int m = 0; m < k; ++m) {
+      const float* c = &xyz[3 * (size_t)idx[q * k + m]];
+      for (int j = 0; j < 3; ++j) {
+        for (int l = 0; l < 3; ++l) cov[3 * j + l] += (double)(c[j] * c[l]); /* float32 product, as upstream */
+        mean[j] += (double)c[j];
+      }
+    }
+    const double inv = 1.0 / (double)k;
+    for (int j = 0; j < 3; ++j) mean[j] *= inv;
+    for (int j = 0; j < 9; ++j) cov[j] *= inv;
+    for (int j = 0; j < 3; ++j)
+      for (int l = 0; l < 3; ++l) cov[3 * j + l] -= mean[j] * mean[l];
+    double v[3];
+    oracle_smallest_eigvec3(cov, v);
+    float nr[3] = {(float)v[0], (float)v[1], (float)v[2]};
+    if (flip) {
+      float vx = viewpoint[0] - xyz[3 * q], vy = viewpoint[1] - xyz[3 * q + 1], vz = viewpoint[2] - xyz[3 * q + 2];
+      float c = vx * nr[0] + vy * nr[1] + vz * nr[2];
+      if (c < 0) { nr[0] = -nr[0]; nr[1] = -nr[1]; nr[2] = -nr[2]; }
+    }
+    out_normals[3 * q] = nr[0]; out_normals[3 * q + 1] = nr[1]; out_normals[3 * q + 2] = nr[2];
+  }
+  if (!out_idx) free(idx);
+  free(d2);
+}

@@ -69,6 +69,9 @@ class Profile(C.Structure):
         ("reduce_launches", C.c_uint64),
         ("pairs_evaluated", C.c_double),
         ("iterations", C.c_uint64),
+        ("knn_scan_ms", C.c_double),
+        ("normals_ms", C.c_double),
+        ("normals_launches", C.c_uint64),
         ("scene_filter_ms", C.c_double),
         ("scene_filter_launches", C.c_uint64),
         ("scene_points_in", C.c_uint64),
@@ -113,6 +116,7 @@ SIGNATURES = {
     "mi355_icp_scene_load": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_size_t]),
     "mi355_icp_scene_filter": (C.c_int, [_ctx, C.c_int, C.c_void_p, _P(C.c_size_t)]),
     "mi355_icp_scene_download": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
+    "mi355_icp_scene_normals": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355_icp_scene_commit_target": (C.c_int, [_ctx]),
     "mi355_icp_solve_rigid": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi355_icp_host_update": (C.c_int, [_P(Params), C.c_void_p, C.c_int, C.c_void_p, _P(C.c_double), _P(C.c_int),

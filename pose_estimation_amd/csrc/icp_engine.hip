@@ -104,6 +104,13 @@ struct mi355_icp_ctx {
   // scene preparation (packed AoS xyz, ping-pong)
   float* scene[2] = {nullptr, nullptr}; size_t scene_cap = 0;
   uint32_t scene_n = 0; int scene_cur = 0; bool scene_loaded = false;
+  float* scene_planes = nullptr; size_t scene_planes_cap = 0;    // SoA copy of the scene for the k-NN scan
+  float* scene_normal_planes = nullptr; size_t scene_normal_planes_cap = 0;
+  float* scene_normals_aos = nullptr; size_t scene_normals_aos_cap = 0;
+  float* knn_d = nullptr; size_t knn_d_cap = 0;
+  int32_t* knn_i = nullptr; size_t knn_i_cap = 0;
+  int32_t* knn_out = nullptr; size_t knn_out_cap = 0;
+  bool scene_normals_valid = false; uint32_t scene_normals_padded = 0;
   unsigned long long* scene_state = nullptr; size_t scene_state_cap = 0;
   uint32_t* scene_counters = nullptr;       // device: ticket, kept total, error bits
   uint32_t* scene_counters_host = nullptr;  // pinned
@@ -544,6 +551,12 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   }
   (void)hipFree(c->scene[0]);
   (void)hipFree(c->scene[1]);
+  (void)hipFree(c->scene_planes);
+  (void)hipFree(c->scene_normal_planes);
+  (void)hipFree(c->scene_normals_aos);
+  (void)hipFree(c->knn_d);
+  (void)hipFree(c->knn_i);
+  (void)hipFree(c->knn_out);
   (void)hipFree(c->scene_state);
   (void)hipFree(c->scene_counters);
   if (c->scene_counters_host) (void)hipHostFree(c->scene_counters_host);
@@ -871,6 +884,7 @@ int mi355_icp_scene_load(mi355_icp_ctx* c, const float* xyz, size_t n_points, si
   c->scene_n = static_cast<uint32_t>(n_points);
   c->scene_cur = 0;
   c->scene_loaded = true;
+  c->scene_normals_valid = false;
   return MI355_ICP_OK;
 }
 
@@ -910,6 +924,7 @@ int mi355_icp_scene_filter(mi355_icp_ctx* c, int n_filters, const mi355_scene_fi
     }
     c->scene_n = c->scene_counters_host[1];
     c->scene_cur ^= 1;
+    c->scene_normals_valid = false;
   }
   if (out_n_points) *out_n_points = c->scene_n;
   return MI355_ICP_OK;
@@ -924,6 +939,65 @@ int mi355_icp_scene_download(mi355_icp_ctx* c, float* out_xyz, size_t capacity_p
   if (capacity_points < c->scene_n) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_download: buffer too small");
   HIP_TRY(c, hipSetDevice(c->device));
   if (c->scene_n) HIP_TRY(c, hipMemcpy(out_xyz, c->scene[c->scene_cur], static_cast<size_t>(c->scene_n) * 12, hipMemcpyDeviceToHost));
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_scene_normals(mi355_icp_ctx* c, int k, int flip_viewpoint, const float viewpoint[3], float* out_normals,
+                            int32_t* out_neighbors) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  c->err.clear();
+  if (!c->scene_loaded || c->scene_n == 0) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_normals: the scene is empty");
+  if (k < 1 || k > kMaxNormalNeighbors) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_normals: 1 <= k <= 32 required");
+  if (flip_viewpoint && !viewpoint) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_normals: viewpoint missing");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t n = c->scene_n;
+  const uint32_t padded = (n + kTile - 1) / kTile * kTile;
+  const uint32_t n_tiles = padded / kTile;
+  const uint32_t k_eff = std::min<uint32_t>(static_cast<uint32_t>(k), n);
+  const uint32_t kk = k <= 8 ? 8 : (k <= 20 ? 20 : 32);  // list length of the kernel instantiation
+  int st;
+  if ((st = grow(c, c->scene_planes, c->scene_planes_cap, static_cast<size_t>(padded) * 3)) != MI355_ICP_OK) return st;
+  if ((st = grow(c, c->scene_normal_planes, c->scene_normal_planes_cap, static_cast<size_t>(padded) * 3)) != MI355_ICP_OK) return st;
+  if ((st = grow(c, c->scene_normals_aos, c->scene_normals_aos_cap, static_cast<size_t>(n) * 3)) != MI355_ICP_OK) return st;
+  // split the target range so that the scan fills the chip (same XCD-aware rule as the NN scan)
+  const uint32_t qblocks = (n + kBlockThreads - 1) / kBlockThreads;
+  uint32_t split = std::max<uint32_t>(1, c->target_blocks / std::max<uint32_t>(qblocks, 1));
+  split = std::min(split, std::max<uint32_t>(1, n_tiles / std::max<uint32_t>(1, c->min_tiles_per_split)));
+  split = std::min<uint32_t>(split, 16);
+  if (split >= 8) split -= split % 8;
+  else if (split >= 4) split = 4;
+  else if (split >= 2) split = 2;
+  const uint32_t q_stride = qblocks * kBlockThreads;
+  const size_t list_len = static_cast<size_t>(split) * kk * q_stride;
+  if ((st = grow(c, c->knn_d, c->knn_d_cap, list_len)) != MI355_ICP_OK) return st;
+  if ((st = grow(c, c->knn_i, c->knn_i_cap, list_len)) != MI355_ICP_OK) return st;
+  if (out_neighbors && (st = grow(c, c->knn_out, c->knn_out_cap, static_cast<size_t>(n) * k_eff)) != MI355_ICP_OK) return st;
+  HIP_TRY(c, hipMemsetAsync(c->scene_counters, 0, 4 * sizeof(uint32_t), c->stream));
+  launch_scene_to_planes(c->stream, c->scene[c->scene_cur], n, c->scene_planes, padded, 0, padded, kTargetPad, c->scene_counters);
+  HIP_TRY(c, hipMemcpyAsync(c->scene_counters_host, c->scene_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->scene_counters_host[2] & 2u) return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "scene_normals: the scene holds NaN/Inf (apply MI355_SCENE_FILTER_FINITE first)");
+  const DevicePlanes P{c->scene_planes, c->scene_planes + padded, c->scene_planes + 2 * static_cast<size_t>(padded)};
+  const float vp[3] = {viewpoint ? viewpoint[0] : 0.f, viewpoint ? viewpoint[1] : 0.f, viewpoint ? viewpoint[2] : 0.f};
+  const bool profile = c->profile_always;
+  if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  launch_knn_scan(c->stream, k, P, n, n_tiles, split, c->knn_d, c->knn_i, q_stride);
+  if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  launch_normals(c->stream, k, P, n, k_eff, split, c->knn_d, c->knn_i, q_stride, flip_viewpoint ? 1 : 0, vp, c->scene_normals_aos,
+                 c->scene_normal_planes, padded, out_neighbors ? c->knn_out : nullptr);
+  if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (profile) {
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->prof.knn_scan_ms += ms;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->prof.normals_ms += ms;
+    c->prof.normals_launches += 1;
+  }
+  c->scene_normals_valid = true;
+  c->scene_normals_padded = padded;
+  if (out_normals) HIP_TRY(c, hipMemcpy(out_normals, c->scene_normals_aos, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost));
+  if (out_neighbors) HIP_TRY(c, hipMemcpy(out_neighbors, c->knn_out, static_cast<size_t>(n) * k_eff * sizeof(int32_t), hipMemcpyDeviceToHost));
   return MI355_ICP_OK;
 }
 
@@ -954,6 +1028,10 @@ int mi355_icp_scene_commit_target(mi355_icp_ctx* c) {
   set.planes = planes;
   set.stride = padded;
   set.clouds.assign(1, CloudEntry{0, n, padded});
+  if (c->scene_normals_valid && c->scene_normals_padded == padded) {  // normals of exactly this scene: copy them over
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.normals), 3 * static_cast<size_t>(padded) * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(set.normals, c->scene_normal_planes, 3 * static_cast<size_t>(padded) * sizeof(float), hipMemcpyDeviceToDevice));
+  }
   return MI355_ICP_OK;
 }
 

@@ -100,6 +100,14 @@ void launch_ref_accumulate(void* stream, const JobDesc* jobs_dev, const RefJobDe
                            uint8_t* selected, double* partials);
 void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums);
 
+// ---- scene normals (normals_kernels.hip) ----
+constexpr int kMaxNormalNeighbors = 32;
+void launch_knn_scan(void* stream, int k, DevicePlanes planes, uint32_t n, uint32_t n_tiles, uint32_t n_split,
+                     float* list_d, int32_t* list_i, uint32_t q_stride);
+void launch_normals(void* stream, int k, DevicePlanes planes, uint32_t n, uint32_t k_eff, uint32_t n_split,
+                    const float* list_d, const int32_t* list_i, uint32_t q_stride, int flip, const float* viewpoint,
+                    float* out_aos, float* out_planes, size_t plane_stride, int32_t* out_knn);
+
 // ---- RCCL, bound at run time (rccl_dyn.cpp) ----
 struct RcclApi;
 const RcclApi* rccl_api(const char** why_not);

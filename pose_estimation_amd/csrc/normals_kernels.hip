@@ -1,0 +1,289 @@
+// normals_kernels.hip — scene normals on the GPU: the step right before the ICP in the
+// reference, cv::ppf_match_3d::computeNormalsPC3d(pc_scene, pc_scene_normals, 20, true, viewpoint)
+// (pose_estimation/src/opencv_surface_match.cpp:57-59; third-party, restated in oracle/icp_oracle.c "Scene normals").
+//
+//   knn_scan_kernel<K>     exact brute-force K nearest neighbours of every scene point within the scene, the NN scan's
+//                          machinery (SoA target tiles through LDS, wave-uniform ds_read_b128 broadcasts, unfused float32
+//                          d2) with a sorted K-list per lane in registers; the target range is split across workgroups
+//   normals_kernel<K>      per point: merge the per-split lists by (d2, index), gather the K neighbours, covariance as
+//                          upstream's meanCovLocalPCInd (float32 products summed in double), cyclic Jacobi in double,
+//                          smallest-eigenvalue eigenvector -> float32, flipped towards the viewpoint
+// Arithmetic contract: neighbour sets identical to the oracle ((d2, index) order, so ties resolve the same way); the
+// double-precision covariance / Jacobi follow the oracle's operation order (compile with -ffp-contract=off).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "icp_internal.h"
+
+namespace mi355 {
+
+namespace {
+
+__device__ __forceinline__ float dist2(float qx, float qy, float qz, float tx, float ty, float tz) {
+  const float dx = qx - tx, dy = qy - ty, dz = qz - tz;
+  float a = dx * dx;
+  const float b = dy * dy, c = dz * dz;
+  a = a + b;
+  return a + c;
+}
+
+// Sorted insert into a register-resident list (ascending d; candidates arrive in ascending index, so a strict
+// comparison keeps equal distances in index order).  Fully unrolled: every index is a compile-time constant.
+template <int K>
+__device__ __forceinline__ void list_insert(float (&d)[K], int32_t (&ix)[K], float nd, int32_t ni) {
+  if (nd < d[K - 1]) {
+    d[K - 1] = nd;
+    ix[K - 1] = ni;
+#pragma unroll
+    for (int m = K - 1; m > 0; --m) {
+      const bool sw = d[m] < d[m - 1];
+      const float lo = sw ? d[m] : d[m - 1], hi = sw ? d[m - 1] : d[m];
+      const int32_t li = sw ? ix[m] : ix[m - 1], hi_i = sw ? ix[m - 1] : ix[m];
+      d[m - 1] = lo;
+      d[m] = hi;
+      ix[m - 1] = li;
+      ix[m] = hi_i;
+    }
+  }
+}
+
+}  // namespace
+
+// grid = (query_blocks * n_split), block = 256, one query per lane.  planes: SoA x|y|z of the scene, padded to whole
+// tiles with kTargetPad.  lists: [split][m][query] for d2 and index.
+template <int K>
+__global__ __launch_bounds__(kBlockThreads) void knn_scan_kernel(const float* __restrict__ px, const float* __restrict__ py,
+                                                                  const float* __restrict__ pz, uint32_t n, uint32_t /*n_tiles*/,
+                                                                  uint32_t n_split, uint32_t split_q, uint32_t split_r,
+                                                                  float* __restrict__ list_d, int32_t* __restrict__ list_i,
+                                                                  uint32_t q_stride) {
+  __shared__ float4 lds[2][3][kTile / 4];
+  const uint32_t qb = blockIdx.x / n_split, sp = blockIdx.x - qb * n_split;
+  const uint32_t tile0 = sp * split_q + (sp < split_r ? sp : split_r);
+  const uint32_t tile1 = tile0 + split_q + (sp < split_r ? 1u : 0u);
+  const uint32_t tid = threadIdx.x;
+  const uint32_t q = qb * kBlockThreads + tid;
+  const uint32_t qc = q < n ? q : 0;  // out-of-range lanes shadow point 0 and store nothing
+  const float qx = px[qc], qy = py[qc], qz = pz[qc];
+  float d[K];
+  int32_t ix[K];
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    d[m] = __builtin_inff();
+    ix[m] = -1;
+  }
+  const float4* __restrict__ gx = reinterpret_cast<const float4*>(px);
+  const float4* __restrict__ gy = reinterpret_cast<const float4*>(py);
+  const float4* __restrict__ gz = reinterpret_cast<const float4*>(pz);
+  {
+    const uint32_t g = tile0 * (kTile / 4) + tid;
+    lds[0][0][tid] = gx[g];
+    lds[0][1][tid] = gy[g];
+    lds[0][2][tid] = gz[g];
+  }
+  __syncthreads();
+  uint32_t cur = 0;
+  for (uint32_t tile = tile0; tile < tile1; ++tile) {
+    const bool more = tile + 1 < tile1;
+    float4 rx, ry, rz;
+    if (more) {
+      const uint32_t g = (tile + 1) * (kTile / 4) + tid;
+      rx = gx[g];
+      ry = gy[g];
+      rz = gz[g];
+    }
+    const float4* __restrict__ LX = lds[cur][0];
+    const float4* __restrict__ LY = lds[cur][1];
+    const float4* __restrict__ LZ = lds[cur][2];
+    const int32_t base = static_cast<int32_t>(tile * kTile);
+#pragma unroll 2
+    for (uint32_t g = 0; g < kTile / 4; ++g) {
+      const float4 X = LX[g], Y = LY[g], Z = LZ[g];
+      const float d0 = dist2(qx, qy, qz, X.x, Y.x, Z.x);
+      const float d1 = dist2(qx, qy, qz, X.y, Y.y, Z.y);
+      const float d2 = dist2(qx, qy, qz, X.z, Y.z, Z.z);
+      const float d3 = dist2(qx, qy, qz, X.w, Y.w, Z.w);
+      const float m = __builtin_fminf(__builtin_fminf(d0, d1), __builtin_fminf(d2, d3));
+      if (m < d[K - 1]) {  // rare once the list has warmed up; the four inserts keep candidates in index order
+        const int32_t j = base + static_cast<int32_t>(g * 4);
+        list_insert<K>(d, ix, d0, j);
+        list_insert<K>(d, ix, d1, j + 1);
+        list_insert<K>(d, ix, d2, j + 2);
+        list_insert<K>(d, ix, d3, j + 3);
+      }
+    }
+    if (more) {
+      lds[cur ^ 1][0][tid] = rx;
+      lds[cur ^ 1][1][tid] = ry;
+      lds[cur ^ 1][2][tid] = rz;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (q < n) {
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+      const size_t o = (static_cast<size_t>(sp) * K + m) * q_stride + q;
+      list_d[o] = d[m];
+      list_i[o] = ix[m];
+    }
+  }
+}
+
+// one thread per scene point
+template <int K>
+__global__ __launch_bounds__(kBlockThreads) void normals_kernel(const float* __restrict__ px, const float* __restrict__ py,
+                                                                 const float* __restrict__ pz, uint32_t n, uint32_t k_eff,
+                                                                 uint32_t n_split, const float* __restrict__ list_d,
+                                                                 const int32_t* __restrict__ list_i, uint32_t q_stride,
+                                                                 int flip, float vx, float vy, float vz,
+                                                                 float* __restrict__ out_aos, float* __restrict__ out_planes,
+                                                                 size_t plane_stride, int32_t* __restrict__ out_knn) {
+  const uint32_t q = blockIdx.x * kBlockThreads + threadIdx.x;
+  if (q >= n) return;
+  float d[K];
+  int32_t ix[K];
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    d[m] = list_d[static_cast<size_t>(m) * q_stride + q];
+    ix[m] = list_i[static_cast<size_t>(m) * q_stride + q];
+  }
+  for (uint32_t sp = 1; sp < n_split; ++sp) {
+#pragma unroll 1
+    for (int m = 0; m < K; ++m) {
+      const size_t o = (static_cast<size_t>(sp) * K + m) * q_stride + q;
+      const float nd = list_d[o];
+      if (!(nd < d[K - 1])) break;  // each split list is sorted: nothing further can enter
+      list_insert<K>(d, ix, nd, list_i[o]);
+    }
+  }
+  // covariance as upstream's meanCovLocalPCInd: float32 products accumulated in double
+  double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, mean[3] = {0, 0, 0};
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    if (static_cast<uint32_t>(m) < k_eff) {
+      const int32_t j = ix[m];
+      if (out_knn) out_knn[static_cast<size_t>(q) * k_eff + m] = j;
+      const float c[3] = {px[j], py[j], pz[j]};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) cov[3 * a + b] += static_cast<double>(c[a] * c[b]);
+        mean[a] += static_cast<double>(c[a]);
+      }
+    }
+  }
+  const double inv = 1.0 / static_cast<double>(k_eff);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) mean[a] *= inv;
+#pragma unroll
+  for (int a = 0; a < 9; ++a) cov[a] *= inv;
+  double A[3][3], V[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      A[a][b] = cov[3 * a + b] - mean[a] * mean[b];
+      V[a][b] = (a == b) ? 1.0 : 0.0;
+    }
+  // cyclic Jacobi, the oracle's jacobi_eig3 operation for operation
+#pragma unroll 1
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    const double off = __builtin_fabs(A[0][1]) + __builtin_fabs(A[0][2]) + __builtin_fabs(A[1][2]);
+    const double diag = __builtin_fabs(A[0][0]) + __builtin_fabs(A[1][1]) + __builtin_fabs(A[2][2]);
+    if (off <= 1e-300 || off <= 1e-32 * diag) break;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int r = p + 1; r < 3; ++r) {
+        if (A[p][r] != 0.0) {
+          const double theta = (A[r][r] - A[p][p]) / (2.0 * A[p][r]);
+          const double tt = (theta >= 0 ? 1.0 : -1.0) / (__builtin_fabs(theta) + __builtin_sqrt(theta * theta + 1.0));
+          const double c = 1.0 / __builtin_sqrt(tt * tt + 1.0), s = tt * c;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const double akp = A[k][p], akq = A[k][r];
+            A[k][p] = c * akp - s * akq;
+            A[k][r] = s * akp + c * akq;
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const double apk = A[p][k], aqk = A[r][k];
+            A[p][k] = c * apk - s * aqk;
+            A[r][k] = s * apk + c * aqk;
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const double vkp = V[k][p], vkq = V[k][r];
+            V[k][p] = c * vkp - s * vkq;
+            V[k][r] = s * vkp + c * vkq;
+          }
+        }
+      }
+  }
+  double w0 = A[0][0], w1 = A[1][1], w2 = A[2][2];
+  double e0 = V[0][0], e1 = V[1][0], e2 = V[2][0], wm = w0;
+  if (w1 < wm) { wm = w1; e0 = V[0][1]; e1 = V[1][1]; e2 = V[2][1]; }
+  if (w2 < wm) { wm = w2; e0 = V[0][2]; e1 = V[1][2]; e2 = V[2][2]; }
+  const double nrm = __builtin_sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+  float n0 = static_cast<float>(e0 / nrm), n1 = static_cast<float>(e1 / nrm), n2 = static_cast<float>(e2 / nrm);
+  if (flip) {
+    const float ax = vx - px[q], ay = vy - py[q], az = vz - pz[q];
+    float c = ax * n0;
+    const float t = ay * n1, u = az * n2;
+    c = c + t;
+    c = c + u;
+    if (c < 0) { n0 = -n0; n1 = -n1; n2 = -n2; }
+  }
+  if (out_aos) {
+    out_aos[static_cast<size_t>(q) * 3] = n0;
+    out_aos[static_cast<size_t>(q) * 3 + 1] = n1;
+    out_aos[static_cast<size_t>(q) * 3 + 2] = n2;
+  }
+  if (out_planes) {
+    out_planes[q] = n0;
+    out_planes[plane_stride + q] = n1;
+    out_planes[2 * plane_stride + q] = n2;
+  }
+}
+
+void launch_knn_scan(void* stream, int k, DevicePlanes planes, uint32_t n, uint32_t n_tiles, uint32_t n_split,
+                     float* list_d, int32_t* list_i, uint32_t q_stride) {
+  const uint32_t qblocks = (n + kBlockThreads - 1) / kBlockThreads;
+  if (!qblocks) return;
+  const uint32_t split_q = n_tiles / n_split, split_r = n_tiles % n_split;
+  dim3 grid(qblocks * n_split);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (k <= 8)
+    hipLaunchKernelGGL(knn_scan_kernel<8>, grid, dim3(kBlockThreads), 0, st, planes.x, planes.y, planes.z, n, n_tiles,
+                       n_split, split_q, split_r, list_d, list_i, q_stride);
+  else if (k <= 20)
+    hipLaunchKernelGGL(knn_scan_kernel<20>, grid, dim3(kBlockThreads), 0, st, planes.x, planes.y, planes.z, n, n_tiles,
+                       n_split, split_q, split_r, list_d, list_i, q_stride);
+  else
+    hipLaunchKernelGGL(knn_scan_kernel<32>, grid, dim3(kBlockThreads), 0, st, planes.x, planes.y, planes.z, n, n_tiles,
+                       n_split, split_q, split_r, list_d, list_i, q_stride);
+}
+
+void launch_normals(void* stream, int k, DevicePlanes planes, uint32_t n, uint32_t k_eff, uint32_t n_split,
+                    const float* list_d, const int32_t* list_i, uint32_t q_stride, int flip, const float* viewpoint,
+                    float* out_aos, float* out_planes, size_t plane_stride, int32_t* out_knn) {
+  const uint32_t blocks = (n + kBlockThreads - 1) / kBlockThreads;
+  if (!blocks) return;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (k <= 8)
+    hipLaunchKernelGGL(normals_kernel<8>, dim3(blocks), dim3(kBlockThreads), 0, st, planes.x, planes.y, planes.z, n, k_eff,
+                       n_split, list_d, list_i, q_stride, flip, viewpoint[0], viewpoint[1], viewpoint[2], out_aos, out_planes,
+                       plane_stride, out_knn);
+  else if (k <= 20)
+    hipLaunchKernelGGL(normals_kernel<20>, dim3(blocks), dim3(kBlockThreads), 0, st, planes.x, planes.y, planes.z, n, k_eff,
+                       n_split, list_d, list_i, q_stride, flip, viewpoint[0], viewpoint[1], viewpoint[2], out_aos, out_planes,
+                       plane_stride, out_knn);
+  else
+    hipLaunchKernelGGL(normals_kernel<32>, dim3(blocks), dim3(kBlockThreads), 0, st, planes.x, planes.y, planes.z, n, k_eff,
+                       n_split, list_d, list_i, q_stride, flip, viewpoint[0], viewpoint[1], viewpoint[2], out_aos, out_planes,
+                       plane_stride, out_knn);
+}
+
+}  // namespace mi355

@@ -292,6 +292,18 @@ class IcpEngine:
         self._check(lib.mi355_icp_scene_download(self._h, out.ctypes.data, n.value, C.byref(n)))
         return out
 
+    def scene_normals(self, k: int = 20, flip_viewpoint: bool = True, viewpoint=(0.0, 0.0, 0.0), want_neighbors: bool = False):
+        """k-NN PCA normals of the current scene (computeNormalsPC3d semantics). Returns normals [n, 3] (and the
+        neighbour indices [n, min(k, n)] when asked); the normals also stay on the device for scene_commit_target."""
+        n = C.c_size_t()
+        self._check(lib.mi355_icp_scene_download(self._h, None, 0, C.byref(n)))
+        vp = np.ascontiguousarray(viewpoint, dtype=np.float32)
+        out = np.empty((n.value, 3), dtype=np.float32)
+        nb = np.empty((n.value, min(k, n.value)), dtype=np.int32) if want_neighbors else None
+        self._check(lib.mi355_icp_scene_normals(self._h, k, int(flip_viewpoint), vp.ctypes.data, out.ctypes.data,
+                                                nb.ctypes.data if want_neighbors else None))
+        return (out, nb) if want_neighbors else out
+
     def scene_commit_target(self):
         self._check(lib.mi355_icp_scene_commit_target(self._h))
         self.n_targets = 1

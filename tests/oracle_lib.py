@@ -275,3 +275,36 @@ def scene_filter(xyz, filters):
     out = np.empty_like(xyz)
     n = lib.oracle_scene_filter_apply(xyz.ctypes.data, xyz.shape[0], arr, len(filters), out.ctypes.data)
     return out[:n].copy()
+
+
+# ---- scene normals (k-NN PCA), reference opencv_surface_match.cpp:57-59 ----
+lib.oracle_knn_self.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+lib.oracle_normals.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+lib.oracle_smallest_eigvec3.argtypes = [C.c_void_p, C.c_void_p]
+
+
+def knn_self(xyz, k, use_kdtree=True, nthreads=1):
+    xyz = _f32(xyz)
+    k = min(k, xyz.shape[0])
+    idx = np.empty((xyz.shape[0], k), dtype=np.int32)
+    d2 = np.empty((xyz.shape[0], k), dtype=np.float32)
+    lib.oracle_knn_self(xyz.ctypes.data, xyz.shape[0], k, idx.ctypes.data, d2.ctypes.data, int(use_kdtree), nthreads)
+    return idx, d2
+
+
+def normals(xyz, k=20, flip=True, viewpoint=(0.0, 0.0, 0.0), use_kdtree=True, nthreads=1, want_idx=False):
+    xyz = _f32(xyz)
+    kk = min(k, xyz.shape[0])
+    out = np.empty_like(xyz)
+    vp = np.ascontiguousarray(viewpoint, dtype=np.float32)
+    idx = np.empty((xyz.shape[0], kk), dtype=np.int32) if want_idx else None
+    lib.oracle_normals(xyz.ctypes.data, xyz.shape[0], k, int(flip), vp.ctypes.data, out.ctypes.data,
+                       idx.ctypes.data if want_idx else None, int(use_kdtree), nthreads)
+    return (out, idx) if want_idx else out
+
+
+def smallest_eigvec3(Cm):
+    Cm = np.ascontiguousarray(Cm, dtype=np.float64).reshape(9)
+    v = np.empty(3)
+    lib.oracle_smallest_eigvec3(Cm.ctypes.data, v.ctypes.data)
+    return v

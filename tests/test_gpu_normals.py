@@ -1,0 +1,73 @@
+"""Scene normals on the GPU against the oracle: identical neighbour lists ((d2, index) order) and normals."""
+import numpy as np
+import pytest
+
+import oracle_lib as ora
+import synth_twin as st
+
+pytestmark = pytest.mark.gpu
+
+
+def check(engine, xyz, k=20, flip=True, vp=(0.0, 0.0, 0.0), kd=True):
+    engine.scene_load(xyz)
+    n_gpu, nb = engine.scene_normals(k, flip, vp, want_neighbors=True)
+    n_cpu, idx = ora.normals(xyz, k, flip, vp, use_kdtree=kd, nthreads=ora.max_threads(), want_idx=True)
+    assert np.array_equal(nb, idx), "neighbour lists differ"
+    same = np.array_equal(n_gpu.view(np.uint32), n_cpu.view(np.uint32))
+    if not same:  # f64 sqrt/divide sequences may differ in the last bit; the direction must still agree to float32 precision
+        np.testing.assert_allclose(n_gpu, n_cpu, atol=3e-6)
+    return same
+
+
+@pytest.mark.parametrize("n", [1, 2, 19, 20, 21, 255, 257, 1025, 5000, 40000])
+def test_normals_match_oracle(engine, n):
+    xyz = st.synth_cloud_np(st.TARGET_SEED, n)
+    check(engine, xyz, kd=n > 3000)
+
+
+def test_other_k_and_viewpoints(engine):
+    xyz = st.synth_cloud_np(st.TARGET_SEED + 3, 6000)
+    for k, flip, vp in ((5, True, (0, 0, 10.0)), (8, False, (0, 0, 0)), (12, True, (3.0, -2.0, 1.0)), (32, True, (0, 0, 0))):
+        check(engine, xyz, k, flip, vp)
+
+
+def test_lattice_ties(engine):
+    g = np.arange(8, dtype=np.float32)
+    t = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    t = np.ascontiguousarray(t[np.random.default_rng(0).permutation(len(t))])
+    engine.scene_load(t)
+    _, nb = engine.scene_normals(7, False, (0, 0, 0), want_neighbors=True)
+    idx, _ = ora.knn_self(t, 7, use_kdtree=False)
+    assert np.array_equal(nb, idx)
+
+
+def test_normals_feed_reference_mode_through_commit_target(engine):
+    """camera frame -> filters -> normals -> commit -> reference-mode ICP, never leaving the device for the scene."""
+    import pose_estimation_amd as pa
+    T = st.perturbation(-1)
+    scene = st.synth_cloud_np(st.TARGET_SEED, 8000)
+    model = st.synth_cloud_np(st.SOURCE_SEED, 6000, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T)
+    raw = np.concatenate([scene, np.full((300, 3), np.nan, np.float32)])
+    raw = raw[np.random.default_rng(5).permutation(len(raw))]
+    engine.scene_load(raw)
+    engine.scene_filter([(pa._lib.SCENE_FILTER_FINITE, [])])
+    clean = engine.scene_download()
+    normals = engine.scene_normals(20, True, (0.0, 0.0, 0.0))
+    engine.scene_commit_target()
+    engine.set_sources([model])
+    res = engine.align_reference(np.eye(4)[None], 100, 0.005, 2.5, 6)
+    tgt6 = np.concatenate([clean, ora.normals(clean, 20, True, (0, 0, 0), nthreads=ora.max_threads())], axis=1)
+    np.testing.assert_allclose(normals, tgt6[:, 3:], atol=3e-6)
+    o = ora.icp_reference(model, np.concatenate([clean, normals], axis=1), np.eye(4), 100, 0.005, 2.5, 6)
+    assert res.passes[0] == o["passes"] and np.linalg.norm(res.poses[0] - o["pose"]) <= 1e-5
+    assert np.linalg.norm(res.poses[0] - np.linalg.inv(T)) < 5e-3
+
+
+def test_normals_need_a_finite_scene(engine):
+    import pose_estimation_amd as pa
+    bad = st.synth_cloud_np(st.TARGET_SEED, 100)
+    bad[7, 1] = np.nan
+    engine.scene_load(bad)
+    with pytest.raises(pa.IcpError) as e:
+        engine.scene_normals(20)
+    assert e.value.status == pa._lib.ERR_NONFINITE_INPUT
