@@ -29,22 +29,24 @@ __device__ __forceinline__ float dist2(float qx, float qy, float qz, float tx, f
 }
 
 // Sorted insert into a register-resident list (ascending d; candidates arrive in ascending index, so a strict
-// comparison keeps equal distances in index order).  Fully unrolled: every index is a compile-time constant.
+// comparison keeps equal distances in index order).  Written as an independent select per slot - slot m takes the old
+// slot m-1 if the newcomer sorts before it, the newcomer if it sorts before slot m only - so there is no dependency
+// chain and every register index is a compile-time constant (one compare + four selects per slot).
 template <int K>
 __device__ __forceinline__ void list_insert(float (&d)[K], int32_t (&ix)[K], float nd, int32_t ni) {
   if (nd < d[K - 1]) {
-    d[K - 1] = nd;
-    ix[K - 1] = ni;
+    bool lt[K];
+#pragma unroll
+    for (int m = 0; m < K; ++m) lt[m] = nd < d[m];
 #pragma unroll
     for (int m = K - 1; m > 0; --m) {
-      const bool sw = d[m] < d[m - 1];
-      const float lo = sw ? d[m] : d[m - 1], hi = sw ? d[m - 1] : d[m];
-      const int32_t li = sw ? ix[m] : ix[m - 1], hi_i = sw ? ix[m - 1] : ix[m];
-      d[m - 1] = lo;
-      d[m] = hi;
-      ix[m - 1] = li;
-      ix[m] = hi_i;
+      const float keep_d = lt[m] ? nd : d[m];
+      const int32_t keep_i = lt[m] ? ni : ix[m];
+      d[m] = lt[m - 1] ? d[m - 1] : keep_d;
+      ix[m] = lt[m - 1] ? ix[m - 1] : keep_i;
     }
+    d[0] = lt[0] ? nd : d[0];
+    ix[0] = lt[0] ? ni : ix[0];
   }
 }
 
