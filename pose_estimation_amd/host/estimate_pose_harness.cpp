@@ -4,8 +4,12 @@
 // driving the refine half through the C++ mirror.  PPF matching is not part of this path, so candidate
 // poses are synthesised around the known alignment the way PPF votes would deliver them.
 //
-//   estimate_pose_harness <n_model> <n_scene> [n_candidates] [reference]
-//     prints the 7-float pose and per-candidate results; "reference" selects Mode::Reference (scene with normals)
+//   estimate_pose_harness <n_model> <n_scene> [n_candidates] [reference|pipeline]
+//     prints the 7-float pose and per-candidate results; "reference" selects Mode::Reference (scene with normals);
+//     "pipeline" starts from a raw camera-like frame (NaN dropouts + a table plane) and runs the whole
+//     create_surface_match_pc -> computeNormalsPC3d -> ICP chain on the device: NaN removal, plane band, k = 20
+//     normals, commit, reference-mode refine (pose_estimation.cpp:211-279, opencv_surface_match.cpp:57-94)
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -42,7 +46,8 @@ int main(int argc, char** argv) {
   const size_t n_model = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 1000;
   const size_t n_scene = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 1000;
   const int n_cand = argc > 3 ? std::atoi(argv[3]) : 7;
-  const bool reference_mode = argc > 4 && std::string(argv[4]) == "reference";
+  const bool pipeline = argc > 4 && std::string(argv[4]) == "pipeline";
+  const bool reference_mode = pipeline || (argc > 4 && std::string(argv[4]) == "reference");
   EstimatePoseRequest req;
   req.object = "bumpy_sphere";
   EstimatePoseResponse resp;
@@ -66,8 +71,41 @@ int main(int argc, char** argv) {
       results.push_back(p);
     }
     size_t best = 0;
-    const std::vector<float> pose = mi355::ppf_match_3d::refine_candidates(
-        icp, mi355::CloudView{model.data(), n_model, 12}, mi355::CloudView{scene.data(), n_scene, 4 * scene_cols}, results, true, &best);
+    std::vector<float> pose;
+    if (pipeline) {
+      // raw frame = the scene sample + a table plane z = -1.3 under it + 5 % NaN pixels, interleaved
+      std::vector<float> raw;
+      raw.reserve(3 * (n_scene + n_scene / 2));
+      for (size_t i = 0; i < n_scene; ++i) {
+        const bool drop = (i % 20) == 7;
+        for (int c2 = 0; c2 < 3; ++c2) raw.push_back(drop ? std::nanf("") : scene[6 * i + c2]);
+        if (i % 2 == 0) {
+          raw.push_back(-1.5f + 3.0f * static_cast<float>(i % 1000) / 1000.0f);
+          raw.push_back(-1.5f + 3.0f * static_cast<float>((i / 7) % 1000) / 1000.0f);
+          raw.push_back(-1.3f);
+        }
+      }
+      mi355::Engine& eng = icp.engine();
+      eng.scene_load(mi355::CloudView{raw.data(), raw.size() / 3, 12});
+      mi355_scene_filter fin{};
+      fin.kind = MI355_SCENE_FILTER_FINITE;
+      mi355_scene_filter band{};
+      band.kind = MI355_SCENE_FILTER_PLANE_BAND_REMOVE;  // plane 0x + 0y + 1z + 1.3 = 0, band 0.005 (pose_estimation.cpp:320)
+      band.p[0] = 0.f; band.p[1] = 0.f; band.p[2] = 1.f; band.p[3] = 1.3f; band.p[4] = 0.005f;
+      const size_t kept = eng.scene_filter({fin, band});
+      std::printf("pipeline: %zu raw points -> %zu kept\n", raw.size() / 3, kept);
+      eng.scene_normals(20, true, {0.f, 0.f, 0.f});  // computeNormalsPC3d(scene, out, 20, true, viewpoint 0)
+      eng.scene_commit_target();
+      eng.set_sources({mi355::CloudView{model.data(), n_model, 12}});
+      std::vector<mi355::ppf_match_3d::Pose3DPtr> subset(results.begin(), results.begin() + static_cast<std::ptrdiff_t>(results.size() > 6 ? 6 : results.size()));
+      icp.registerUploaded(subset, 0, 0);
+      best = mi355::ppf_match_3d::select_best_pose(subset, results.size());
+      pose.assign(7, 0.f);
+      mi355_icp_pose_to_pose7(results[best]->pose.data(), pose.data(), 1);
+    } else {
+      pose = mi355::ppf_match_3d::refine_candidates(icp, mi355::CloudView{model.data(), n_model, 12},
+                                                    mi355::CloudView{scene.data(), n_scene, 4 * scene_cols}, results, true, &best);
+    }
     for (size_t k = 0; k < results.size(); ++k)
       std::printf("candidate %zu votes %zu residual %.17g iterations %d\n", k, results[k]->numVotes, results[k]->residual,
                   k < icp.last_result().iterations.size() ? icp.last_result().iterations[k] : 0);

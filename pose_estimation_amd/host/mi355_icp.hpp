@@ -76,6 +76,25 @@ class Engine {
     return r;
   }
 
+  // --- scene preparation on the device (pose_estimation.cpp:229-276 and opencv_surface_match.cpp:57-59) ---
+  void scene_load(const CloudView& raw) { check(mi355_icp_scene_load(ctx_, raw.data, raw.n, raw.stride_bytes), "mi355_icp_scene_load"); }
+  std::size_t scene_filter(const std::vector<mi355_scene_filter>& filters) {
+    std::size_t kept = 0;
+    check(mi355_icp_scene_filter(ctx_, static_cast<int>(filters.size()), filters.data(), &kept), "mi355_icp_scene_filter");
+    return kept;
+  }
+  std::vector<float> scene_download() {
+    std::size_t n = 0;
+    check(mi355_icp_scene_download(ctx_, nullptr, 0, &n), "mi355_icp_scene_download");
+    std::vector<float> out(3 * n);
+    check(mi355_icp_scene_download(ctx_, out.data(), n, &n), "mi355_icp_scene_download");
+    return out;
+  }
+  void scene_normals(int k, bool flip, const std::array<float, 3>& viewpoint) {
+    check(mi355_icp_scene_normals(ctx_, k, flip ? 1 : 0, viewpoint.data(), nullptr, nullptr), "mi355_icp_scene_normals");
+  }
+  void scene_commit_target() { check(mi355_icp_scene_commit_target(ctx_), "mi355_icp_scene_commit_target"); }
+
   mi355_icp_ctx* handle() { return ctx_; }
 
  private:

@@ -71,3 +71,21 @@ def test_normals_need_a_finite_scene(engine):
     with pytest.raises(pa.IcpError) as e:
         engine.scene_normals(20)
     assert e.value.status == pa._lib.ERR_NONFINITE_INPUT
+
+
+def test_cpp_harness_full_pipeline_on_device(engine):
+    """The C++ host mirror drives raw frame -> NaN removal + plane band -> k=20 normals -> commit -> reference-mode
+    refine, and lands on the known alignment."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build", "estimate_pose_harness")
+    out = subprocess.run([exe, "4000", "6000", "3", "pipeline"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    kept = [l for l in lines if l.startswith("pipeline:")][0].split()
+    assert int(kept[1]) == 9000 and int(kept[5]) == 6000 - 300       # 3000 plane points and 300 NaN pixels removed
+    poses = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]).reshape(4, 4) for l in lines if l.startswith("pose ")}
+    gt = np.linalg.inv(st.perturbation(-1))
+    for k in range(3):
+        assert np.linalg.norm(poses[k] - gt) < 6e-3, k
