@@ -56,6 +56,7 @@ struct Plan {
   uint32_t max_blocks_x = 0;   // scan grid.x
   uint32_t max_src_blocks = 0; // resolve grid.x
   int scan_ppl = 8;            // source points per lane the scan kernel is launched with
+  bool fused = false;          // fused-filter scan + exact resolve (large launches) instead of the all-exact scan
 };
 
 uint32_t env_u32(const char* name, uint32_t dflt) {
@@ -124,6 +125,16 @@ struct mi355_icp_ctx {
 
   int scan_ppl = 0;                  // scan points-per-lane override (2, 4, 8); 0 = planner decides per call
   bool scan_sgpr = false;            // experimental scalar-load scan (MI355_ICP_SCAN_MODE=sgpr)
+  int scan_fused = -1;               // -1 auto (fused filter for >= 4e11 pairs per launch), 0 never (exact), 1 always
+  // fused-filter path
+  unsigned long long* keys3 = nullptr; size_t keys3_cap = 0;
+  uint32_t* overflow_list = nullptr;   size_t overflow_list_cap = 0;
+  uint32_t* overflow_count = nullptr;  uint32_t* overflow_count_host = nullptr; size_t overflow_jobs_cap = 0;
+  float* fb_planes = nullptr;          size_t fb_planes_cap = 0;   // gathered overflow points (SoA)
+  int32_t* fb_index = nullptr;         size_t fb_index_cap = 0;
+  float* fb_dist2 = nullptr;           size_t fb_dist2_cap = 0;
+  JobDesc* jobs2_dev = nullptr;        JobDesc* jobs2_host = nullptr; size_t jobs2_cap = 0;
+  uint64_t overflow_points_total = 0;  // statistics
   uint32_t target_blocks = 12288;    // planner: aim for about this many scan workgroups per launch
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
 };
@@ -216,7 +227,7 @@ int grow(mi355_icp_ctx* c, T*& ptr, size_t& cap, size_t need) {
 
 int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs) {
   int st;
-  if ((st = grow(c, c->keys, c->keys_cap, static_cast<size_t>(plan.max_split) * plan.out_total)) != MI355_ICP_OK) return st;
+  if (!plan.fused && (st = grow(c, c->keys, c->keys_cap, static_cast<size_t>(plan.max_split) * plan.out_total)) != MI355_ICP_OK) return st;
   if (plan.out_total > c->out_cap) {
     if (c->out_index) { HIP_TRY(c, hipFree(c->out_index)); c->out_index = nullptr; }
     if (c->out_dist2) { HIP_TRY(c, hipFree(c->out_dist2)); c->out_dist2 = nullptr; }
@@ -227,6 +238,18 @@ int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs) {
     c->out_cap = want;
   }
   if ((st = grow(c, c->partials, c->partials_cap, static_cast<size_t>(std::max<uint32_t>(plan.partial_total, 1)) * MI355_ICP_NSUMS)) != MI355_ICP_OK) return st;
+  if (plan.fused) {
+    if ((st = grow(c, c->keys3, c->keys3_cap, 3 * static_cast<size_t>(plan.max_split) * plan.out_total)) != MI355_ICP_OK) return st;
+    if ((st = grow(c, c->overflow_list, c->overflow_list_cap, std::max<size_t>(plan.out_total, 1))) != MI355_ICP_OK) return st;
+    if (n_jobs > c->overflow_jobs_cap) {
+      if (c->overflow_count) { HIP_TRY(c, hipFree(c->overflow_count)); c->overflow_count = nullptr; }
+      if (c->overflow_count_host) { HIP_TRY(c, hipHostFree(c->overflow_count_host)); c->overflow_count_host = nullptr; }
+      const size_t want = std::max<size_t>(n_jobs, 8) * 2;
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->overflow_count), want * sizeof(uint32_t)));
+      HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->overflow_count_host), want * sizeof(uint32_t), hipHostMallocDefault));
+      c->overflow_jobs_cap = want;
+    }
+  }
   if (n_jobs > c->jobs_cap) {
     if (c->sums_dev) { HIP_TRY(c, hipFree(c->sums_dev)); c->sums_dev = nullptr; }
     if (c->jobs_dev) { HIP_TRY(c, hipFree(c->jobs_dev)); c->jobs_dev = nullptr; }
@@ -241,6 +264,15 @@ int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs) {
     c->jobs_cap = want;
   }
   return MI355_ICP_OK;
+}
+
+// XCD-aware split count: workgroups b and b+8 share an XCD (and its L2); with n_split in {1,2,4} or a multiple of 8
+// they also share the run of target tiles they stream.
+uint32_t xcd_round(uint32_t split) {
+  if (split >= 8) return split - split % 8;
+  if (split >= 4) return 4;
+  if (split >= 2) return 2;
+  return 1;
 }
 
 // Lays the jobs out and decides how finely to cut each target: enough scan workgroups to keep
@@ -262,6 +294,9 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   // makes the coarsest workgroups; below ~4e11 pairs per launch the finer 2-point workgroups balance the 256 CUs
   // better and win (profiles/r01b_scan_ab_sizes.txt: 1M<->1M 135 vs 141 ms; 64x50k<->50k 24.3 vs 21.5 ms).
   plan.scan_ppl = c->scan_ppl ? c->scan_ppl : (total_pairs >= 4e11 ? 8 : 2);
+  // The fused filter (7 issue slots per pair instead of 9, exact results by construction: icp_fused_kernels.hip) pays
+  // once the scan dominates; small launches keep the all-exact scan, whose resolve re-scans half as many targets.
+  plan.fused = c->scan_fused < 0 ? total_pairs >= 4e11 : c->scan_fused == 1;
   const uint32_t scan_src = static_cast<uint32_t>(kBlockThreads * plan.scan_ppl);
   uint64_t total_src_blocks = 0;
   for (int k = 0; k < n_jobs; ++k)
@@ -287,9 +322,7 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
     uint32_t split = std::min(std::max<uint32_t>(want_split, 1), cap);
     // XCD-aware: workgroups b and b+8 share an XCD (and its L2); with n_split in {1,2,4} or a multiple of 8 they
     // also share the run of target tiles they stream
-    if (split >= 8) split -= split % 8;
-    else if (split >= 4) split = 4;
-    else if (split >= 2) split = 2;
+    split = xcd_round(split);
     J.n_split = split;
     J.split_q = J.tgt_tiles / split;
     J.split_r = J.tgt_tiles % split;
@@ -324,6 +357,75 @@ bool pose_to_f32(const double* pose16, float* out12) {
   return ok;
 }
 
+// Fused path, overflow handling: points whose candidate chunks did not fit the filter's band are answered by the
+// all-exact scan on a gathered copy.  counts[] (host) holds the number of such points per active job.
+int run_overflow_fallback(mi355_icp_ctx* c, const Plan& plan, int n_active, const uint32_t* counts) {
+  std::vector<int> who;
+  size_t padded_total = 0, blocks_total = 0, scan_blocks_total = 0;
+  for (int k = 0; k < n_active; ++k)
+    if (counts[k]) {
+      who.push_back(k);
+      padded_total += (static_cast<size_t>(counts[k]) + kSrcPad - 1) / kSrcPad * kSrcPad;
+      blocks_total += (counts[k] + kSrcPerBlock - 1) / kSrcPerBlock;
+      scan_blocks_total += (counts[k] + 2 * kBlockThreads - 1) / (2 * kBlockThreads);
+    }
+  int st;
+  if ((st = grow(c, c->fb_planes, c->fb_planes_cap, 3 * padded_total)) != MI355_ICP_OK) return st;
+  if ((st = grow(c, c->fb_index, c->fb_index_cap, padded_total)) != MI355_ICP_OK) return st;
+  if ((st = grow(c, c->fb_dist2, c->fb_dist2_cap, padded_total)) != MI355_ICP_OK) return st;
+  if (who.size() > c->jobs2_cap) {
+    if (c->jobs2_dev) { HIP_TRY(c, hipFree(c->jobs2_dev)); c->jobs2_dev = nullptr; }
+    if (c->jobs2_host) { HIP_TRY(c, hipHostFree(c->jobs2_host)); c->jobs2_host = nullptr; }
+    const size_t want = std::max<size_t>(who.size(), 8) * 2;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->jobs2_dev), want * sizeof(JobDesc)));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->jobs2_host), want * sizeof(JobDesc), hipHostMallocDefault));
+    c->jobs2_cap = want;
+  }
+  const uint32_t want_split = static_cast<uint32_t>(std::max<size_t>(1, c->target_blocks / std::max<size_t>(scan_blocks_total, 1)));
+  uint32_t max_split = 1, bx = 0, sbx = 0;
+  size_t off = 0, prow = 0;
+  const DevicePlanes S = c->sources.view(), T = c->targets.view();
+  for (size_t q = 0; q < who.size(); ++q) {
+    const JobDesc& M = c->jobs_host[who[q]];
+    const uint32_t n = counts[who[q]];
+    const uint32_t padded = (n + kSrcPad - 1) / kSrcPad * kSrcPad;
+    launch_gather_points(c->stream, S, M.src_off, c->overflow_list + M.out_off, n, c->fb_planes + off, padded_total, padded);
+    JobDesc J = M;
+    J.src_off = static_cast<uint32_t>(off);
+    J.src_n = n;
+    J.src_blocks = (n + kSrcPerBlock - 1) / kSrcPerBlock;
+    J.scan_blocks = (n + 2 * kBlockThreads - 1) / (2 * kBlockThreads);
+    const uint32_t cap = std::max<uint32_t>(1, J.tgt_tiles / std::max<uint32_t>(1, c->min_tiles_per_split));
+    J.n_split = xcd_round(std::min(std::max<uint32_t>(want_split, 1), cap));
+    J.split_q = J.tgt_tiles / J.n_split;
+    J.split_r = J.tgt_tiles % J.n_split;
+    J.out_off = static_cast<uint32_t>(off);
+    J.partial_off = static_cast<uint32_t>(prow);
+    c->jobs2_host[q] = J;
+    max_split = std::max(max_split, J.n_split);
+    bx = std::max(bx, J.scan_blocks * J.n_split);
+    sbx = std::max(sbx, J.src_blocks);
+    off += padded;
+    prow += J.src_blocks;
+  }
+  if ((st = grow(c, c->keys, c->keys_cap, static_cast<size_t>(max_split) * padded_total)) != MI355_ICP_OK) return st;
+  if ((st = grow(c, c->partials, c->partials_cap, std::max<size_t>(blocks_total, plan.partial_total) * MI355_ICP_NSUMS)) != MI355_ICP_OK) return st;
+  HIP_TRY(c, hipMemcpyAsync(c->jobs2_dev, c->jobs2_host, who.size() * sizeof(JobDesc), hipMemcpyHostToDevice, c->stream));
+  const DevicePlanes F{c->fb_planes, c->fb_planes + padded_total, c->fb_planes + 2 * padded_total};
+  launch_nn_scan(c->stream, 2, c->jobs2_dev, static_cast<int>(who.size()), bx, F, T, c->keys, static_cast<uint32_t>(padded_total));
+  launch_resolve(c->stream, c->jobs2_dev, static_cast<int>(who.size()), sbx, F, T, c->keys, static_cast<uint32_t>(padded_total), c->fb_index,
+                 c->fb_dist2, c->partials, c->error_flag);
+  for (size_t q = 0; q < who.size(); ++q) {
+    const JobDesc& M = c->jobs_host[who[q]];
+    const JobDesc& J = c->jobs2_host[q];
+    launch_scatter_results(c->stream, c->overflow_list + M.out_off, J.src_n, c->fb_index + J.out_off, c->fb_dist2 + J.out_off,
+                           c->out_index, c->out_dist2, M.out_off);
+    c->overflow_points_total += J.src_n;
+  }
+  HIP_TRY(c, hipGetLastError());
+  return MI355_ICP_OK;
+}
+
 // Enqueues one correspondence pass for the first n_active descriptors of jobs_host and leaves
 // their sums in sums_host (synchronises the stream).  `local_only` skips the collective.
 int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only) {
@@ -336,13 +438,32 @@ int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, boo
     sbx = std::max(sbx, J.src_blocks);
     pairs += static_cast<double>(J.src_n) * static_cast<double>(J.tgt_n);
   }
-  (void)plan;
   const DevicePlanes S = c->sources.view(), T = c->targets.view();
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-  if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
-  if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-  if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
-  if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+  if (plan.fused) {
+    const uint32_t rank_stride = plan.max_split * plan.out_total;
+    if (bx) launch_nn_scan_fused(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, T, c->keys3, plan.out_total, rank_stride);
+    if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->overflow_count, 0, static_cast<size_t>(n_active) * sizeof(uint32_t), c->stream));
+    if (sbx) launch_resolve_fused(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys3, plan.out_total, rank_stride, c->out_index,
+                                  c->out_dist2, c->partials, c->overflow_list, c->overflow_count, c->error_flag);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->overflow_count_host, c->overflow_count, static_cast<size_t>(n_active) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    bool any = false;
+    for (int k = 0; k < n_active; ++k) any = any || c->overflow_count_host[k] != 0;
+    if (any) {
+      const int st = run_overflow_fallback(c, plan, n_active, c->overflow_count_host);
+      if (st != MI355_ICP_OK) return st;
+    }
+    if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    if (sbx) launch_accumulate(c->stream, c->jobs_dev, n_active, sbx, S, T, c->out_index, c->out_dist2, c->partials);
+  } else {
+    if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
+    if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
+    if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+  }
   launch_final_reduce(c->stream, c->jobs_dev, n_active, c->partials, c->sums_dev);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
   HIP_TRY(c, hipGetLastError());
@@ -518,6 +639,9 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   {
     const char* mode = std::getenv("MI355_ICP_SCAN_MODE");
     c->scan_sgpr = mode && std::string(mode) == "sgpr";
+    if (mode && std::string(mode) == "exact") c->scan_fused = 0;
+    if (mode && std::string(mode) == "fused") c->scan_fused = 1;
+    if (c->scan_sgpr) c->scan_fused = 0;
   }
   c->target_blocks = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks);
   c->min_tiles_per_split = env_u32("MI355_ICP_MIN_TILES_PER_SPLIT", c->min_tiles_per_split);
@@ -560,6 +684,15 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   (void)hipFree(c->scene_state);
   (void)hipFree(c->scene_counters);
   if (c->scene_counters_host) (void)hipHostFree(c->scene_counters_host);
+  (void)hipFree(c->keys3);
+  (void)hipFree(c->overflow_list);
+  (void)hipFree(c->overflow_count);
+  if (c->overflow_count_host) (void)hipHostFree(c->overflow_count_host);
+  (void)hipFree(c->fb_planes);
+  (void)hipFree(c->fb_index);
+  (void)hipFree(c->fb_dist2);
+  (void)hipFree(c->jobs2_dev);
+  if (c->jobs2_host) (void)hipHostFree(c->jobs2_host);
   (void)hipFree(c->owner);
   (void)hipFree(c->selected);
   (void)hipFree(c->ref_partials);

@@ -1,0 +1,181 @@
+// icp_fused_kernels.hip — the fast NN scan for large clouds: a FUSED-arithmetic filter in front of the exact test.
+//
+// The exact contract (oracle/icp_oracle.c) forbids FMA in d2, which costs 9 VALU issue slots per pair.  This kernel
+// evaluates every pair with the fused surrogate
+//        s = fma(dz, dz, fma(dy, dy, dx * dx))          (same float32 differences dx, dy, dz as the exact formula)
+// in 7 slots (3 v_sub, 1 v_mul, 2 v_fma, 1 v_min), and does NOT decide the nearest neighbour.  It only keeps, per
+// source point, the three smallest per-chunk minima of s (chunk = 64 consecutive targets).  Because s and the exact
+// d2 are both within 4 roundings of the real dx^2 + dy^2 + dz^2, |s - d2| <= 2^-21 * d2 (+ 2^-147 near underflow), so
+// the exact nearest neighbour lies in a chunk whose surrogate minimum is <= v1 * (1 + 2^-19) + 2^-140, v1 being the
+// smallest surrogate chunk minimum.  resolve_fused_kernel (icp_kernels.hip, exact arithmetic, checked for fused ops)
+// re-scans those one or two candidate chunks with the exact formula and picks the (d2, index)-lexicographic minimum;
+// if three or more chunks fall inside the band (exact ties spread over the cloud, e.g. lattices) the point is handed to
+// the exact scan (nn_scan_kernel) through the engine's overflow list.  Results are bit-identical to the exact path by
+// construction; tests run the whole parity suite in both modes.
+//
+// This file is the ONLY place where a fused float32 multiply-add may appear in the correspondence path, and it is
+// therefore excluded from `make check-isa`.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "icp_internal.h"
+
+namespace mi355 {
+
+namespace {
+
+__device__ __forceinline__ void transform_point(const float* __restrict__ m, float x, float y, float z, float& ox,
+                                                float& oy, float& oz) {
+  // the source transform stays exact (unfused): it defines the query point for both the filter and the exact test
+  float a, b;
+  a = __fmul_rn(m[0], x); b = __fmul_rn(m[1], y); a = __fadd_rn(a, b); b = __fmul_rn(m[2], z); a = __fadd_rn(a, b); ox = __fadd_rn(a, m[3]);
+  a = __fmul_rn(m[4], x); b = __fmul_rn(m[5], y); a = __fadd_rn(a, b); b = __fmul_rn(m[6], z); a = __fadd_rn(a, b); oy = __fadd_rn(a, m[7]);
+  a = __fmul_rn(m[8], x); b = __fmul_rn(m[9], y); a = __fadd_rn(a, b); b = __fmul_rn(m[10], z); a = __fadd_rn(a, b); oz = __fadd_rn(a, m[11]);
+}
+
+__device__ __forceinline__ float surrogate(float qx, float qy, float qz, float tx, float ty, float tz) {
+  const float dx = qx - tx, dy = qy - ty, dz = qz - tz;
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
+}  // namespace
+
+// grid / block / workgroup-to-work mapping exactly as nn_scan_kernel.  keys3: [3][n_split][key_stride] u64,
+// (surrogate bits << 32 | fused-chunk id), rank 0 = smallest.
+template <int kPointsPerLane>
+__global__ __launch_bounds__(kBlockThreads) void nn_scan_fused_kernel(const JobDesc* __restrict__ jobs,
+                                                                       const float* __restrict__ sx,
+                                                                       const float* __restrict__ sy,
+                                                                       const float* __restrict__ sz,
+                                                                       const float* __restrict__ tx,
+                                                                       const float* __restrict__ ty,
+                                                                       const float* __restrict__ tz,
+                                                                       unsigned long long* __restrict__ keys3,
+                                                                       uint32_t key_stride, uint32_t rank_stride) {
+  __shared__ float4 lds[2][3][kTile / 4];
+  const JobDesc& J = jobs[blockIdx.y];
+  const uint32_t n_split = J.n_split;
+  const uint32_t sb = blockIdx.x / n_split;
+  const uint32_t sp = blockIdx.x - sb * n_split;
+  if (sb >= J.scan_blocks) return;
+  constexpr uint32_t kScanSrcPerBlock = kBlockThreads * kPointsPerLane;
+  const uint32_t tile0 = sp * J.split_q + (sp < J.split_r ? sp : J.split_r);
+  const uint32_t tile1 = tile0 + J.split_q + (sp < J.split_r ? 1u : 0u);
+  const uint32_t tid = threadIdx.x;
+  float pose[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
+
+  float qx[kPointsPerLane], qy[kPointsPerLane], qz[kPointsPerLane];
+  float m1[kPointsPerLane], m2[kPointsPerLane], m3[kPointsPerLane];
+  uint32_t c1[kPointsPerLane], c2[kPointsPerLane], c3[kPointsPerLane];
+  const uint32_t src_base = J.src_off + sb * kScanSrcPerBlock + tid;
+#pragma unroll
+  for (int p = 0; p < kPointsPerLane; ++p) {
+    const uint32_t i = src_base + p * kBlockThreads;
+    transform_point(pose, sx[i], sy[i], sz[i], qx[p], qy[p], qz[p]);
+    m1[p] = m2[p] = m3[p] = __builtin_inff();
+    c1[p] = c2[p] = c3[p] = tile0 * kFusedChunksPerTile;
+  }
+  const float4* __restrict__ gx = reinterpret_cast<const float4*>(tx + J.tgt_off);
+  const float4* __restrict__ gy = reinterpret_cast<const float4*>(ty + J.tgt_off);
+  const float4* __restrict__ gz = reinterpret_cast<const float4*>(tz + J.tgt_off);
+  {
+    const uint32_t g = tile0 * (kTile / 4) + tid;
+    lds[0][0][tid] = gx[g];
+    lds[0][1][tid] = gy[g];
+    lds[0][2][tid] = gz[g];
+  }
+  __syncthreads();
+  uint32_t cur = 0;
+  for (uint32_t tile = tile0; tile < tile1; ++tile) {
+    const bool more = tile + 1 < tile1;
+    float4 rx, ry, rz;
+    if (more) {
+      const uint32_t g = (tile + 1) * (kTile / 4) + tid;
+      rx = gx[g];
+      ry = gy[g];
+      rz = gz[g];
+    }
+    const float4* __restrict__ LX = lds[cur][0];
+    const float4* __restrict__ LY = lds[cur][1];
+    const float4* __restrict__ LZ = lds[cur][2];
+    const uint32_t chunk_base = tile * kFusedChunksPerTile;
+    for (uint32_t c = 0; c < kFusedChunksPerTile; ++c) {
+      float cmin[kPointsPerLane];
+#pragma unroll
+      for (int p = 0; p < kPointsPerLane; ++p) cmin[p] = __builtin_inff();
+#pragma unroll
+      for (uint32_t g = 0; g < kFusedChunk / 4; ++g) {
+        const float4 X = LX[c * (kFusedChunk / 4) + g];
+        const float4 Y = LY[c * (kFusedChunk / 4) + g];
+        const float4 Z = LZ[c * (kFusedChunk / 4) + g];
+#pragma unroll
+        for (int p = 0; p < kPointsPerLane; ++p) {
+          const float s0 = surrogate(qx[p], qy[p], qz[p], X.x, Y.x, Z.x);
+          const float s1 = surrogate(qx[p], qy[p], qz[p], X.y, Y.y, Z.y);
+          const float s2 = surrogate(qx[p], qy[p], qz[p], X.z, Y.z, Z.z);
+          const float s3 = surrogate(qx[p], qy[p], qz[p], X.w, Y.w, Z.w);
+          cmin[p] = __builtin_fminf(__builtin_fminf(cmin[p], s0), s1);
+          cmin[p] = __builtin_fminf(__builtin_fminf(cmin[p], s2), s3);
+        }
+      }
+      const uint32_t chunk = chunk_base + c;
+#pragma unroll
+      for (int p = 0; p < kPointsPerLane; ++p) {  // sorted insert of (cmin, chunk) into the three smallest; strict <: earlier chunk first on ties
+        // everything through SSA scalars: selects between array ELEMENTS make hipcc select between their stack
+        // addresses instead (scratch traffic + branches)
+        const float cm = cmin[p], o1 = m1[p], o2 = m2[p], o3 = m3[p];
+        const uint32_t i1 = c1[p], i2 = c2[p], i3 = c3[p];
+        const bool l1 = cm < o1, l2 = cm < o2, l3 = cm < o3;
+        const float keep3 = l3 ? cm : o3, keep2 = l2 ? cm : o2;
+        const uint32_t keepi3 = l3 ? chunk : i3, keepi2 = l2 ? chunk : i2;
+        m3[p] = l2 ? o2 : keep3;
+        c3[p] = l2 ? i2 : keepi3;
+        m2[p] = l1 ? o1 : keep2;
+        c2[p] = l1 ? i1 : keepi2;
+        m1[p] = l1 ? cm : o1;
+        c1[p] = l1 ? chunk : i1;
+      }
+    }
+    if (more) {
+      lds[cur ^ 1][0][tid] = rx;
+      lds[cur ^ 1][1][tid] = ry;
+      lds[cur ^ 1][2][tid] = rz;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const size_t out = static_cast<size_t>(sp) * key_stride + J.out_off + sb * kScanSrcPerBlock + tid;
+#pragma unroll
+  for (int p = 0; p < kPointsPerLane; ++p) {
+    const size_t o = out + p * kBlockThreads;
+    keys3[o] = (static_cast<unsigned long long>(__float_as_uint(m1[p])) << 32) | c1[p];
+    keys3[rank_stride + o] = (static_cast<unsigned long long>(__float_as_uint(m2[p])) << 32) | c2[p];
+    keys3[2 * static_cast<size_t>(rank_stride) + o] = (static_cast<unsigned long long>(__float_as_uint(m3[p])) << 32) | c3[p];
+  }
+}
+
+void launch_nn_scan_fused(void* stream, int points_per_lane, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x,
+                          DevicePlanes src, DevicePlanes tgt, unsigned long long* keys3, uint32_t key_stride,
+                          uint32_t rank_stride) {
+  dim3 grid(max_blocks_x, static_cast<uint32_t>(n_jobs));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (points_per_lane) {
+    case 2:
+      hipLaunchKernelGGL(nn_scan_fused_kernel<2>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tgt.x,
+                         tgt.y, tgt.z, keys3, key_stride, rank_stride);
+      break;
+    case 4:
+      hipLaunchKernelGGL(nn_scan_fused_kernel<4>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tgt.x,
+                         tgt.y, tgt.z, keys3, key_stride, rank_stride);
+      break;
+    default:
+      hipLaunchKernelGGL(nn_scan_fused_kernel<8>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tgt.x,
+                         tgt.y, tgt.z, keys3, key_stride, rank_stride);
+      break;
+  }
+}
+
+}  // namespace mi355

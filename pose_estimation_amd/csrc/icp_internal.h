@@ -18,6 +18,8 @@ constexpr int kTile = 1024;                              // target points per LD
 constexpr int kChunk = 32;                               // granule at which the scan remembers "where the min fell"
 constexpr int kChunksPerTile = kTile / kChunk;
 constexpr float kTargetPad = 3.0e38f;                    // coordinate of padding targets: d2 overflows to +inf
+constexpr int kFusedChunk = 64;                          // granule of the fused-filter scan (icp_fused_kernels.hip)
+constexpr int kFusedChunksPerTile = kTile / kFusedChunk;
 
 // One alignment job as the kernels see it (read with scalar loads; 112 bytes).
 struct JobDesc {
@@ -82,6 +84,19 @@ struct DevicePlanes {
 };
 void launch_nn_scan(void* stream, int points_per_lane, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x,
                     DevicePlanes src, DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride);
+void launch_nn_scan_fused(void* stream, int points_per_lane, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x,
+                          DevicePlanes src, DevicePlanes tgt, unsigned long long* keys3, uint32_t key_stride,
+                          uint32_t rank_stride);
+void launch_resolve_fused(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
+                          DevicePlanes tgt, const unsigned long long* keys3, uint32_t key_stride, uint32_t rank_stride,
+                          int32_t* out_index, float* out_dist2, double* partials, uint32_t* overflow_list,
+                          uint32_t* overflow_count, uint32_t* error_flag);
+void launch_accumulate(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
+                       DevicePlanes tgt, const int32_t* index, const float* dist2, double* partials);
+void launch_gather_points(void* stream, DevicePlanes src, uint32_t src_off, const uint32_t* list, uint32_t n, float* out_planes,
+                          size_t out_stride, uint32_t n_padded);
+void launch_scatter_results(void* stream, const uint32_t* list, uint32_t n, const int32_t* idx_tmp, const float* d2_tmp,
+                            int32_t* out_index, float* out_dist2, uint32_t out_off);
 void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
                     DevicePlanes tgt, const unsigned long long* keys, uint32_t key_stride, int32_t* out_index,
                     float* out_dist2, double* partials, uint32_t* error_flag);

@@ -401,6 +401,155 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Exact half of the fused-filter path (icp_fused_kernels.hip explains the filter).  One lane per source point: take
+// the three smallest surrogate chunk minima over all splits, keep the chunks inside the error band of the smallest,
+// re-scan those (one or two 64-target chunks) with the EXACT unfused formula and pick the (d2, index)-lexicographic
+// minimum.  Three or more chunks in the band -> the point goes to the overflow list and is answered by the exact scan.
+__global__ __launch_bounds__(kBlockThreads) void resolve_fused_kernel(
+    const JobDesc* __restrict__ jobs, const float* __restrict__ sx, const float* __restrict__ sy,
+    const float* __restrict__ sz, const float* __restrict__ tx, const float* __restrict__ ty,
+    const float* __restrict__ tz, const unsigned long long* __restrict__ keys3, uint32_t key_stride,
+    uint32_t rank_stride, int32_t* __restrict__ out_index, float* __restrict__ out_dist2,
+    uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ overflow_count, uint32_t* __restrict__ error_flag) {
+  const JobDesc& J = jobs[blockIdx.y];
+  const uint32_t sb = blockIdx.x;
+  if (sb >= J.src_blocks) return;
+  float pose[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
+  const uint32_t n_split = J.n_split;
+#pragma unroll 1
+  for (int p = 0; p < kResolvePointsPerLane; ++p) {
+    const uint32_t local = sb * kSrcPerBlock + p * kBlockThreads + threadIdx.x;
+    if (local >= J.src_n) continue;
+    unsigned long long k1 = ~0ull, k2 = ~0ull, k3 = ~0ull;
+    for (uint32_t sp = 0; sp < n_split; ++sp) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const unsigned long long k = keys3[static_cast<size_t>(r) * rank_stride + static_cast<size_t>(sp) * key_stride + J.out_off + local];
+        const bool l1 = k < k1, l2 = k < k2, l3 = k < k3;
+        k3 = l2 ? k2 : (l3 ? k : k3);
+        k2 = l1 ? k1 : (l2 ? k : k2);
+        k1 = l1 ? k : k1;
+      }
+    }
+    // error band of the fused surrogate around its minimum (relative 2^-19 covers 2 x 4 roundings with margin,
+    // absolute 2^-140 covers gradual underflow); evaluated in double so the band itself is exact
+    const double v1 = static_cast<double>(__uint_as_float(static_cast<uint32_t>(k1 >> 32)));
+    const double band = v1 * (1.0 + 1.9073486328125e-06) + 7.1746481373430634e-43;
+    const bool in2 = static_cast<double>(__uint_as_float(static_cast<uint32_t>(k2 >> 32))) <= band;
+    const bool in3 = static_cast<double>(__uint_as_float(static_cast<uint32_t>(k3 >> 32))) <= band;
+    if (in3) {  // too many candidate chunks (or everything is +inf): let the exact scan answer
+      const uint32_t pos = atomicAdd(&overflow_count[blockIdx.y], 1u);
+      overflow_list[J.out_off + pos] = local;
+      continue;
+    }
+    const uint32_t i = J.src_off + local;
+    float qx, qy, qz;
+    transform_point(pose, sx[i], sy[i], sz[i], qx, qy, qz);
+    float best = __builtin_inff();
+    uint32_t best_j = 0xFFFFFFFFu;
+    const int n_cand = in2 ? 2 : 1;
+    for (int cnd = 0; cnd < n_cand; ++cnd) {
+      const uint32_t chunk = static_cast<uint32_t>(cnd == 0 ? k1 : k2);
+      const uint32_t tbase = J.tgt_off + chunk * kFusedChunk;
+      const float4* __restrict__ gx = reinterpret_cast<const float4*>(tx + tbase);
+      const float4* __restrict__ gy = reinterpret_cast<const float4*>(ty + tbase);
+      const float4* __restrict__ gz = reinterpret_cast<const float4*>(tz + tbase);
+#pragma unroll 4
+      for (int g = 0; g < kFusedChunk / 4; ++g) {
+        const float4 X = gx[g], Y = gy[g], Z = gz[g];
+        const float xs[4] = {X.x, X.y, X.z, X.w};
+        const float ys[4] = {Y.x, Y.y, Y.z, Y.w};
+        const float zs[4] = {Z.x, Z.y, Z.z, Z.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = dist2(qx, qy, qz, xs[e], ys[e], zs[e]);
+          const uint32_t j = chunk * kFusedChunk + static_cast<uint32_t>(g * 4 + e);
+          if (d < best || (d == best && j < best_j)) {
+            best = d;
+            best_j = j;
+          }
+        }
+      }
+    }
+    if (best_j == 0xFFFFFFFFu) {  // cannot happen for finite data (a finite surrogate minimum implies a finite exact d2 nearby)
+      atomicOr(error_flag, 1u);
+      best_j = 0;
+    }
+    out_index[J.out_off + local] = static_cast<int32_t>(best_j);
+    out_dist2[J.out_off + local] = best;
+  }
+}
+
+// N2 for the fused path: accumulation over ALL points after every index is known (fixed order: same bits every run)
+__global__ __launch_bounds__(kBlockThreads) void accumulate_kernel(const JobDesc* __restrict__ jobs,
+                                                                    const float* __restrict__ sx, const float* __restrict__ sy,
+                                                                    const float* __restrict__ sz, const float* __restrict__ tx,
+                                                                    const float* __restrict__ ty, const float* __restrict__ tz,
+                                                                    const int32_t* __restrict__ index,
+                                                                    const float* __restrict__ dist2,
+                                                                    double* __restrict__ partials) {
+  __shared__ double scratch[kBlockThreads / 64][MI355_ICP_NSUMS];
+  const JobDesc& J = jobs[blockIdx.y];
+  const uint32_t sb = blockIdx.x;
+  if (sb >= J.src_blocks) return;
+  const float max_d2 = J.max_d2;
+  double acc[MI355_ICP_NSUMS];
+#pragma unroll
+  for (int k = 0; k < MI355_ICP_NSUMS; ++k) acc[k] = 0.0;
+#pragma unroll 1
+  for (int p = 0; p < kResolvePointsPerLane; ++p) {
+    const uint32_t local = sb * kSrcPerBlock + p * kBlockThreads + threadIdx.x;
+    if (local < J.src_n) {
+      const float best = dist2[J.out_off + local];
+      if (best <= max_d2) {
+        const uint32_t i = J.src_off + local, j = J.tgt_off + static_cast<uint32_t>(index[J.out_off + local]);
+        const double a0 = sx[i], a1 = sy[i], a2 = sz[i], b0 = tx[j], b1 = ty[j], b2 = tz[j];
+        acc[0] += 1.0;
+        acc[1] += a0; acc[2] += a1; acc[3] += a2;
+        acc[4] += b0; acc[5] += b1; acc[6] += b2;
+        acc[7] += a0 * b0; acc[8] += a0 * b1; acc[9] += a0 * b2;
+        acc[10] += a1 * b0; acc[11] += a1 * b1; acc[12] += a1 * b2;
+        acc[13] += a2 * b0; acc[14] += a2 * b1; acc[15] += a2 * b2;
+        acc[16] += static_cast<double>(best);
+      }
+    }
+  }
+  const double r = block_sum<MI355_ICP_NSUMS>(acc, scratch);
+  if (threadIdx.x < MI355_ICP_NSUMS) partials[static_cast<size_t>(J.partial_off + sb) * MI355_ICP_NSUMS + threadIdx.x] = r;
+}
+
+// overflow handling: gather the listed source points into scratch planes / scatter their exact answers back
+__global__ __launch_bounds__(kBlockThreads) void gather_points_kernel(const float* __restrict__ sx, const float* __restrict__ sy,
+                                                                       const float* __restrict__ sz, uint32_t src_off,
+                                                                       const uint32_t* __restrict__ list, uint32_t n,
+                                                                       float* __restrict__ out, size_t out_stride,
+                                                                       uint32_t n_padded) {
+  const uint32_t k = blockIdx.x * kBlockThreads + threadIdx.x;
+  if (k >= n_padded) return;
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (k < n) {
+    const uint32_t i = src_off + list[k];
+    x = sx[i]; y = sy[i]; z = sz[i];
+  }
+  out[k] = x;
+  out[out_stride + k] = y;
+  out[2 * out_stride + k] = z;
+}
+
+__global__ __launch_bounds__(kBlockThreads) void scatter_results_kernel(const uint32_t* __restrict__ list, uint32_t n,
+                                                                         const int32_t* __restrict__ idx_tmp,
+                                                                         const float* __restrict__ d2_tmp,
+                                                                         int32_t* __restrict__ out_index,
+                                                                         float* __restrict__ out_dist2, uint32_t out_off) {
+  const uint32_t k = blockIdx.x * kBlockThreads + threadIdx.x;
+  if (k >= n) return;
+  out_index[out_off + list[k]] = idx_tmp[k];
+  out_dist2[out_off + list[k]] = d2_tmp[k];
+}
+
+// ---------------------------------------------------------------------------------------------
 // N2 final reduction: one workgroup per job sums that job's per-block partials in a fixed order
 // (thread t takes blocks t, t+256, ... ascending; then the block_sum tree), so a given cloud,
 // pose and slab always reduces to the same bits.
@@ -477,6 +626,38 @@ extern "C" int mi355_icp_diag_read(unsigned long long* out, size_t n_slots) {
   return hipMemcpy(out, buf, n_slots * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 #endif
+
+void launch_resolve_fused(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
+                          DevicePlanes tgt, const unsigned long long* keys3, uint32_t key_stride, uint32_t rank_stride,
+                          int32_t* out_index, float* out_dist2, double* partials, uint32_t* overflow_list,
+                          uint32_t* overflow_count, uint32_t* error_flag) {
+  (void)partials;
+  dim3 grid(max_src_blocks, static_cast<uint32_t>(n_jobs));
+  hipLaunchKernelGGL(resolve_fused_kernel, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x,
+                     src.y, src.z, tgt.x, tgt.y, tgt.z, keys3, key_stride, rank_stride, out_index, out_dist2, overflow_list,
+                     overflow_count, error_flag);
+}
+
+void launch_accumulate(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
+                       DevicePlanes tgt, const int32_t* index, const float* dist2, double* partials) {
+  dim3 grid(max_src_blocks, static_cast<uint32_t>(n_jobs));
+  hipLaunchKernelGGL(accumulate_kernel, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x, src.y,
+                     src.z, tgt.x, tgt.y, tgt.z, index, dist2, partials);
+}
+
+void launch_gather_points(void* stream, DevicePlanes src, uint32_t src_off, const uint32_t* list, uint32_t n, float* out_planes,
+                          size_t out_stride, uint32_t n_padded) {
+  if (!n_padded) return;
+  hipLaunchKernelGGL(gather_points_kernel, dim3((n_padded + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0,
+                     static_cast<hipStream_t>(stream), src.x, src.y, src.z, src_off, list, n, out_planes, out_stride, n_padded);
+}
+
+void launch_scatter_results(void* stream, const uint32_t* list, uint32_t n, const int32_t* idx_tmp, const float* d2_tmp,
+                            int32_t* out_index, float* out_dist2, uint32_t out_off) {
+  if (!n) return;
+  hipLaunchKernelGGL(scatter_results_kernel, dim3((n + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0,
+                     static_cast<hipStream_t>(stream), list, n, idx_tmp, d2_tmp, out_index, out_dist2, out_off);
+}
 
 void launch_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums) {
   hipLaunchKernelGGL(final_reduce_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0,

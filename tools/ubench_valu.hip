@@ -133,6 +133,46 @@ __global__ __launch_bounds__(256) void clock_probe(float* out, long long* ticks,
   if (threadIdx.x == 0) { ticks[2 * blockIdx.x] = t1 - t0; ticks[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// The same loop with the fused surrogate d2 = fma(dz,dz, fma(dy,dy, dx*dx)): 3 sub, 1 mul, 2 fma, 1 min per pair.
+__global__ __launch_bounds__(256) void clock_probe_fma(float* out, long long* ticks, int iters) {
+  float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  float b = 1.0001f + blockIdx.x * 1e-9f, c = 0.9999f;
+  long long t0 = clock64(), r0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+    asm volatile(REP16("v_sub_f32 %4, %0, %8\n v_sub_f32 %5, %1, %8\n v_sub_f32 %6, %2, %8\n"
+                       "v_mul_f32 %4, %4, %4\n v_fma_f32 %4, %5, %5, %4\n v_fma_f32 %4, %6, %6, %4\n"
+                       "v_sub_f32 %5, %0, %9\n v_sub_f32 %6, %1, %9\n v_sub_f32 %7, %2, %9\n"
+                       "v_mul_f32 %5, %5, %5\n v_fma_f32 %5, %6, %6, %5\n v_fma_f32 %5, %7, %7, %5\n"
+                       "v_min_f32 %3, %3, %4\n v_min_f32 %3, %3, %5\n")
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+  }
+  long long t1 = clock64(), r1 = wall_clock64();
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+  if (threadIdx.x == 0) { ticks[2 * blockIdx.x] = t1 - t0; ticks[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+static void run_clock_probe_fma(int n_cu, float* out, long long* cyc) {
+  const int grid = n_cu * 4, iters = 400000;
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    clock_probe_fma<<<grid, 256>>>(out, cyc, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<long long> h(grid * 2);
+    hipMemcpy(h.data(), cyc, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    double sc = 0, rt = 0;
+    for (int i = 0; i < grid; ++i) { sc += double(h[2 * i]); rt += double(h[2 * i + 1]); }
+    const double ghz = sc / rt * 0.1;
+    const double pairs = double(grid) * 256.0 * iters * 16.0 * 2.0;
+    printf("fused-surrogate probe (3 sub, 1 mul, 2 fma, 1 min per pair): %.1f ms, clock %.3f GHz, %.3e pairs/s, slots/pair = %.2f\n",
+           ms, ghz, pairs / (ms * 1e-3), ghz * 1e9 / 2.0 * n_cu * 4 * 64 / (pairs / (ms * 1e-3)));
+  }
+}
+
 static void run_clock_probe(int n_cu, float* out, long long* cyc) {
   const int grid = n_cu * 4, iters = 400000;  // 4 waves/SIMD, 18 instr x 16 x iters per wave
   for (int rep = 0; rep < 3; ++rep) {
@@ -191,8 +231,9 @@ int main() {
   hipMalloc(&out, sizeof(float) * n_cu * 8 * 256);
   hipMalloc(&cyc, sizeof(long long) * n_cu * 8 * 4);
   const int iters = 20000;
-  run_short_probe(n_cu, out, cyc);
+  if (!getenv("UBENCH_SKIP_SHORT")) run_short_probe(n_cu, out, cyc);
   run_clock_probe(n_cu, out, cyc);
+  run_clock_probe_fma(n_cu, out, cyc);
   if (getenv("UBENCH_CLOCK_ONLY")) return 0;
   for (int w : {1, 2, 4, 8}) {
     run<ADD>(w, n_cu, out, cyc, iters);
