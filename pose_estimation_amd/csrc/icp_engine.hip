@@ -125,7 +125,7 @@ struct mi355_icp_ctx {
 
   int scan_ppl = 0;                  // scan points-per-lane override (2, 4, 8); 0 = planner decides per call
   bool scan_sgpr = false;            // experimental scalar-load scan (MI355_ICP_SCAN_MODE=sgpr)
-  int scan_fused = -1;               // -1 auto (fused filter for >= 4e11 pairs per launch), 0 never (exact), 1 always
+  int scan_fused = -1;               // -1 auto (fused filter for >= 1e9 pairs per launch), 0 never (exact), 1 always
   // fused-filter path
   unsigned long long* keys3 = nullptr; size_t keys3_cap = 0;
   uint32_t* overflow_list = nullptr;   size_t overflow_list_cap = 0;
@@ -294,9 +294,11 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   // makes the coarsest workgroups; below ~4e11 pairs per launch the finer 2-point workgroups balance the 256 CUs
   // better and win (profiles/r01b_scan_ab_sizes.txt: 1M<->1M 135 vs 141 ms; 64x50k<->50k 24.3 vs 21.5 ms).
   plan.scan_ppl = c->scan_ppl ? c->scan_ppl : (total_pairs >= 4e11 ? 8 : 2);
-  // The fused filter (7 issue slots per pair instead of 9, exact results by construction: icp_fused_kernels.hip) pays
-  // once the scan dominates; small launches keep the all-exact scan, whose resolve re-scans half as many targets.
-  plan.fused = c->scan_fused < 0 ? total_pairs >= 4e11 : c->scan_fused == 1;
+  // The fused filter (7 issue slots per pair instead of 9, exact results by construction: icp_fused_kernels.hip) wins
+  // wherever the scan dominates the pass (profiles/r01h_scan_ab_fused_vs_exact.txt: +21 % at 1M<->1M, +17 % at
+  // 64x50k, +13 % at 100k<->100k); tiny launches keep the all-exact scan: its resolve re-scans half as many targets and
+  // it needs no overflow-count round trip to the host.
+  plan.fused = c->scan_fused < 0 ? total_pairs >= 1e9 : c->scan_fused == 1;
   const uint32_t scan_src = static_cast<uint32_t>(kBlockThreads * plan.scan_ppl);
   uint64_t total_src_blocks = 0;
   for (int k = 0; k < n_jobs; ++k)
