@@ -861,6 +861,7 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
     Plan plan;
     const int np = static_cast<int>(part.size());
     if ((st = make_plan_on(c, level_clouds(c->sources, level), level_clouds(c->targets, level), np, psid.data(), ptid.data(), 0.0f, plan)) != MI355_ICP_OK) return st;
+    plan.fused = false;  // run_ref_pass drives the all-exact scan kernels (and their key buffer)
     if ((st = ensure_buffers(c, plan, static_cast<size_t>(np))) != MI355_ICP_OK) return st;
     std::vector<uint32_t> owner_off(static_cast<size_t>(np));
     size_t owner_total = 0;
@@ -953,6 +954,7 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
   Plan plan;
   if ((st = make_plan_on(c, level_clouds(c->sources, level), level_clouds(c->targets, level), 1, &source_id, &target_id, 0.0f, plan)) != MI355_ICP_OK) return st;
   if (plan.jobs[0].tgt_n < 1) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: the level has no target points");
+  plan.fused = false;  // as in mi355_icp_align_reference
   if ((st = ensure_buffers(c, plan, 1)) != MI355_ICP_OK) return st;
   const size_t owner_total = level_clouds(c->targets, level)[target_id].padded;
   if ((st = ensure_ref_buffers(c, plan, 1, owner_total)) != MI355_ICP_OK) return st;
