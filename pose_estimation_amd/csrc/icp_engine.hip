@@ -441,6 +441,11 @@ int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, boo
     pairs += static_cast<double>(J.src_n) * static_cast<double>(J.tgt_n);
   }
   const DevicePlanes S = c->sources.view(), T = c->targets.view();
+  // never launch against a buffer the planner did not size for this launch shape (an out-of-bounds kernel can take the GPU down)
+  const size_t key_need = static_cast<size_t>(plan.max_split) * plan.out_total;
+  if (plan.out_total > c->out_cap || static_cast<size_t>(plan.partial_total) * MI355_ICP_NSUMS > c->partials_cap ||
+      (plan.fused ? (3 * key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : key_need > c->keys_cap))
+    return fail(c, MI355_ICP_ERR_INTERNAL, "work buffers are smaller than the plan (ensure_buffers not run for this plan)");
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (plan.fused) {
     const uint32_t rank_stride = plan.max_split * plan.out_total;
@@ -566,6 +571,11 @@ int run_ref_pass(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, fl
     pairs += static_cast<double>(J.src_n) * static_cast<double>(J.tgt_n);
   }
   const DevicePlanes S = level_view(c->sources, level), T = level_view(c->targets, level);
+  if (static_cast<size_t>(plan.max_split) * plan.out_total > c->keys_cap || plan.out_total > c->out_cap ||
+      plan.out_total > c->selected_cap || owner_total > c->owner_cap ||
+      static_cast<size_t>(plan.partial_total) * kRefSums > c->ref_partials_cap ||
+      static_cast<size_t>(plan.partial_total) * MI355_ICP_NSUMS > c->partials_cap)
+    return fail(c, MI355_ICP_ERR_INTERNAL, "work buffers are smaller than the plan (reference mode)");
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
