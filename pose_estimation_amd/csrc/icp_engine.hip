@@ -361,7 +361,7 @@ bool pose_to_f32(const double* pose16, float* out12) {
 
 // Fused path, overflow handling: points whose candidate chunks did not fit the filter's band are answered by the
 // all-exact scan on a gathered copy.  counts[] (host) holds the number of such points per active job.
-int run_overflow_fallback(mi355_icp_ctx* c, const Plan& plan, int n_active, const uint32_t* counts) {
+int run_overflow_fallback(mi355_icp_ctx* c, const Plan& plan, int n_active, const uint32_t* counts, DevicePlanes S, DevicePlanes T) {
   std::vector<int> who;
   size_t padded_total = 0, blocks_total = 0, scan_blocks_total = 0;
   for (int k = 0; k < n_active; ++k)
@@ -386,7 +386,6 @@ int run_overflow_fallback(mi355_icp_ctx* c, const Plan& plan, int n_active, cons
   const uint32_t want_split = static_cast<uint32_t>(std::max<size_t>(1, c->target_blocks / std::max<size_t>(scan_blocks_total, 1)));
   uint32_t max_split = 1, bx = 0, sbx = 0;
   size_t off = 0, prow = 0;
-  const DevicePlanes S = c->sources.view(), T = c->targets.view();
   for (size_t q = 0; q < who.size(); ++q) {
     const JobDesc& M = c->jobs_host[who[q]];
     const uint32_t n = counts[who[q]];
@@ -428,6 +427,25 @@ int run_overflow_fallback(mi355_icp_ctx* c, const Plan& plan, int n_active, cons
   return MI355_ICP_OK;
 }
 
+// Fused-filter path up to "index and dist2 of every point are final": filter scan -> exact resolve of the candidate
+// chunks -> (rarely) the all-exact scan for points whose candidates overflowed the band.  Records ev[1] after the scan.
+int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint32_t bx, uint32_t sbx, DevicePlanes S,
+                          DevicePlanes T, bool profile) {
+  const uint32_t rank_stride = plan.max_split * plan.out_total;
+  if (bx) launch_nn_scan_fused(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, T, c->keys3, plan.out_total, rank_stride);
+  if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->overflow_count, 0, static_cast<size_t>(n_active) * sizeof(uint32_t), c->stream));
+  if (sbx) launch_resolve_fused(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys3, plan.out_total, rank_stride, c->out_index,
+                                c->out_dist2, c->partials, c->overflow_list, c->overflow_count, c->error_flag);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(c->overflow_count_host, c->overflow_count, static_cast<size_t>(n_active) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  bool any = false;
+  for (int k = 0; k < n_active; ++k) any = any || c->overflow_count_host[k] != 0;
+  if (any) return run_overflow_fallback(c, plan, n_active, c->overflow_count_host, S, T);
+  return MI355_ICP_OK;
+}
+
 // Enqueues one correspondence pass for the first n_active descriptors of jobs_host and leaves
 // their sums in sums_host (synchronises the stream).  `local_only` skips the collective.
 int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only) {
@@ -448,21 +466,8 @@ int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, boo
     return fail(c, MI355_ICP_ERR_INTERNAL, "work buffers are smaller than the plan (ensure_buffers not run for this plan)");
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (plan.fused) {
-    const uint32_t rank_stride = plan.max_split * plan.out_total;
-    if (bx) launch_nn_scan_fused(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, T, c->keys3, plan.out_total, rank_stride);
-    if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->overflow_count, 0, static_cast<size_t>(n_active) * sizeof(uint32_t), c->stream));
-    if (sbx) launch_resolve_fused(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys3, plan.out_total, rank_stride, c->out_index,
-                                  c->out_dist2, c->partials, c->overflow_list, c->overflow_count, c->error_flag);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->overflow_count_host, c->overflow_count, static_cast<size_t>(n_active) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    bool any = false;
-    for (int k = 0; k < n_active; ++k) any = any || c->overflow_count_host[k] != 0;
-    if (any) {
-      const int st = run_overflow_fallback(c, plan, n_active, c->overflow_count_host);
-      if (st != MI355_ICP_OK) return st;
-    }
+    const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile);
+    if (fst != MI355_ICP_OK) return fst;
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if (sbx) launch_accumulate(c->stream, c->jobs_dev, n_active, sbx, S, T, c->out_index, c->out_dist2, c->partials);
   } else {
@@ -571,15 +576,21 @@ int run_ref_pass(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, fl
     pairs += static_cast<double>(J.src_n) * static_cast<double>(J.tgt_n);
   }
   const DevicePlanes S = level_view(c->sources, level), T = level_view(c->targets, level);
-  if (static_cast<size_t>(plan.max_split) * plan.out_total > c->keys_cap || plan.out_total > c->out_cap ||
-      plan.out_total > c->selected_cap || owner_total > c->owner_cap ||
+  const size_t ref_key_need = static_cast<size_t>(plan.max_split) * plan.out_total;
+  if ((plan.fused ? (3 * ref_key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : ref_key_need > c->keys_cap) ||
+      plan.out_total > c->out_cap || plan.out_total > c->selected_cap || owner_total > c->owner_cap ||
       static_cast<size_t>(plan.partial_total) * kRefSums > c->ref_partials_cap ||
       static_cast<size_t>(plan.partial_total) * MI355_ICP_NSUMS > c->partials_cap)
     return fail(c, MI355_ICP_ERR_INTERNAL, "work buffers are smaller than the plan (reference mode)");
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-  if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
-  if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-  if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
+  if (plan.fused) {
+    const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile);
+    if (fst != MI355_ICP_OK) return fst;
+  } else {
+    if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
+    if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
+  }
   if (rejection_scale > 0.0f) {
     launch_rejection_select(c->stream, c->jobs_dev, n_active, c->out_dist2, rejection_scale, c->thr_dev);
   } else {
@@ -871,7 +882,6 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
     Plan plan;
     const int np = static_cast<int>(part.size());
     if ((st = make_plan_on(c, level_clouds(c->sources, level), level_clouds(c->targets, level), np, psid.data(), ptid.data(), 0.0f, plan)) != MI355_ICP_OK) return st;
-    plan.fused = false;  // run_ref_pass drives the all-exact scan kernels (and their key buffer)
     if ((st = ensure_buffers(c, plan, static_cast<size_t>(np))) != MI355_ICP_OK) return st;
     std::vector<uint32_t> owner_off(static_cast<size_t>(np));
     size_t owner_total = 0;
@@ -964,7 +974,6 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
   Plan plan;
   if ((st = make_plan_on(c, level_clouds(c->sources, level), level_clouds(c->targets, level), 1, &source_id, &target_id, 0.0f, plan)) != MI355_ICP_OK) return st;
   if (plan.jobs[0].tgt_n < 1) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: the level has no target points");
-  plan.fused = false;  // as in mi355_icp_align_reference
   if ((st = ensure_buffers(c, plan, 1)) != MI355_ICP_OK) return st;
   const size_t owner_total = level_clouds(c->targets, level)[target_id].padded;
   if ((st = ensure_ref_buffers(c, plan, 1, owner_total)) != MI355_ICP_OK) return st;
