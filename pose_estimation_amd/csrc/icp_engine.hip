@@ -44,6 +44,13 @@ struct CloudSet {
   size_t stride = 0;
   std::vector<CloudEntry> clouds;
   std::vector<LevelPlanes> levels;  // levels[l - 1] = level l, built on demand by reference mode
+  // expansion-filter copy of the clouds (targets only, built on demand): Morton-sorted, centred per 1024-point tile.
+  // planes: tcx | tcy | tcz | tt | sox | soy | soz, each `stride` floats; perm: sorted position -> original index;
+  // table: per tile (centre x, y, z, r^2)
+  float* xt_planes = nullptr;
+  uint32_t* xt_perm = nullptr;
+  float* xt_table = nullptr;
+  bool xt_valid = false;
   DevicePlanes view() const { return DevicePlanes{planes, planes + stride, planes + 2 * stride}; }
   DevicePlanes normal_view() const { return DevicePlanes{normals, normals + stride, normals + 2 * stride}; }
 };
@@ -57,6 +64,7 @@ struct Plan {
   uint32_t max_src_blocks = 0; // resolve grid.x
   int scan_ppl = 8;            // source points per lane the scan kernel is launched with
   bool fused = false;          // fused-filter scan + exact resolve (large launches) instead of the all-exact scan
+  bool xfilter = false;        // expansion-filter scan on the sorted/centred target copy (largest launches); implies fused
 };
 
 uint32_t env_u32(const char* name, uint32_t dflt) {
@@ -125,7 +133,7 @@ struct mi355_icp_ctx {
 
   int scan_ppl = 0;                  // scan points-per-lane override (2, 4, 8); 0 = planner decides per call
   bool scan_sgpr = false;            // experimental scalar-load scan (MI355_ICP_SCAN_MODE=sgpr)
-  int scan_fused = -1;               // -1 auto (fused filter for >= 1e9 pairs per launch), 0 never (exact), 1 always
+  int scan_fused = -1;               // -1 auto (by pairs per launch: >= 1e9 fused, >= 4e11 expansion filter), 0 exact, 1 fused, 2 xfilter
   // fused-filter path
   unsigned long long* keys3 = nullptr; size_t keys3_cap = 0;
   uint32_t* overflow_list = nullptr;   size_t overflow_list_cap = 0;
@@ -203,6 +211,10 @@ int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* co
   for (auto& lv : set.levels)
     if (lv.planes) HIP_TRY(c, hipFree(lv.planes));
   set.levels.clear();
+  if (set.xt_planes) { HIP_TRY(c, hipFree(set.xt_planes)); set.xt_planes = nullptr; }
+  if (set.xt_perm) { HIP_TRY(c, hipFree(set.xt_perm)); set.xt_perm = nullptr; }
+  if (set.xt_table) { HIP_TRY(c, hipFree(set.xt_table)); set.xt_table = nullptr; }
+  set.xt_valid = false;
   set.clouds.clear();
   HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.planes), 3 * stride * sizeof(float)));
   HIP_TRY(c, hipMemcpy(set.planes, host.data(), 3 * stride * sizeof(float), hipMemcpyHostToDevice));
@@ -239,7 +251,7 @@ int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs) {
   }
   if ((st = grow(c, c->partials, c->partials_cap, static_cast<size_t>(std::max<uint32_t>(plan.partial_total, 1)) * MI355_ICP_NSUMS)) != MI355_ICP_OK) return st;
   if (plan.fused) {
-    if ((st = grow(c, c->keys3, c->keys3_cap, 3 * static_cast<size_t>(plan.max_split) * plan.out_total)) != MI355_ICP_OK) return st;
+    if ((st = grow(c, c->keys3, c->keys3_cap, (plan.xfilter ? 4 : 3) * static_cast<size_t>(plan.max_split) * plan.out_total)) != MI355_ICP_OK) return st;
     if ((st = grow(c, c->overflow_list, c->overflow_list_cap, std::max<size_t>(plan.out_total, 1))) != MI355_ICP_OK) return st;
     if (n_jobs > c->overflow_jobs_cap) {
       if (c->overflow_count) { HIP_TRY(c, hipFree(c->overflow_count)); c->overflow_count = nullptr; }
@@ -298,7 +310,11 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   // wherever the scan dominates the pass (profiles/r01h_scan_ab_fused_vs_exact.txt: +21 % at 1M<->1M, +17 % at
   // 64x50k, +13 % at 100k<->100k); tiny launches keep the all-exact scan: its resolve re-scans half as many targets and
   // it needs no overflow-count round trip to the host.
-  plan.fused = c->scan_fused < 0 ? total_pairs >= 1e9 : c->scan_fused == 1;
+  plan.fused = c->scan_fused < 0 ? total_pairs >= 1e9 : c->scan_fused >= 1;
+  // The expansion filter (4 issue slots per pair) needs a sorted, tile-centred copy of the targets (built once per
+  // upload, ~0.1 s of host time per million points), so it is kept for launches where one pass already costs that much.
+  plan.xfilter = c->scan_fused < 0 ? total_pairs >= 4e11 : c->scan_fused == 2;
+  if (plan.xfilter) plan.scan_ppl = c->scan_ppl ? c->scan_ppl : 4;
   const uint32_t scan_src = static_cast<uint32_t>(kBlockThreads * plan.scan_ppl);
   uint64_t total_src_blocks = 0;
   for (int k = 0; k < n_jobs; ++k)
@@ -427,16 +443,114 @@ int run_overflow_fallback(mi355_icp_ctx* c, const Plan& plan, int n_active, cons
   return MI355_ICP_OK;
 }
 
+// Builds the expansion-filter copy of every target cloud (see CloudSet::xt_*): Morton sort (21 bits per axis inside the
+// cloud's bounding box), then per 1024-point tile: centre = bounding-box centre, tc = fl(t - c), tt = fl(|tc|^2) from
+// double, r^2 = max |tc|^2 rounded up.  Padding slots: tc = 0, tt = +inf (never a minimum), sorted-original = kTargetPad.
+int ensure_xtarget(mi355_icp_ctx* c, CloudSet& set) {
+  if (set.xt_valid) return MI355_ICP_OK;
+  const size_t stride = set.stride;
+  std::vector<float> orig(3 * stride);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(orig.data(), set.planes, 3 * stride * sizeof(float), hipMemcpyDeviceToHost));
+  std::vector<float> xt(7 * stride, 0.0f);
+  std::vector<uint32_t> perm(stride, 0u);
+  std::vector<float> table(4 * (stride / kTile), 0.0f);
+  float *tcx = xt.data(), *tcy = tcx + stride, *tcz = tcy + stride, *tt = tcz + stride, *sox = tt + stride, *soy = sox + stride,
+        *soz = soy + stride;
+  const float *ox = orig.data(), *oy = ox + stride, *oz = oy + stride;
+  for (size_t i = 0; i < stride; ++i) {
+    tt[i] = std::numeric_limits<float>::infinity();
+    sox[i] = soy[i] = soz[i] = kTargetPad;
+  }
+  auto spread = [](uint64_t v) {  // 21 bits -> every third bit
+    v &= 0x1FFFFFull;
+    v = (v | v << 32) & 0x1F00000000FFFFull;
+    v = (v | v << 16) & 0x1F0000FF0000FFull;
+    v = (v | v << 8) & 0x100F00F00F00F00Full;
+    v = (v | v << 4) & 0x10C30C30C30C30C3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+  };
+  for (const CloudEntry& e : set.clouds) {
+    if (!e.n) continue;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t i = 0; i < e.n; ++i) {
+      const double p[3] = {ox[e.off + i], oy[e.off + i], oz[e.off + i]};
+      for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
+    }
+    double scale[3];
+    for (int k = 0; k < 3; ++k) scale[k] = hi[k] > lo[k] ? 2097151.0 / (hi[k] - lo[k]) : 0.0;
+    std::vector<std::pair<uint64_t, uint32_t>> order(e.n);
+    for (uint32_t i = 0; i < e.n; ++i) {
+      const uint64_t a = static_cast<uint64_t>((ox[e.off + i] - lo[0]) * scale[0]);
+      const uint64_t b = static_cast<uint64_t>((oy[e.off + i] - lo[1]) * scale[1]);
+      const uint64_t d = static_cast<uint64_t>((oz[e.off + i] - lo[2]) * scale[2]);
+      order[i] = {spread(a) | spread(b) << 1 | spread(d) << 2, i};
+    }
+    std::sort(order.begin(), order.end());
+    for (uint32_t t0 = 0; t0 < e.n; t0 += kTile) {
+      const uint32_t t1 = std::min<uint32_t>(t0 + kTile, e.n);
+      double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+      for (uint32_t s = t0; s < t1; ++s) {
+        const uint32_t i = e.off + order[s].second;
+        const double p[3] = {ox[i], oy[i], oz[i]};
+        for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], p[k]); bhi[k] = std::max(bhi[k], p[k]); }
+      }
+      const float cx = static_cast<float>(0.5 * (blo[0] + bhi[0])), cy = static_cast<float>(0.5 * (blo[1] + bhi[1])),
+                  cz = static_cast<float>(0.5 * (blo[2] + bhi[2]));
+      double r2 = 0.0;
+      for (uint32_t s = t0; s < t1; ++s) {
+        const uint32_t i = e.off + order[s].second, o = e.off + s;
+        const float dx = ox[i] - cx, dy = oy[i] - cy, dz = oz[i] - cz;  // float32 subtractions: the tc the kernel sees
+        tcx[o] = dx; tcy[o] = dy; tcz[o] = dz;
+        const double n2 = static_cast<double>(dx) * dx + static_cast<double>(dy) * dy + static_cast<double>(dz) * dz;
+        tt[o] = static_cast<float>(n2);
+        r2 = std::max(r2, n2);
+        sox[o] = ox[i]; soy[o] = oy[i]; soz[o] = oz[i];
+        perm[o] = order[s].second;
+      }
+      float* row = &table[4 * ((e.off + t0) / kTile)];
+      row[0] = cx; row[1] = cy; row[2] = cz;
+      row[3] = std::nextafter(static_cast<float>(r2), std::numeric_limits<float>::infinity());
+    }
+  }
+  if (!set.xt_planes) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.xt_planes), 7 * stride * sizeof(float)));
+  if (!set.xt_perm) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.xt_perm), stride * sizeof(uint32_t)));
+  if (!set.xt_table) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.xt_table), table.size() * sizeof(float)));
+  HIP_TRY(c, hipMemcpy(set.xt_planes, xt.data(), 7 * stride * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(set.xt_perm, perm.data(), stride * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(set.xt_table, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
+  set.xt_valid = true;
+  return MI355_ICP_OK;
+}
+
 // Fused-filter path up to "index and dist2 of every point are final": filter scan -> exact resolve of the candidate
 // chunks -> (rarely) the all-exact scan for points whose candidates overflowed the band.  Records ev[1] after the scan.
 int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint32_t bx, uint32_t sbx, DevicePlanes S,
                           DevicePlanes T, bool profile) {
   const uint32_t rank_stride = plan.max_split * plan.out_total;
-  if (bx) launch_nn_scan_fused(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, T, c->keys3, plan.out_total, rank_stride);
+  const CloudSet& X = c->targets;
+  const bool xf = plan.xfilter && X.xt_valid && T.x == X.planes;  // only for the level-0 targets the copy was built from
+  if (xf) {
+    const float* xp = X.xt_planes;
+    const size_t st = X.stride;
+    if (bx) launch_nn_scan_xfilter(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, xp, xp + st, xp + 2 * st, xp + 3 * st,
+                                   X.xt_table, c->keys3, plan.out_total, rank_stride);
+  } else if (bx) {
+    launch_nn_scan_fused(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, T, c->keys3, plan.out_total, rank_stride);
+  }
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
   HIP_TRY(c, hipMemsetAsync(c->overflow_count, 0, static_cast<size_t>(n_active) * sizeof(uint32_t), c->stream));
-  if (sbx) launch_resolve_fused(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys3, plan.out_total, rank_stride, c->out_index,
-                                c->out_dist2, c->partials, c->overflow_list, c->overflow_count, c->error_flag);
+  if (sbx && xf) {
+    const float* xp = X.xt_planes;
+    const size_t st = X.stride;
+    launch_resolve_xfilter(c->stream, c->jobs_dev, n_active, sbx, S, DevicePlanes{xp + 4 * st, xp + 5 * st, xp + 6 * st}, X.xt_perm,
+                           c->keys3, plan.out_total, rank_stride, c->out_index, c->out_dist2, c->overflow_list, c->overflow_count,
+                           c->error_flag);
+  } else if (sbx) {
+    launch_resolve_fused(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys3, plan.out_total, rank_stride, c->out_index,
+                         c->out_dist2, c->partials, c->overflow_list, c->overflow_count, c->error_flag);
+  }
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(c->overflow_count_host, c->overflow_count, static_cast<size_t>(n_active) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -462,7 +576,7 @@ int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, boo
   // never launch against a buffer the planner did not size for this launch shape (an out-of-bounds kernel can take the GPU down)
   const size_t key_need = static_cast<size_t>(plan.max_split) * plan.out_total;
   if (plan.out_total > c->out_cap || static_cast<size_t>(plan.partial_total) * MI355_ICP_NSUMS > c->partials_cap ||
-      (plan.fused ? (3 * key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : key_need > c->keys_cap))
+      (plan.fused ? ((plan.xfilter ? 4 : 3) * key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : key_need > c->keys_cap))
     return fail(c, MI355_ICP_ERR_INTERNAL, "work buffers are smaller than the plan (ensure_buffers not run for this plan)");
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (plan.fused) {
@@ -664,6 +778,7 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
     c->scan_sgpr = mode && std::string(mode) == "sgpr";
     if (mode && std::string(mode) == "exact") c->scan_fused = 0;
     if (mode && std::string(mode) == "fused") c->scan_fused = 1;
+    if (mode && std::string(mode) == "xfilter") c->scan_fused = 2;
     if (c->scan_sgpr) c->scan_fused = 0;
   }
   c->target_blocks = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks);
@@ -695,6 +810,9 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
     (void)hipFree(set->planes);
     (void)hipFree(set->normals);
     for (auto& lv : set->levels) (void)hipFree(lv.planes);
+    (void)hipFree(set->xt_planes);
+    (void)hipFree(set->xt_perm);
+    (void)hipFree(set->xt_table);
   }
   (void)hipFree(c->scene[0]);
   (void)hipFree(c->scene[1]);
@@ -763,6 +881,7 @@ int mi355_icp_align(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const i
   int st = make_plan(c, n_jobs, source_ids, target_ids, params->max_correspondence_distance, plan);
   if (st != MI355_ICP_OK) return st;
   if ((st = ensure_buffers(c, plan, static_cast<size_t>(n_jobs))) != MI355_ICP_OK) return st;
+  if (plan.xfilter && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
 
   struct JobState { double pose[16]; double prev_mse = 0.0; double residual = 0.0; int iters = 0; int status = MI355_ICP_OK; int converged = 0; };
@@ -820,6 +939,7 @@ int mi355_icp_correspond(mi355_icp_ctx* c, int n_jobs, const int* source_ids, co
   int st = make_plan(c, n_jobs, source_ids, target_ids, max_correspondence_distance, plan);
   if (st != MI355_ICP_OK) return st;
   if ((st = ensure_buffers(c, plan, static_cast<size_t>(n_jobs))) != MI355_ICP_OK) return st;
+  if (plan.xfilter && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
   for (int k = 0; k < n_jobs; ++k) {
     JobDesc J = plan.jobs[static_cast<size_t>(k)];
@@ -1181,6 +1301,10 @@ int mi355_icp_scene_commit_target(mi355_icp_ctx* c) {
   for (auto& lv : set.levels)
     if (lv.planes) HIP_TRY(c, hipFree(lv.planes));
   set.levels.clear();
+  if (set.xt_planes) { HIP_TRY(c, hipFree(set.xt_planes)); set.xt_planes = nullptr; }
+  if (set.xt_perm) { HIP_TRY(c, hipFree(set.xt_perm)); set.xt_perm = nullptr; }
+  if (set.xt_table) { HIP_TRY(c, hipFree(set.xt_table)); set.xt_table = nullptr; }
+  set.xt_valid = false;
   set.planes = planes;
   set.stride = padded;
   set.clouds.assign(1, CloudEntry{0, n, padded});

@@ -178,4 +178,182 @@ void launch_nn_scan_fused(void* stream, int points_per_lane, const JobDesc* jobs
   }
 }
 
+// =====================================================================================================================
+// Second filter, for the largest launches: the EXPANSION surrogate on spatially sorted, tile-centred targets.
+//
+//   s(q, t) = |qc|^2 + ( tt + q'.tc ),   qc = fl(q - c_tile), q' = -2 qc, tc = fl(t - c_tile), tt = fl(|tc|^2)
+//
+// costs 3 v_fma + 1 v_min per pair (4 issue slots instead of 7): tt and tc are precomputed per target at upload
+// (XTarget, icp_engine.hip: targets Morton-sorted so a 1024-target tile is spatially compact, then centred on the tile),
+// q' and |qc|^2 once per (source point, tile).  The price is cancellation: s is only good to an ABSOLUTE error
+//        |s - d2_exact| <= 30.4 u (|qc|^2 + r_tile^2),  u = 2^-24          (derivation: DESIGN.md 3.1)
+// which is why the tiles must be compact.  The kernel uses E = 2^-18 (|qc|^2 + r_tile^2) + 2^-140 (2x margin), and per
+// 64-target chunk forms a lower bound L = max(s_min - E, 0) and an upper bound U = s_min + E of the exact minimum in that
+// chunk.  It keeps the three smallest L (with chunk ids) and the smallest U per source point.  The exact nearest
+// neighbour (and every exact tie) lies in a chunk with L <= U_min; resolve_xfilter_kernel (exact arithmetic,
+// icp_kernels.hip) re-scans those one or two chunks with the contract formula on the ORIGINAL coordinates and picks the
+// (d2, original index)-lexicographic minimum; three or more candidate chunks, or a point whose bound is not finite, go
+// to the all-exact scan through the overflow list.  Bit-identical results by construction.
+template <int kPointsPerLane>
+__global__ __launch_bounds__(kBlockThreads) void nn_scan_xfilter_kernel(const JobDesc* __restrict__ jobs,
+                                                                         const float* __restrict__ sx,
+                                                                         const float* __restrict__ sy,
+                                                                         const float* __restrict__ sz,
+                                                                         const float* __restrict__ tcx,
+                                                                         const float* __restrict__ tcy,
+                                                                         const float* __restrict__ tcz,
+                                                                         const float* __restrict__ ttp,
+                                                                         const float4* __restrict__ tile_table,
+                                                                         unsigned long long* __restrict__ keys4,
+                                                                         uint32_t key_stride, uint32_t rank_stride) {
+  __shared__ float4 lds[2][4][kTile / 4];  // x, y, z (centred) and tt: 2 x 16 KiB
+  const JobDesc& J = jobs[blockIdx.y];
+  const uint32_t n_split = J.n_split;
+  const uint32_t sb = blockIdx.x / n_split;
+  const uint32_t sp = blockIdx.x - sb * n_split;
+  if (sb >= J.scan_blocks) return;
+  constexpr uint32_t kScanSrcPerBlock = kBlockThreads * kPointsPerLane;
+  const uint32_t tile0 = sp * J.split_q + (sp < J.split_r ? sp : J.split_r);
+  const uint32_t tile1 = tile0 + J.split_q + (sp < J.split_r ? 1u : 0u);
+  const uint32_t tid = threadIdx.x;
+  float pose[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
+  float qx[kPointsPerLane], qy[kPointsPerLane], qz[kPointsPerLane];
+  float l1[kPointsPerLane], l2[kPointsPerLane], l3[kPointsPerLane], umin[kPointsPerLane];
+  uint32_t c1[kPointsPerLane], c2[kPointsPerLane], c3[kPointsPerLane];
+  bool unsafe = false;
+  const uint32_t src_base = J.src_off + sb * kScanSrcPerBlock + tid;
+#pragma unroll
+  for (int p = 0; p < kPointsPerLane; ++p) {
+    const uint32_t i = src_base + p * kBlockThreads;
+    transform_point(pose, sx[i], sy[i], sz[i], qx[p], qy[p], qz[p]);
+    l1[p] = l2[p] = l3[p] = umin[p] = __builtin_inff();
+    c1[p] = c2[p] = c3[p] = tile0 * kFusedChunksPerTile;
+  }
+  const uint32_t tile_base = J.tgt_off / kTile;  // tgt_off is a multiple of kTile
+  const float4* __restrict__ gx = reinterpret_cast<const float4*>(tcx + J.tgt_off);
+  const float4* __restrict__ gy = reinterpret_cast<const float4*>(tcy + J.tgt_off);
+  const float4* __restrict__ gz = reinterpret_cast<const float4*>(tcz + J.tgt_off);
+  const float4* __restrict__ gw = reinterpret_cast<const float4*>(ttp + J.tgt_off);
+  {
+    const uint32_t g = tile0 * (kTile / 4) + tid;
+    lds[0][0][tid] = gx[g];
+    lds[0][1][tid] = gy[g];
+    lds[0][2][tid] = gz[g];
+    lds[0][3][tid] = gw[g];
+  }
+  __syncthreads();
+  uint32_t cur = 0;
+  for (uint32_t tile = tile0; tile < tile1; ++tile) {
+    const bool more = tile + 1 < tile1;
+    float4 rx, ry, rz, rw;
+    if (more) {
+      const uint32_t g = (tile + 1) * (kTile / 4) + tid;
+      rx = gx[g];
+      ry = gy[g];
+      rz = gz[g];
+      rw = gw[g];
+    }
+    const float4 tc = tile_table[tile_base + tile];  // centre xyz, r^2 (wave-uniform)
+    float ax[kPointsPerLane], ay[kPointsPerLane], az[kPointsPerLane], qq[kPointsPerLane], ee[kPointsPerLane];
+#pragma unroll
+    for (int p = 0; p < kPointsPerLane; ++p) {
+      const float cx = qx[p] - tc.x, cy = qy[p] - tc.y, cz = qz[p] - tc.z;
+      ax[p] = -2.0f * cx;
+      ay[p] = -2.0f * cy;
+      az[p] = -2.0f * cz;
+      qq[p] = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, cx * cx));
+      ee[p] = __builtin_fmaf(3.814697265625e-06f, qq[p] + tc.w, 7.1746481e-43f);  // 2^-18 (|qc|^2 + r^2) + 2^-140
+      unsafe = unsafe || !(ee[p] < 1.0e37f);                                           // inf / NaN bound: exact scan instead
+    }
+    const float4* __restrict__ LX = lds[cur][0];
+    const float4* __restrict__ LY = lds[cur][1];
+    const float4* __restrict__ LZ = lds[cur][2];
+    const float4* __restrict__ LW = lds[cur][3];
+    const uint32_t chunk_base = tile * kFusedChunksPerTile;
+    for (uint32_t c = 0; c < kFusedChunksPerTile; ++c) {
+      float cmin[kPointsPerLane];
+#pragma unroll
+      for (int p = 0; p < kPointsPerLane; ++p) cmin[p] = __builtin_inff();
+#pragma unroll
+      for (uint32_t g = 0; g < kFusedChunk / 4; ++g) {
+        const float4 X = LX[c * (kFusedChunk / 4) + g];
+        const float4 Y = LY[c * (kFusedChunk / 4) + g];
+        const float4 Z = LZ[c * (kFusedChunk / 4) + g];
+        const float4 W = LW[c * (kFusedChunk / 4) + g];
+#pragma unroll
+        for (int p = 0; p < kPointsPerLane; ++p) {
+          const float m0 = __builtin_fmaf(az[p], Z.x, __builtin_fmaf(ay[p], Y.x, __builtin_fmaf(ax[p], X.x, W.x)));
+          const float m1 = __builtin_fmaf(az[p], Z.y, __builtin_fmaf(ay[p], Y.y, __builtin_fmaf(ax[p], X.y, W.y)));
+          const float m2 = __builtin_fmaf(az[p], Z.z, __builtin_fmaf(ay[p], Y.z, __builtin_fmaf(ax[p], X.z, W.z)));
+          const float m3 = __builtin_fmaf(az[p], Z.w, __builtin_fmaf(ay[p], Y.w, __builtin_fmaf(ax[p], X.w, W.w)));
+          cmin[p] = __builtin_fminf(__builtin_fminf(cmin[p], m0), m1);
+          cmin[p] = __builtin_fminf(__builtin_fminf(cmin[p], m2), m3);
+        }
+      }
+      const uint32_t chunk = chunk_base + c;
+#pragma unroll
+      for (int p = 0; p < kPointsPerLane; ++p) {
+        const float s = cmin[p] + qq[p];
+        const float lo = __builtin_fmaxf(s - ee[p], 0.0f), hi = s + ee[p];
+        umin[p] = __builtin_fminf(umin[p], hi);
+        const float o1 = l1[p], o2 = l2[p], o3 = l3[p];
+        const uint32_t i1 = c1[p], i2 = c2[p], i3 = c3[p];
+        const bool b1 = lo < o1, b2 = lo < o2, b3 = lo < o3;
+        const float keep3 = b3 ? lo : o3, keep2 = b2 ? lo : o2;
+        const uint32_t keepi3 = b3 ? chunk : i3, keepi2 = b2 ? chunk : i2;
+        l3[p] = b2 ? o2 : keep3;
+        c3[p] = b2 ? i2 : keepi3;
+        l2[p] = b1 ? o1 : keep2;
+        c2[p] = b1 ? i1 : keepi2;
+        l1[p] = b1 ? lo : o1;
+        c1[p] = b1 ? chunk : i1;
+      }
+    }
+    if (more) {
+      lds[cur ^ 1][0][tid] = rx;
+      lds[cur ^ 1][1][tid] = ry;
+      lds[cur ^ 1][2][tid] = rz;
+      lds[cur ^ 1][3][tid] = rw;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const size_t out = static_cast<size_t>(sp) * key_stride + J.out_off + sb * kScanSrcPerBlock + tid;
+#pragma unroll
+  for (int p = 0; p < kPointsPerLane; ++p) {
+    const size_t o = out + p * kBlockThreads;
+    // an unsafe lane publishes "everything is a candidate": L = 0 three times, U = +inf -> overflow -> exact scan
+    const float w1 = unsafe ? 0.0f : l1[p], w2 = unsafe ? 0.0f : l2[p], w3 = unsafe ? 0.0f : l3[p];
+    const float wu = unsafe ? __builtin_inff() : umin[p];
+    keys4[o] = (static_cast<unsigned long long>(__float_as_uint(w1)) << 32) | c1[p];
+    keys4[rank_stride + o] = (static_cast<unsigned long long>(__float_as_uint(w2)) << 32) | c2[p];
+    keys4[2 * static_cast<size_t>(rank_stride) + o] = (static_cast<unsigned long long>(__float_as_uint(w3)) << 32) | c3[p];
+    keys4[3 * static_cast<size_t>(rank_stride) + o] = static_cast<unsigned long long>(__float_as_uint(wu)) << 32;
+  }
+}
+
+void launch_nn_scan_xfilter(void* stream, int points_per_lane, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x,
+                            DevicePlanes src, const float* tcx, const float* tcy, const float* tcz, const float* tt,
+                            const void* tile_table, unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride) {
+  dim3 grid(max_blocks_x, static_cast<uint32_t>(n_jobs));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float4* table = static_cast<const float4*>(tile_table);
+  switch (points_per_lane) {
+    case 2:
+      hipLaunchKernelGGL(nn_scan_xfilter_kernel<2>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tcx, tcy,
+                         tcz, tt, table, keys4, key_stride, rank_stride);
+      break;
+    case 8:
+      hipLaunchKernelGGL(nn_scan_xfilter_kernel<8>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tcx, tcy,
+                         tcz, tt, table, keys4, key_stride, rank_stride);
+      break;
+    default:
+      hipLaunchKernelGGL(nn_scan_xfilter_kernel<4>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tcx, tcy,
+                         tcz, tt, table, keys4, key_stride, rank_stride);
+      break;
+  }
+}
+
 }  // namespace mi355

@@ -91,6 +91,13 @@ void launch_resolve_fused(void* stream, const JobDesc* jobs_dev, int n_jobs, uin
                           DevicePlanes tgt, const unsigned long long* keys3, uint32_t key_stride, uint32_t rank_stride,
                           int32_t* out_index, float* out_dist2, double* partials, uint32_t* overflow_list,
                           uint32_t* overflow_count, uint32_t* error_flag);
+void launch_nn_scan_xfilter(void* stream, int points_per_lane, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x,
+                            DevicePlanes src, const float* tcx, const float* tcy, const float* tcz, const float* tt,
+                            const void* tile_table, unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride);
+void launch_resolve_xfilter(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
+                            DevicePlanes sorted_original, const uint32_t* perm, const unsigned long long* keys4,
+                            uint32_t key_stride, uint32_t rank_stride, int32_t* out_index, float* out_dist2,
+                            uint32_t* overflow_list, uint32_t* overflow_count, uint32_t* error_flag);
 void launch_accumulate(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
                        DevicePlanes tgt, const int32_t* index, const float* dist2, double* partials);
 void launch_gather_points(void* stream, DevicePlanes src, uint32_t src_off, const uint32_t* list, uint32_t n, float* out_planes,

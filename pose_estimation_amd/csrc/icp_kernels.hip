@@ -482,6 +482,88 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_fused_kernel(
   }
 }
 
+// Exact half of the expansion-filter path (nn_scan_xfilter_kernel).  keys4: three smallest lower bounds L (with chunk id)
+// and the smallest upper bound U per split; candidates are the chunks with L <= U_min.  The re-scan reads the SORTED
+// copy of the original coordinates (so, soy, soz: sorted order, uncentred) and maps positions back through perm; ties
+// are resolved on the ORIGINAL index, which is what the oracle's lowest-index rule refers to.
+__global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
+    const JobDesc* __restrict__ jobs, const float* __restrict__ sx, const float* __restrict__ sy,
+    const float* __restrict__ sz, const float* __restrict__ sox, const float* __restrict__ soy,
+    const float* __restrict__ soz, const uint32_t* __restrict__ perm, const unsigned long long* __restrict__ keys4,
+    uint32_t key_stride, uint32_t rank_stride, int32_t* __restrict__ out_index, float* __restrict__ out_dist2,
+    uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ overflow_count, uint32_t* __restrict__ error_flag) {
+  const JobDesc& J = jobs[blockIdx.y];
+  const uint32_t sb = blockIdx.x;
+  if (sb >= J.src_blocks) return;
+  float pose[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
+  const uint32_t n_split = J.n_split;
+#pragma unroll 1
+  for (int p = 0; p < kResolvePointsPerLane; ++p) {
+    const uint32_t local = sb * kSrcPerBlock + p * kBlockThreads + threadIdx.x;
+    if (local >= J.src_n) continue;
+    unsigned long long k1 = ~0ull, k2 = ~0ull, k3 = ~0ull;
+    float umin = __builtin_inff();
+    for (uint32_t sp = 0; sp < n_split; ++sp) {
+      const size_t base = static_cast<size_t>(sp) * key_stride + J.out_off + local;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const unsigned long long k = keys4[static_cast<size_t>(r) * rank_stride + base];
+        const bool l1 = k < k1, l2 = k < k2, l3 = k < k3;
+        k3 = l2 ? k2 : (l3 ? k : k3);
+        k2 = l1 ? k1 : (l2 ? k : k2);
+        k1 = l1 ? k : k1;
+      }
+      umin = __builtin_fminf(umin, __uint_as_float(static_cast<uint32_t>(keys4[3 * static_cast<size_t>(rank_stride) + base] >> 32)));
+    }
+    const bool in2 = __uint_as_float(static_cast<uint32_t>(k2 >> 32)) <= umin;
+    const bool in3 = __uint_as_float(static_cast<uint32_t>(k3 >> 32)) <= umin;
+    if (in3 || !(umin < __builtin_inff())) {  // too many candidate chunks, or no finite bound: the exact scan answers
+      const uint32_t pos = atomicAdd(&overflow_count[blockIdx.y], 1u);
+      overflow_list[J.out_off + pos] = local;
+      continue;
+    }
+    const uint32_t i = J.src_off + local;
+    float qx, qy, qz;
+    transform_point(pose, sx[i], sy[i], sz[i], qx, qy, qz);
+    float best = __builtin_inff();
+    uint32_t best_j = 0xFFFFFFFFu;
+    const int n_cand = in2 ? 2 : 1;
+    for (int cnd = 0; cnd < n_cand; ++cnd) {
+      const uint32_t chunk = static_cast<uint32_t>(cnd == 0 ? k1 : k2);
+      const uint32_t tbase = J.tgt_off + chunk * kFusedChunk;
+      const float4* __restrict__ gx = reinterpret_cast<const float4*>(sox + tbase);
+      const float4* __restrict__ gy = reinterpret_cast<const float4*>(soy + tbase);
+      const float4* __restrict__ gz = reinterpret_cast<const float4*>(soz + tbase);
+      const uint4* __restrict__ gp = reinterpret_cast<const uint4*>(perm + tbase);
+#pragma unroll 4
+      for (int g = 0; g < kFusedChunk / 4; ++g) {
+        const float4 X = gx[g], Y = gy[g], Z = gz[g];
+        const uint4 Pm = gp[g];
+        const float xs[4] = {X.x, X.y, X.z, X.w};
+        const float ys[4] = {Y.x, Y.y, Y.z, Y.w};
+        const float zs[4] = {Z.x, Z.y, Z.z, Z.w};
+        const uint32_t js[4] = {Pm.x, Pm.y, Pm.z, Pm.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = dist2(qx, qy, qz, xs[e], ys[e], zs[e]);
+          if (d < best || (d == best && js[e] < best_j)) {
+            best = d;
+            best_j = js[e];
+          }
+        }
+      }
+    }
+    if (best_j == 0xFFFFFFFFu) {
+      atomicOr(error_flag, 1u);
+      best_j = 0;
+    }
+    out_index[J.out_off + local] = static_cast<int32_t>(best_j);
+    out_dist2[J.out_off + local] = best;
+  }
+}
+
 // N2 for the fused path: accumulation over ALL points after every index is known (fixed order: same bits every run)
 __global__ __launch_bounds__(kBlockThreads) void accumulate_kernel(const JobDesc* __restrict__ jobs,
                                                                     const float* __restrict__ sx, const float* __restrict__ sy,
@@ -636,6 +718,16 @@ void launch_resolve_fused(void* stream, const JobDesc* jobs_dev, int n_jobs, uin
   hipLaunchKernelGGL(resolve_fused_kernel, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x,
                      src.y, src.z, tgt.x, tgt.y, tgt.z, keys3, key_stride, rank_stride, out_index, out_dist2, overflow_list,
                      overflow_count, error_flag);
+}
+
+void launch_resolve_xfilter(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
+                            DevicePlanes sorted_original, const uint32_t* perm, const unsigned long long* keys4,
+                            uint32_t key_stride, uint32_t rank_stride, int32_t* out_index, float* out_dist2,
+                            uint32_t* overflow_list, uint32_t* overflow_count, uint32_t* error_flag) {
+  dim3 grid(max_src_blocks, static_cast<uint32_t>(n_jobs));
+  hipLaunchKernelGGL(resolve_xfilter_kernel, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x,
+                     src.y, src.z, sorted_original.x, sorted_original.y, sorted_original.z, perm, keys4, key_stride, rank_stride,
+                     out_index, out_dist2, overflow_list, overflow_count, error_flag);
 }
 
 void launch_accumulate(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,

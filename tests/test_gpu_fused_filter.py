@@ -1,6 +1,8 @@
-"""The fused-filter scan (icp_fused_kernels.hip) must give bit-identical results to the all-exact path and the oracle:
-forced on for every size here (the planner only picks it above 4e11 pairs), including data built to stress its error
-band - near-ties spread over many chunks (overflow -> exact fallback), two-chunk near-ties, exact duplicates, lattices."""
+"""The filter scans (icp_fused_kernels.hip: the fused surrogate, and the expansion surrogate on the sorted/centred target
+copy) must give bit-identical results to the all-exact path and the oracle: each is forced on for every size here (the
+planner only picks them above 1e9 / 4e11 pairs), including data built to stress their error bands - near-ties spread
+over many chunks (overflow -> exact fallback), two-chunk near-ties, exact duplicates, lattices, clouds far from the
+origin (cancellation), subnormal and overflowing distances."""
 import os
 
 import numpy as np
@@ -12,11 +14,11 @@ import synth_twin as st
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def fused():
+@pytest.fixture(scope="module", params=["fused", "xfilter"])
+def fused(request):
     import pose_estimation_amd as pa
     old = os.environ.get("MI355_ICP_SCAN_MODE")
-    os.environ["MI355_ICP_SCAN_MODE"] = "fused"
+    os.environ["MI355_ICP_SCAN_MODE"] = request.param
     eng = pa.IcpEngine(0)
     if old is None:
         os.environ.pop("MI355_ICP_SCAN_MODE")
@@ -94,6 +96,21 @@ def test_lattice_ties_denormals_and_overflowing_distances(fused):
         idx, d2, _ = fused.correspond(np.eye(4)[None])
         oi, od = ora.nn_brute(q, cloud, nthreads=ora.max_threads())
         assert np.array_equal(d2.view(np.uint32), od.view(np.uint32)) and np.array_equal(idx, oi)
+
+
+def test_far_from_the_origin_and_anisotropic_clouds(fused):
+    """Cancellation stress for the expansion filter: the same surface shifted 50 units away, squashed flat, and a scene
+    made of two distant clusters (large tiles in Morton order)."""
+    src, tgt, gt = st.make_pair(st.synth_cloud_np, 6000, 9000)
+    shift = np.float32([50.0, -30.0, 20.0])
+    same_as_oracle(fused, (src + shift).astype(np.float32), (tgt + shift).astype(np.float32), np.eye(4), kd=False)
+    flat = np.float32([1.0, 1.0, 1e-3])
+    same_as_oracle(fused, (src * flat).astype(np.float32), (tgt * flat).astype(np.float32), np.eye(4), kd=False)
+    two = np.concatenate([tgt, tgt + np.float32([1000.0, 0, 0])]).astype(np.float32)
+    two = two[np.random.default_rng(3).permutation(len(two))]
+    same_as_oracle(fused, np.concatenate([src, src + np.float32([1000.0, 0, 0])]).astype(np.float32), two, np.eye(4), kd=False)
+    P = st.rigid_transform(25.0, (0.3, 1, -0.2), (40.0, -10.0, 5.0))      # a pose that throws the source far off the target
+    same_as_oracle(fused, src, tgt, P, kd=False)
 
 
 def test_fused_align_golden_and_batched(fused):
