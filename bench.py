@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (vector)" (= f32 MFMA dense peak)
 HBM_PEAK_GBS = 8000.0             # same guide, HBM3E spec
 FLOP_PER_PAIR = 8                 # 3 sub + 3 mul + 2 add (SURVEY.md 8d FLOP model; the min is not counted)
-SCAN_KERNEL = "nn_scan_fused_kernel (7 issue slots per pair) + exact resolve"
+SCAN_KERNEL = "nn_scan_xfilter_kernel (expansion filter, 4 issue slots per pair) + exact resolve"
 
 
 def parse():
@@ -175,10 +175,12 @@ def main():
                 "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_note,
                 "algorithmic_flop_per_launch": FLOP_PER_PAIR * pairs_launch,
                 "avg_launch_ms": scan_ms, "launches": int(prof.nn_scan_launches),
-                "note": "FP32 vector ALU bound. The dominant kernel evaluates every pair with a fused surrogate (3 sub, 1 mul, "
-                        "2 fma, 1 min = 7 issue slots per 8 FLOP: attainable ceiling 8/14 = 57% of the FMA-counted 157.3 TFLOP/s "
-                        "peak); the exact unfused formula (9 slots) then decides inside the one or two candidate chunks, so "
-                        "indices and distances stay bit-identical to the oracle; DESIGN.md 3.1",
+                "note": "FP32 vector ALU bound. FLOP are counted by the SURVEY 8d model (8 per evaluated pair). The dominant "
+                        "kernel evaluates every pair with the expansion surrogate |qc|^2 + |tc|^2 - 2 qc.tc on tile-centred "
+                        "coordinates (3 fma + 1 min = 4 issue slots, i.e. 6 executed FLOP per pair: attainable 16/8 model-FLOP per "
+                        "slot-pair = 100% of 157.3 by this count); the exact unfused formula (9 slots) then decides inside the one "
+                        "or two candidate chunks, so indices and distances stay bit-identical to the oracle; DESIGN.md 3.1",
+                "executed_flop_per_pair": 6,
             },
             "roofline_hbm": {
                 "bound": "hbm", "kernel": SCAN_KERNEL, "achieved": alg_bytes / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,

@@ -90,6 +90,7 @@ typedef struct mi355_icp_profile {
   double   knn_scan_ms;      /* scene normals: k-NN scan kernel */
   double   normals_ms;       /* scene normals: merge + PCA kernel */
   uint64_t normals_launches;
+  uint64_t overflow_points;  /* filter scans: source points handed to the all-exact scan (>= 3 candidate chunks) */
   double   scene_filter_ms;  /* scene compaction kernel */
   uint64_t scene_filter_launches;
   uint64_t scene_points_in;  /* points read / written by those launches */

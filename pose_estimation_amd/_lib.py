@@ -72,6 +72,7 @@ class Profile(C.Structure):
         ("knn_scan_ms", C.c_double),
         ("normals_ms", C.c_double),
         ("normals_launches", C.c_uint64),
+        ("overflow_points", C.c_uint64),
         ("scene_filter_ms", C.c_double),
         ("scene_filter_launches", C.c_uint64),
         ("scene_points_in", C.c_uint64),

@@ -438,6 +438,7 @@ int run_overflow_fallback(mi355_icp_ctx* c, const Plan& plan, int n_active, cons
     launch_scatter_results(c->stream, c->overflow_list + M.out_off, J.src_n, c->fb_index + J.out_off, c->fb_dist2 + J.out_off,
                            c->out_index, c->out_dist2, M.out_off);
     c->overflow_points_total += J.src_n;
+    c->prof.overflow_points += J.src_n;
   }
   HIP_TRY(c, hipGetLastError());
   return MI355_ICP_OK;

@@ -42,6 +42,7 @@ def main():
     p = pa.default_params(max_iterations=1, flags=pa._lib.FLAG_PROFILE)
     times = [[] for _ in engines]
     other = [[] for _ in engines]
+    over = [0 for _ in engines]
     ref = None
     for r in range(a.rounds + 1):
         for k, e in enumerate(engines):
@@ -55,11 +56,12 @@ def main():
                 pr = e.profile()
                 times[k].append(pr.nn_scan_ms)
                 other[k].append(pr.resolve_ms + pr.reduce_ms)
+                over[k] = pr.overflow_points
     print(f"# {a.jobs} job(s) x {a.n} source x {nt} target")
-    for v, t, o in zip(a.variants, times, other):
+    for v, t, o, ov in zip(a.variants, times, other, over):
         med = statistics.median(t)
         print(f"{v:44s} scan median {med:9.3f} ms  min {min(t):9.3f}  -> {a.jobs * a.n * nt / med / 1e9:8.3f} Tpairs/s"
-              f"  resolve+reduce {statistics.median(o):7.3f} ms  ({len(t)} rounds)")
+              f"  resolve+reduce {statistics.median(o):7.3f} ms  overflow points/pass {ov}  ({len(t)} rounds)")
 
 
 if __name__ == "__main__":
