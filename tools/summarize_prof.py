@@ -41,7 +41,7 @@ for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
             else:
                 write = sum(vals) / len(vals)
 if fetch is not None and write is not None:
-    json.dump({"tag": tag, "kernel": "nn_scan_fused_kernel (the scan bench.py's default workload launches)", "workload": "bench.py default (1048576x1048576, 1 GPU)",
+    json.dump({"tag": tag, "kernel": "the filter scan bench.py's default workload launches (nn_scan_xfilter_kernel)", "workload": "bench.py default (1048576x1048576, 1 GPU)",
                "fetch_size_kib_per_launch": fetch, "write_size_kib_per_launch": write,
                "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"},
