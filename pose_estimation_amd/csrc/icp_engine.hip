@@ -65,6 +65,7 @@ struct Plan {
   int scan_ppl = 8;            // source points per lane the scan kernel is launched with
   bool fused = false;          // fused-filter scan + exact resolve (large launches) instead of the all-exact scan
   bool xfilter = false;        // expansion-filter scan on the sorted/centred target copy (largest launches); implies fused
+  int xkind = 0;               // 0 VALU kernel, 1 MFMA kernel, 2 both side by side
 };
 
 uint32_t env_u32(const char* name, uint32_t dflt) {
@@ -133,6 +134,9 @@ struct mi355_icp_ctx {
 
   int scan_ppl = 0;                  // scan points-per-lane override (2, 4, 8); 0 = planner decides per call
   bool scan_sgpr = false;            // experimental scalar-load scan (MI355_ICP_SCAN_MODE=sgpr)
+  uint32_t mfma_share_pct = 65;      // hybrid: per cent of the scan workgroups that run on the matrix cores
+  hipStream_t stream2 = nullptr;     // hybrid: the MFMA workgroups are launched here, beside the VALU ones
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int scan_fused = -1;               // -1 auto (by pairs per launch: >= 1e9 fused, >= 4e11 expansion filter), 0 exact, 1 fused, 2 xfilter
   // fused-filter path
   unsigned long long* keys3 = nullptr; size_t keys3_cap = 0;
@@ -313,8 +317,10 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   plan.fused = c->scan_fused < 0 ? total_pairs >= 1e9 : c->scan_fused >= 1;
   // The expansion filter (4 issue slots per pair) needs a sorted, tile-centred copy of the targets (built once per
   // upload, ~0.1 s of host time per million points), so it is kept for launches where one pass already costs that much.
-  plan.xfilter = c->scan_fused < 0 ? total_pairs >= 4e11 : c->scan_fused == 2;
+  plan.xfilter = c->scan_fused < 0 ? total_pairs >= 4e11 : c->scan_fused >= 2;
+  plan.xkind = c->scan_fused >= 2 ? c->scan_fused - 2 : 0;
   if (plan.xfilter) plan.scan_ppl = c->scan_ppl ? c->scan_ppl : 4;
+  if (plan.xfilter && plan.xkind && plan.scan_ppl != 2) plan.scan_ppl = 4;  // the MFMA kernel spans 128 * {4, 8} points
   const uint32_t scan_src = static_cast<uint32_t>(kBlockThreads * plan.scan_ppl);
   uint64_t total_src_blocks = 0;
   for (int k = 0; k < n_jobs; ++k)
@@ -535,8 +541,31 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
   if (xf) {
     const float* xp = X.xt_planes;
     const size_t st = X.stride;
-    if (bx) launch_nn_scan_xfilter(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, xp, xp + st, xp + 2 * st, xp + 3 * st,
-                                   X.xt_table, c->keys3, plan.out_total, rank_stride);
+    const int ppl = plan.scan_ppl == 2 ? 2 : 4;  // the MFMA kernel spans 128 * {4, 8} points per workgroup
+    if (bx && plan.xkind == 0) {
+      launch_nn_scan_xfilter(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, xp, xp + st, xp + 2 * st, xp + 3 * st,
+                             X.xt_table, c->keys3, plan.out_total, rank_stride);
+    } else if (bx && plan.xkind == 1) {
+      launch_nn_scan_xmfma(c->stream, ppl, c->jobs_dev, n_active, bx, 0, S, xp, xp + st, xp + 2 * st, xp + 3 * st, X.xt_table,
+                           c->keys3, plan.out_total, rank_stride);
+    } else if (bx) {
+      // both pipes at once: scan blocks [0, first) on the vector ALU, [first, ...) on the matrix cores, in two streams
+      uint32_t max_scan_blocks = 0, split = 1;
+      for (int k = 0; k < n_active; ++k) {
+        max_scan_blocks = std::max(max_scan_blocks, c->jobs_host[k].scan_blocks);
+        split = std::max(split, c->jobs_host[k].n_split);
+      }
+      const uint32_t first = static_cast<uint32_t>(static_cast<uint64_t>(max_scan_blocks) * (100 - c->mfma_share_pct) / 100);
+      HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+      if (first)
+        launch_nn_scan_xfilter(c->stream, ppl, c->jobs_dev, n_active, first * split, S, xp, xp + st, xp + 2 * st, xp + 3 * st,
+                               X.xt_table, c->keys3, plan.out_total, rank_stride);
+      launch_nn_scan_xmfma(c->stream2, ppl, c->jobs_dev, n_active, (max_scan_blocks - first) * split, first, S, xp, xp + st,
+                           xp + 2 * st, xp + 3 * st, X.xt_table, c->keys3, plan.out_total, rank_stride);
+      HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    }
   } else if (bx) {
     launch_nn_scan_fused(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, T, c->keys3, plan.out_total, rank_stride);
   }
@@ -780,6 +809,9 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
     if (mode && std::string(mode) == "exact") c->scan_fused = 0;
     if (mode && std::string(mode) == "fused") c->scan_fused = 1;
     if (mode && std::string(mode) == "xfilter") c->scan_fused = 2;
+    if (mode && std::string(mode) == "xmfma") c->scan_fused = 3;   // expansion filter on the matrix cores only
+    if (mode && std::string(mode) == "xhybrid") c->scan_fused = 4; // VALU and MFMA workgroups side by side
+    c->mfma_share_pct = env_u32("MI355_ICP_MFMA_SHARE", c->mfma_share_pct);
     if (c->scan_sgpr) c->scan_fused = 0;
   }
   c->target_blocks = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks);
@@ -793,6 +825,9 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
   for (auto& ev : c->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(reinterpret_cast<void**>(&c->error_flag), sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(c->error_flag, 0, sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->flag_host), sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
@@ -807,6 +842,9 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   if (c->comm) rccl_comm_destroy(c->comm);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   for (CloudSet* set : {&c->targets, &c->sources}) {
     (void)hipFree(set->planes);
     (void)hipFree(set->normals);

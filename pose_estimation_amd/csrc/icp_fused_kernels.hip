@@ -334,6 +334,189 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_xfilter_kernel(const Jo
   }
 }
 
+// =====================================================================================================================
+// The expansion filter on the MATRIX cores.  tt + q'.tc is a K = 4 contraction, [tcx tcy tcz tt] . [q'x q'y q'z 1]^T, so
+// a pair of v_mfma_f32_32x32x2_f32 produces the surrogate of 32 targets x 32 sources (exact float32 fma chain, one
+// rounding per product: cdna_hip_programming.md "FP32-input MFMA") and the VALU is left with the minimum over the 16
+// accumulator registers - about one issue slot per pair instead of four.  f32 MFMA runs at the VALU rate, so this
+// kernel alone is no faster than nn_scan_xfilter_kernel; the point is that the matrix pipe and the vector ALU work
+// concurrently, so a launch that gives part of the source points to these workgroups and the rest to the VALU kernel's
+// finishes sooner than either alone (icp_engine.hip, run_fused_index_phase).
+//
+// Layout.  B operand (columns = sources): lane l holds, for source (l & 31), component k = l >> 5 of the K-pair:
+// B0 = (q'x | q'y), B1 = (q'z | 1).  A operand (rows = targets): lane l holds target (l & 31) of the 32-target block,
+// A0 = (tcx | tcy), A1 = (tcz | tt), read from the LDS tile with one ds_read_b32 each (lanes 0-31 walk one plane, lanes
+// 32-63 the next: conflict-free).  D: lane l holds column (l & 31) and the 16 rows (reg & 3) + 8 (reg >> 2) + 4 (l >> 5),
+// so the per-source minimum over a block is an in-lane minimum over the 16 registers plus one exchange between lanes l
+// and l + 32 per 64-target chunk.  Same bounds, same keys, same resolve as the VALU kernel.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// __launch_bounds__(256, 2): a register budget of <= 256 makes hipcc pick the VGPR-destination form of the MFMA; with
+// the default (512 registers allowed) it accumulates in AGPRs and spends one v_accvgpr_read per value, doubling the
+// VALU work this kernel exists to avoid.
+template <int kSets>  // 32-source column sets per wave: a workgroup covers 128 * kSets source points
+__global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xmfma_kernel(const JobDesc* __restrict__ jobs,
+                                                                       const float* __restrict__ sx,
+                                                                       const float* __restrict__ sy,
+                                                                       const float* __restrict__ sz,
+                                                                       const float* __restrict__ tcx,
+                                                                       const float* __restrict__ tcy,
+                                                                       const float* __restrict__ tcz,
+                                                                       const float* __restrict__ ttp,
+                                                                       const float4* __restrict__ tile_table,
+                                                                       unsigned long long* __restrict__ keys4,
+                                                                       uint32_t key_stride, uint32_t rank_stride,
+                                                                       uint32_t first_block) {
+  __shared__ float lds[2][4][kTile];  // x, y, z (centred) and tt: 2 x 16 KiB
+  const JobDesc& J = jobs[blockIdx.y];
+  const uint32_t n_split = J.n_split;
+  const uint32_t bxi = blockIdx.x + first_block * n_split;  // this launch covers scan blocks [first_block, ...)
+  const uint32_t sb = bxi / n_split;
+  const uint32_t sp = bxi - sb * n_split;
+  if (sb >= J.scan_blocks) return;
+  constexpr uint32_t kScanSrcPerBlock = 128 * kSets;
+  const uint32_t tile0 = sp * J.split_q + (sp < J.split_r ? sp : J.split_r);
+  const uint32_t tile1 = tile0 + J.split_q + (sp < J.split_r ? 1u : 0u);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const bool hi = lane >= 32;
+  float pose[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
+  float qx[kSets], qy[kSets], qz[kSets];
+  float l1[kSets], l2[kSets], l3[kSets], umin[kSets];
+  uint32_t c1[kSets], c2[kSets], c3[kSets];
+  bool unsafe = false;
+  const uint32_t src_local = (wave * kSets) * 32 + (lane & 31u);
+#pragma unroll
+  for (int m = 0; m < kSets; ++m) {
+    const uint32_t i = J.src_off + sb * kScanSrcPerBlock + src_local + m * 32;  // padded planes: always in bounds
+    transform_point(pose, sx[i], sy[i], sz[i], qx[m], qy[m], qz[m]);
+    l1[m] = l2[m] = l3[m] = umin[m] = __builtin_inff();
+    c1[m] = c2[m] = c3[m] = tile0 * kFusedChunksPerTile;
+  }
+  const uint32_t tile_base = J.tgt_off / kTile;
+  const float4* __restrict__ gx = reinterpret_cast<const float4*>(tcx + J.tgt_off);
+  const float4* __restrict__ gy = reinterpret_cast<const float4*>(tcy + J.tgt_off);
+  const float4* __restrict__ gz = reinterpret_cast<const float4*>(tcz + J.tgt_off);
+  const float4* __restrict__ gw = reinterpret_cast<const float4*>(ttp + J.tgt_off);
+  {
+    const uint32_t g = tile0 * (kTile / 4) + tid;
+    reinterpret_cast<float4*>(lds[0][0])[tid] = gx[g];
+    reinterpret_cast<float4*>(lds[0][1])[tid] = gy[g];
+    reinterpret_cast<float4*>(lds[0][2])[tid] = gz[g];
+    reinterpret_cast<float4*>(lds[0][3])[tid] = gw[g];
+  }
+  __syncthreads();
+  uint32_t cur = 0;
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t tile = tile0; tile < tile1; ++tile) {
+    const bool more = tile + 1 < tile1;
+    float4 rx, ry, rz, rw;
+    if (more) {
+      const uint32_t g = (tile + 1) * (kTile / 4) + tid;
+      rx = gx[g];
+      ry = gy[g];
+      rz = gz[g];
+      rw = gw[g];
+    }
+    const float4 tc = tile_table[tile_base + tile];
+    float b0[kSets], b1[kSets], qq[kSets], ee[kSets];
+#pragma unroll
+    for (int m = 0; m < kSets; ++m) {
+      const float cx = qx[m] - tc.x, cy = qy[m] - tc.y, cz = qz[m] - tc.z;
+      b0[m] = hi ? -2.0f * cy : -2.0f * cx;
+      b1[m] = hi ? 1.0f : -2.0f * cz;
+      qq[m] = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, cx * cx));
+      ee[m] = __builtin_fmaf(3.814697265625e-06f, qq[m] + tc.w, 7.1746481e-43f);
+      unsafe = unsafe || !(ee[m] < 1.0e37f);
+    }
+    const float* __restrict__ A0p = hi ? lds[cur][1] : lds[cur][0];  // (tcx | tcy)
+    const float* __restrict__ A1p = hi ? lds[cur][3] : lds[cur][2];  // (tcz | tt)
+    const uint32_t chunk_base = tile * kFusedChunksPerTile;
+    for (uint32_t c = 0; c < kFusedChunksPerTile; ++c) {
+      float cmin[kSets];
+#pragma unroll
+      for (int m = 0; m < kSets; ++m) cmin[m] = __builtin_inff();
+#pragma unroll
+      for (uint32_t blk = 0; blk < kFusedChunk / 32; ++blk) {
+        const uint32_t t = c * kFusedChunk + blk * 32 + (lane & 31u);
+        const float a0 = A0p[t], a1 = A1p[t];
+#pragma unroll
+        for (int m = 0; m < kSets; ++m) {
+          f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[m], zero, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[m], acc, 0, 0, 0);
+          float v = __builtin_fminf(__builtin_fminf(acc[0], acc[1]), acc[2]);
+          v = __builtin_fminf(__builtin_fminf(v, acc[3]), acc[4]);
+          v = __builtin_fminf(__builtin_fminf(v, acc[5]), acc[6]);
+          v = __builtin_fminf(__builtin_fminf(v, acc[7]), acc[8]);
+          v = __builtin_fminf(__builtin_fminf(v, acc[9]), acc[10]);
+          v = __builtin_fminf(__builtin_fminf(v, acc[11]), acc[12]);
+          v = __builtin_fminf(__builtin_fminf(v, acc[13]), acc[14]);
+          cmin[m] = __builtin_fminf(__builtin_fminf(cmin[m], v), acc[15]);
+        }
+      }
+      const uint32_t chunk = chunk_base + c;
+#pragma unroll
+      for (int m = 0; m < kSets; ++m) {
+        const float both = __builtin_fminf(cmin[m], __shfl_xor(cmin[m], 32, 64));  // rows of the other lane half
+        const float s = both + qq[m];
+        const float lo = __builtin_fmaxf(s - ee[m], 0.0f), up = s + ee[m];
+        umin[m] = __builtin_fminf(umin[m], up);
+        const float o1 = l1[m], o2 = l2[m], o3 = l3[m];
+        const uint32_t i1 = c1[m], i2 = c2[m], i3 = c3[m];
+        const bool d1 = lo < o1, d2 = lo < o2, d3 = lo < o3;
+        const float keep3 = d3 ? lo : o3, keep2 = d2 ? lo : o2;
+        const uint32_t keepi3 = d3 ? chunk : i3, keepi2 = d2 ? chunk : i2;
+        l3[m] = d2 ? o2 : keep3;
+        c3[m] = d2 ? i2 : keepi3;
+        l2[m] = d1 ? o1 : keep2;
+        c2[m] = d1 ? i1 : keepi2;
+        l1[m] = d1 ? lo : o1;
+        c1[m] = d1 ? chunk : i1;
+      }
+    }
+    if (more) {
+      reinterpret_cast<float4*>(lds[cur ^ 1][0])[tid] = rx;
+      reinterpret_cast<float4*>(lds[cur ^ 1][1])[tid] = ry;
+      reinterpret_cast<float4*>(lds[cur ^ 1][2])[tid] = rz;
+      reinterpret_cast<float4*>(lds[cur ^ 1][3])[tid] = rw;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  unsafe = unsafe || __shfl_xor(static_cast<int>(unsafe), 32, 64) != 0;
+  if (!hi) {
+    const size_t out = static_cast<size_t>(sp) * key_stride + J.out_off + sb * kScanSrcPerBlock + src_local;
+#pragma unroll
+    for (int m = 0; m < kSets; ++m) {
+      const size_t o = out + m * 32;
+      const float w1 = unsafe ? 0.0f : l1[m], w2 = unsafe ? 0.0f : l2[m], w3 = unsafe ? 0.0f : l3[m];
+      const float wu = unsafe ? __builtin_inff() : umin[m];
+      keys4[o] = (static_cast<unsigned long long>(__float_as_uint(w1)) << 32) | c1[m];
+      keys4[rank_stride + o] = (static_cast<unsigned long long>(__float_as_uint(w2)) << 32) | c2[m];
+      keys4[2 * static_cast<size_t>(rank_stride) + o] = (static_cast<unsigned long long>(__float_as_uint(w3)) << 32) | c3[m];
+      keys4[3 * static_cast<size_t>(rank_stride) + o] = static_cast<unsigned long long>(__float_as_uint(wu)) << 32;
+    }
+  }
+}
+
+// points_per_lane selects the workgroup's source span exactly as for the VALU kernel (256 * ppl = 128 * kSets points)
+void launch_nn_scan_xmfma(void* stream, int points_per_lane, const JobDesc* jobs_dev, int n_jobs, uint32_t blocks_x,
+                          uint32_t first_block, DevicePlanes src, const float* tcx, const float* tcy, const float* tcz,
+                          const float* tt, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
+                          uint32_t rank_stride) {
+  if (!blocks_x) return;
+  dim3 grid(blocks_x, static_cast<uint32_t>(n_jobs));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float4* table = static_cast<const float4*>(tile_table);
+  if (points_per_lane == 2)
+    hipLaunchKernelGGL(nn_scan_xmfma_kernel<4>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tcx, tcy, tcz,
+                       tt, table, keys4, key_stride, rank_stride, first_block);
+  else
+    hipLaunchKernelGGL(nn_scan_xmfma_kernel<8>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tcx, tcy, tcz,
+                       tt, table, keys4, key_stride, rank_stride, first_block);
+}
+
 void launch_nn_scan_xfilter(void* stream, int points_per_lane, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x,
                             DevicePlanes src, const float* tcx, const float* tcy, const float* tcz, const float* tt,
                             const void* tile_table, unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride) {

@@ -94,6 +94,10 @@ void launch_resolve_fused(void* stream, const JobDesc* jobs_dev, int n_jobs, uin
 void launch_nn_scan_xfilter(void* stream, int points_per_lane, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x,
                             DevicePlanes src, const float* tcx, const float* tcy, const float* tcz, const float* tt,
                             const void* tile_table, unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride);
+void launch_nn_scan_xmfma(void* stream, int points_per_lane, const JobDesc* jobs_dev, int n_jobs, uint32_t blocks_x,
+                          uint32_t first_block, DevicePlanes src, const float* tcx, const float* tcy, const float* tcz,
+                          const float* tt, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
+                          uint32_t rank_stride);
 void launch_resolve_xfilter(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
                             DevicePlanes sorted_original, const uint32_t* perm, const unsigned long long* keys4,
                             uint32_t key_stride, uint32_t rank_stride, int32_t* out_index, float* out_dist2,
