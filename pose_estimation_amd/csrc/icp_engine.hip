@@ -134,6 +134,9 @@ struct mi355_icp_ctx {
 
   int scan_ppl = 0;                  // scan points-per-lane override (2, 4, 8); 0 = planner decides per call
   bool scan_sgpr = false;            // experimental scalar-load scan (MI355_ICP_SCAN_MODE=sgpr)
+  uint32_t* xt_scratch = nullptr; size_t xt_scratch_cap = 0;  // Morton codes / indices while building the sorted target copy
+  float* xt_box = nullptr;        size_t xt_box_cap = 0;
+  unsigned char* xt_temp = nullptr; size_t xt_temp_cap = 0;   // rocPRIM sort scratch
   uint32_t mfma_share_pct = 65;      // hybrid: per cent of the scan workgroups that run on the matrix cores
   hipStream_t stream2 = nullptr;     // hybrid: the MFMA workgroups are launched here, beside the VALU ones
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -315,9 +318,9 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   // 64x50k, +13 % at 100k<->100k); tiny launches keep the all-exact scan: its resolve re-scans half as many targets and
   // it needs no overflow-count round trip to the host.
   plan.fused = c->scan_fused < 0 ? total_pairs >= 1e9 : c->scan_fused >= 1;
-  // The expansion filter (4 issue slots per pair) needs a sorted, tile-centred copy of the targets (built once per
-  // upload, ~0.1 s of host time per million points), so it is kept for launches where one pass already costs that much.
-  plan.xfilter = c->scan_fused < 0 ? total_pairs >= 4e11 : c->scan_fused >= 2;
+  // The expansion filter (4 issue slots per pair) needs a sorted, tile-centred copy of the targets, built on the device
+  // once per upload (~0.2 ms per 100k points): worth it as soon as the filter itself is.
+  plan.xfilter = c->scan_fused < 0 ? total_pairs >= 1e9 : c->scan_fused >= 2;
   plan.xkind = c->scan_fused >= 2 ? c->scan_fused - 2 : 0;
   if (plan.xfilter) plan.scan_ppl = c->scan_ppl ? c->scan_ppl : 4;
   if (plan.xfilter && plan.xkind && plan.scan_ppl != 2) plan.scan_ppl = 4;  // the MFMA kernel spans 128 * {4, 8} points
@@ -450,83 +453,43 @@ int run_overflow_fallback(mi355_icp_ctx* c, const Plan& plan, int n_active, cons
   return MI355_ICP_OK;
 }
 
-// Builds the expansion-filter copy of every target cloud (see CloudSet::xt_*): Morton sort (21 bits per axis inside the
-// cloud's bounding box), then per 1024-point tile: centre = bounding-box centre, tc = fl(t - c), tt = fl(|tc|^2) from
-// double, r^2 = max |tc|^2 rounded up.  Padding slots: tc = 0, tt = +inf (never a minimum), sorted-original = kTargetPad.
+// Builds, on the device, the expansion-filter copy of every target cloud (see CloudSet::xt_* and xtarget_kernels.hip).
+// Everything is enqueued on the engine's stream; the scan that follows on the same stream sees it complete.
 int ensure_xtarget(mi355_icp_ctx* c, CloudSet& set) {
   if (set.xt_valid) return MI355_ICP_OK;
   const size_t stride = set.stride;
-  std::vector<float> orig(3 * stride);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipMemcpy(orig.data(), set.planes, 3 * stride * sizeof(float), hipMemcpyDeviceToHost));
-  std::vector<float> xt(7 * stride, 0.0f);
-  std::vector<uint32_t> perm(stride, 0u);
-  std::vector<float> table(4 * (stride / kTile), 0.0f);
-  float *tcx = xt.data(), *tcy = tcx + stride, *tcz = tcy + stride, *tt = tcz + stride, *sox = tt + stride, *soy = sox + stride,
-        *soz = soy + stride;
-  const float *ox = orig.data(), *oy = ox + stride, *oz = oy + stride;
-  for (size_t i = 0; i < stride; ++i) {
-    tt[i] = std::numeric_limits<float>::infinity();
-    sox[i] = soy[i] = soz[i] = kTargetPad;
+  const int n_clouds = static_cast<int>(set.clouds.size());
+  uint32_t max_n = 1;
+  std::vector<uint32_t> meta(2 * static_cast<size_t>(n_clouds));
+  for (int k = 0; k < n_clouds; ++k) {
+    meta[k] = set.clouds[k].off;
+    meta[n_clouds + k] = set.clouds[k].n;
+    max_n = std::max(max_n, set.clouds[k].n);
   }
-  auto spread = [](uint64_t v) {  // 21 bits -> every third bit
-    v &= 0x1FFFFFull;
-    v = (v | v << 32) & 0x1F00000000FFFFull;
-    v = (v | v << 16) & 0x1F0000FF0000FFull;
-    v = (v | v << 8) & 0x100F00F00F00F00Full;
-    v = (v | v << 4) & 0x10C30C30C30C30C3ull;
-    v = (v | v << 2) & 0x1249249249249249ull;
-    return v;
-  };
-  for (const CloudEntry& e : set.clouds) {
-    if (!e.n) continue;
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (uint32_t i = 0; i < e.n; ++i) {
-      const double p[3] = {ox[e.off + i], oy[e.off + i], oz[e.off + i]};
-      for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
-    }
-    double scale[3];
-    for (int k = 0; k < 3; ++k) scale[k] = hi[k] > lo[k] ? 2097151.0 / (hi[k] - lo[k]) : 0.0;
-    std::vector<std::pair<uint64_t, uint32_t>> order(e.n);
-    for (uint32_t i = 0; i < e.n; ++i) {
-      const uint64_t a = static_cast<uint64_t>((ox[e.off + i] - lo[0]) * scale[0]);
-      const uint64_t b = static_cast<uint64_t>((oy[e.off + i] - lo[1]) * scale[1]);
-      const uint64_t d = static_cast<uint64_t>((oz[e.off + i] - lo[2]) * scale[2]);
-      order[i] = {spread(a) | spread(b) << 1 | spread(d) << 2, i};
-    }
-    std::sort(order.begin(), order.end());
-    for (uint32_t t0 = 0; t0 < e.n; t0 += kTile) {
-      const uint32_t t1 = std::min<uint32_t>(t0 + kTile, e.n);
-      double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
-      for (uint32_t s = t0; s < t1; ++s) {
-        const uint32_t i = e.off + order[s].second;
-        const double p[3] = {ox[i], oy[i], oz[i]};
-        for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], p[k]); bhi[k] = std::max(bhi[k], p[k]); }
-      }
-      const float cx = static_cast<float>(0.5 * (blo[0] + bhi[0])), cy = static_cast<float>(0.5 * (blo[1] + bhi[1])),
-                  cz = static_cast<float>(0.5 * (blo[2] + bhi[2]));
-      double r2 = 0.0;
-      for (uint32_t s = t0; s < t1; ++s) {
-        const uint32_t i = e.off + order[s].second, o = e.off + s;
-        const float dx = ox[i] - cx, dy = oy[i] - cy, dz = oz[i] - cz;  // float32 subtractions: the tc the kernel sees
-        tcx[o] = dx; tcy[o] = dy; tcz[o] = dz;
-        const double n2 = static_cast<double>(dx) * dx + static_cast<double>(dy) * dy + static_cast<double>(dz) * dz;
-        tt[o] = static_cast<float>(n2);
-        r2 = std::max(r2, n2);
-        sox[o] = ox[i]; soy[o] = oy[i]; soz[o] = oz[i];
-        perm[o] = order[s].second;
-      }
-      float* row = &table[4 * ((e.off + t0) / kTile)];
-      row[0] = cx; row[1] = cy; row[2] = cz;
-      row[3] = std::nextafter(static_cast<float>(r2), std::numeric_limits<float>::infinity());
-    }
-  }
+  size_t temp_bytes = 0;
+  if (xtarget_sort_temp_bytes(max_n, &temp_bytes) != 0) return fail(c, MI355_ICP_ERR_HIP, "rocprim::radix_sort_pairs (size query) failed");
+  int st;
+  if ((st = grow(c, c->xt_scratch, c->xt_scratch_cap, 4 * static_cast<size_t>(max_n) + 2 * static_cast<size_t>(n_clouds))) != MI355_ICP_OK) return st;
+  if ((st = grow(c, c->xt_box, c->xt_box_cap, 6 * static_cast<size_t>(n_clouds))) != MI355_ICP_OK) return st;
+  if ((st = grow(c, c->xt_temp, c->xt_temp_cap, temp_bytes + 16)) != MI355_ICP_OK) return st;
   if (!set.xt_planes) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.xt_planes), 7 * stride * sizeof(float)));
   if (!set.xt_perm) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.xt_perm), stride * sizeof(uint32_t)));
-  if (!set.xt_table) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.xt_table), table.size() * sizeof(float)));
-  HIP_TRY(c, hipMemcpy(set.xt_planes, xt.data(), 7 * stride * sizeof(float), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(set.xt_perm, perm.data(), stride * sizeof(uint32_t), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(set.xt_table, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (!set.xt_table) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.xt_table), 4 * (stride / kTile) * sizeof(float)));
+  uint32_t* code = c->xt_scratch;
+  uint32_t* index = code + max_n;
+  uint32_t* code2 = index + max_n;
+  uint32_t* order = code2 + max_n;
+  uint32_t* meta_dev = order + max_n;
+  HIP_TRY(c, hipMemcpyAsync(meta_dev, meta.data(), meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // `meta` is a pageable temporary
+  launch_xt_fill(c->stream, set.xt_planes, stride, set.xt_perm);
+  HIP_TRY(c, hipMemsetAsync(set.xt_table, 0, 4 * (stride / kTile) * sizeof(float), c->stream));
+  launch_bbox(c->stream, set.view(), meta_dev, meta_dev + n_clouds, n_clouds, c->xt_box);
+  for (int k = 0; k < n_clouds; ++k)
+    if (xtarget_build_cloud(c->stream, set.view(), set.clouds[k].off, set.clouds[k].n, c->xt_box + 6 * k, code, index, code2, order,
+                            c->xt_temp, temp_bytes, set.xt_planes, stride, set.xt_perm, set.xt_table) != 0)
+      return fail(c, MI355_ICP_ERR_HIP, "rocprim::radix_sort_pairs failed");
+  HIP_TRY(c, hipGetLastError());
   set.xt_valid = true;
   return MI355_ICP_OK;
 }
@@ -864,6 +827,9 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   (void)hipFree(c->scene_state);
   (void)hipFree(c->scene_counters);
   if (c->scene_counters_host) (void)hipHostFree(c->scene_counters_host);
+  (void)hipFree(c->xt_scratch);
+  (void)hipFree(c->xt_box);
+  (void)hipFree(c->xt_temp);
   (void)hipFree(c->keys3);
   (void)hipFree(c->overflow_list);
   (void)hipFree(c->overflow_count);

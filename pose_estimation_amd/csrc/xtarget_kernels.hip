@@ -1,0 +1,218 @@
+// xtarget_kernels.hip — builds, on the device, the copy of the target clouds the expansion filter scans
+// (nn_scan_xfilter_kernel, icp_fused_kernels.hip): points Morton-sorted so that a 1024-point tile is spatially
+// compact, then centred on their tile.  Nothing here affects results - the filter's bounds hold for ANY order and
+// ANY centre (only the number of candidate chunks, i.e. speed, depends on compactness) - so the sort may use a library
+// primitive: rocprim::radix_sort_pairs (stable, hence deterministic).
+//
+//   bbox_kernel      one workgroup per cloud: bounding box (the Morton grid)
+//   morton_kernel    30-bit code per point (10 bits per axis inside the box)
+//   <rocPRIM>        stable radix sort of (code, index)
+//   centre_kernel    one workgroup per 1024-point tile: tile box -> centre c; tc = fl(t - c) (the float32 subtraction the
+//                    bound is written for), tt = fl(|tc|^2) from double, r^2 = max |tc|^2 rounded up; also the sorted
+//                    copy of the original coordinates and the sorted-position -> original-index table
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "icp_internal.h"
+
+namespace mi355 {
+
+namespace {
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
+  v &= 0x3FFu;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+template <int NT>
+__device__ __forceinline__ void block_minmax(float (&lo)[3], float (&hi)[3], float (*slo)[3], float (*shi)[3]) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      lo[k] = __builtin_fminf(lo[k], __shfl_xor(lo[k], off, 64));
+      hi[k] = __builtin_fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+    }
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      slo[wave][k] = lo[k];
+      shi[wave][k] = hi[k];
+    }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = slo[0][k];
+    hi[k] = shi[0][k];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) {
+      lo[k] = __builtin_fminf(lo[k], slo[w][k]);
+      hi[k] = __builtin_fmaxf(hi[k], shi[w][k]);
+    }
+  }
+}
+
+}  // namespace
+
+// grid = n_clouds, block = 1024.  box[cloud] = {lo x, y, z, hi x, y, z}
+__global__ __launch_bounds__(1024) void bbox_kernel(const float* __restrict__ px, const float* __restrict__ py,
+                                                     const float* __restrict__ pz, const uint32_t* __restrict__ cloud_off,
+                                                     const uint32_t* __restrict__ cloud_n, float* __restrict__ box) {
+  __shared__ float slo[16][3], shi[16][3];
+  const uint32_t off = cloud_off[blockIdx.x], n = cloud_n[blockIdx.x];
+  float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+    const float p[3] = {px[off + i], py[off + i], pz[off + i]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = __builtin_fminf(lo[k], p[k]);
+      hi[k] = __builtin_fmaxf(hi[k], p[k]);
+    }
+  }
+  block_minmax<1024>(lo, hi, slo, shi);
+  if (threadIdx.x < 3) {
+    box[6 * blockIdx.x + threadIdx.x] = lo[threadIdx.x];
+    box[6 * blockIdx.x + 3 + threadIdx.x] = hi[threadIdx.x];
+  }
+}
+
+// one thread per point of one cloud
+__global__ __launch_bounds__(kBlockThreads) void morton_kernel(const float* __restrict__ px, const float* __restrict__ py,
+                                                                const float* __restrict__ pz, uint32_t off, uint32_t n,
+                                                                const float* __restrict__ box, uint32_t* __restrict__ code,
+                                                                uint32_t* __restrict__ index) {
+  const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
+  if (i >= n) return;
+  const float p[3] = {px[off + i], py[off + i], pz[off + i]};
+  uint32_t q[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float lo = box[k], ext = box[3 + k] - box[k];
+    const float f = ext > 0.f ? (p[k] - lo) / ext * 1023.0f : 0.f;
+    q[k] = static_cast<uint32_t>(__builtin_fminf(__builtin_fmaxf(f, 0.f), 1023.f));
+  }
+  code[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+  index[i] = i;
+}
+
+// grid = tiles of one cloud, block = 256 (4 points per thread).  order[]: sorted position -> index inside the cloud.
+__global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __restrict__ px, const float* __restrict__ py,
+                                                                const float* __restrict__ pz, uint32_t off, uint32_t n,
+                                                                const uint32_t* __restrict__ order, float* __restrict__ xt,
+                                                                size_t stride, uint32_t* __restrict__ perm,
+                                                                float* __restrict__ table) {
+  __shared__ float slo[4][3], shi[4][3];
+  __shared__ double sr2[4];
+  const uint32_t t0 = blockIdx.x * kTile;
+  float x[4], y[4], z[4];
+  uint32_t src[4];
+  float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t s = t0 + k * kBlockThreads + threadIdx.x;
+    src[k] = 0xFFFFFFFFu;
+    if (s < n) {
+      src[k] = order[s];
+      x[k] = px[off + src[k]];
+      y[k] = py[off + src[k]];
+      z[k] = pz[off + src[k]];
+      lo[0] = __builtin_fminf(lo[0], x[k]); hi[0] = __builtin_fmaxf(hi[0], x[k]);
+      lo[1] = __builtin_fminf(lo[1], y[k]); hi[1] = __builtin_fmaxf(hi[1], y[k]);
+      lo[2] = __builtin_fminf(lo[2], z[k]); hi[2] = __builtin_fmaxf(hi[2], z[k]);
+    }
+  }
+  block_minmax<kBlockThreads>(lo, hi, slo, shi);
+  const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
+  double r2 = 0.0;
+  float* tcx = xt + off;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t s = t0 + k * kBlockThreads + threadIdx.x;
+    if (src[k] != 0xFFFFFFFFu) {
+      const float dx = x[k] - cx, dy = y[k] - cy, dz = z[k] - cz;  // the float32 subtractions the bound is written for
+      const double n2 = static_cast<double>(dx) * dx + static_cast<double>(dy) * dy + static_cast<double>(dz) * dz;
+      tcx[s] = dx;
+      tcx[stride + s] = dy;
+      tcx[2 * stride + s] = dz;
+      tcx[3 * stride + s] = static_cast<float>(n2);
+      tcx[4 * stride + s] = x[k];
+      tcx[5 * stride + s] = y[k];
+      tcx[6 * stride + s] = z[k];
+      perm[off + s] = src[k];
+      r2 = n2 > r2 ? n2 : r2;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double other = __shfl_xor(r2, o, 64);
+    r2 = other > r2 ? other : r2;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63u) == 0) sr2[threadIdx.x >> 6] = r2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = sr2[0];
+    for (int w = 1; w < 4; ++w) m = sr2[w] > m ? sr2[w] : m;
+    const float r = __uint_as_float(__float_as_uint(static_cast<float>(m)) + 1u);  // next float up: r^2 >= every |tc|^2 (m >= 0, finite)
+    float* row = table + 4 * static_cast<size_t>((off + t0) / kTile);
+    row[0] = cx; row[1] = cy; row[2] = cz; row[3] = r;
+  }
+}
+
+// fills the padding of all seven planes and the perm table before the per-cloud kernels run
+__global__ __launch_bounds__(kBlockThreads) void xt_fill_kernel(float* __restrict__ xt, size_t stride, uint32_t* __restrict__ perm) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * kBlockThreads + threadIdx.x;
+  if (i >= stride) return;
+  xt[i] = 0.f;
+  xt[stride + i] = 0.f;
+  xt[2 * stride + i] = 0.f;
+  xt[3 * stride + i] = __builtin_inff();
+  xt[4 * stride + i] = kTargetPad;
+  xt[5 * stride + i] = kTargetPad;
+  xt[6 * stride + i] = kTargetPad;
+  perm[i] = 0u;
+}
+
+int xtarget_sort_temp_bytes(uint32_t n, size_t* bytes) {
+  uint32_t* k = nullptr;
+  size_t tmp = 0;
+  if (rocprim::radix_sort_pairs(nullptr, tmp, k, k, k, k, n, 0, 30, static_cast<hipStream_t>(nullptr), false) != hipSuccess) return 1;
+  *bytes = tmp;
+  return 0;
+}
+
+// Enqueues the whole build for one cloud on `stream`.  code/index/code2/order: n entries each; temp: sort scratch.
+int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const float* box, uint32_t* code,
+                        uint32_t* index, uint32_t* code2, uint32_t* order, void* temp, size_t temp_bytes, float* xt,
+                        size_t stride, uint32_t* perm, float* table) {
+  if (!n) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(morton_kernel, dim3((n + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, st, planes.x, planes.y,
+                     planes.z, off, n, box, code, index);
+  size_t tb = temp_bytes;
+  if (rocprim::radix_sort_pairs(temp, tb, code, code2, index, order, n, 0, 30, st, false) != hipSuccess) return 1;
+  hipLaunchKernelGGL(centre_kernel, dim3((n + kTile - 1) / kTile), dim3(kBlockThreads), 0, st, planes.x, planes.y, planes.z, off, n,
+                     order, xt, stride, perm, table);
+  return 0;
+}
+
+void launch_bbox(void* stream, DevicePlanes planes, const uint32_t* cloud_off, const uint32_t* cloud_n, int n_clouds, float* box) {
+  hipLaunchKernelGGL(bbox_kernel, dim3(static_cast<uint32_t>(n_clouds)), dim3(1024), 0, static_cast<hipStream_t>(stream), planes.x,
+                     planes.y, planes.z, cloud_off, cloud_n, box);
+}
+
+void launch_xt_fill(void* stream, float* xt, size_t stride, uint32_t* perm) {
+  hipLaunchKernelGGL(xt_fill_kernel, dim3(static_cast<uint32_t>((stride + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0,
+                     static_cast<hipStream_t>(stream), xt, stride, perm);
+}
+
+}  // namespace mi355
