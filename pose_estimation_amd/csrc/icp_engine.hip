@@ -1015,6 +1015,7 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
       owner_total += level_clouds(c->targets, level)[ptid[a]].padded;
     }
     if ((st = ensure_ref_buffers(c, plan, static_cast<size_t>(np), owner_total)) != MI355_ICP_OK) return st;
+    if (level == 0 && plan.xfilter && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;  // coarser levels: fused filter
 
     const double tolp = static_cast<double>(rp->tolerance) * static_cast<double>(level + 1) * static_cast<double>(level + 1);
     const int maxit = static_cast<int>(std::floor(static_cast<double>(rp->iterations) / static_cast<double>(level + 1) + 0.5));
@@ -1102,6 +1103,7 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
   if ((st = ensure_buffers(c, plan, 1)) != MI355_ICP_OK) return st;
   const size_t owner_total = level_clouds(c->targets, level)[target_id].padded;
   if ((st = ensure_ref_buffers(c, plan, 1, owner_total)) != MI355_ICP_OK) return st;
+  if (level == 0 && plan.xfilter && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
   JobDesc J = plan.jobs[0];
   RefJobDesc R{};
