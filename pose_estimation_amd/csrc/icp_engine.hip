@@ -50,6 +50,7 @@ struct CloudSet {
   float* xt_planes = nullptr;
   uint32_t* xt_perm = nullptr;
   float* xt_table = nullptr;
+  void* xt_bf = nullptr;     // bf16 operand image of the matrix-core filter: kXbTileVecs uint4 per tile
   bool xt_valid = false;
   DevicePlanes view() const { return DevicePlanes{planes, planes + stride, planes + 2 * stride}; }
   DevicePlanes normal_view() const { return DevicePlanes{normals, normals + stride, normals + 2 * stride}; }
@@ -65,7 +66,8 @@ struct Plan {
   int scan_ppl = 8;            // source points per lane the scan kernel is launched with
   bool fused = false;          // fused-filter scan + exact resolve (large launches) instead of the all-exact scan
   bool xfilter = false;        // expansion-filter scan on the sorted/centred target copy (largest launches); implies fused
-  int xkind = 0;               // 0 VALU kernel, 1 MFMA kernel, 2 both side by side
+  int xkind = 0;               // 0 VALU kernel, 1 f32 MFMA kernel, 2 both side by side, 3 split-bf16 MFMA kernel
+  uint32_t key_rows() const { return (xkind == 3 ? 2u : 1u) * max_split; }  // key rows per rank (wave halves publish separately)
 };
 
 uint32_t env_u32(const char* name, uint32_t dflt) {
@@ -140,7 +142,8 @@ struct mi355_icp_ctx {
   uint32_t mfma_share_pct = 65;      // hybrid: per cent of the scan workgroups that run on the matrix cores
   hipStream_t stream2 = nullptr;     // hybrid: the MFMA workgroups are launched here, beside the VALU ones
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int scan_fused = -1;               // -1 auto (by pairs per launch: >= 1e9 fused, >= 4e11 expansion filter), 0 exact, 1 fused, 2 xfilter
+  int scan_fused = -1;               // -1 auto (by pairs per launch: >= 1e9 the split-bf16 expansion filter), 0 exact, 1 fused, 2 xfilter,
+                                     // 3 xmfma, 4 xhybrid, 5 xbf16 (MI355_ICP_SCAN_MODE)
   // fused-filter path
   unsigned long long* keys3 = nullptr; size_t keys3_cap = 0;
   uint32_t* overflow_list = nullptr;   size_t overflow_list_cap = 0;
@@ -221,6 +224,7 @@ int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* co
   if (set.xt_planes) { HIP_TRY(c, hipFree(set.xt_planes)); set.xt_planes = nullptr; }
   if (set.xt_perm) { HIP_TRY(c, hipFree(set.xt_perm)); set.xt_perm = nullptr; }
   if (set.xt_table) { HIP_TRY(c, hipFree(set.xt_table)); set.xt_table = nullptr; }
+  if (set.xt_bf) { HIP_TRY(c, hipFree(set.xt_bf)); set.xt_bf = nullptr; }
   set.xt_valid = false;
   set.clouds.clear();
   HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.planes), 3 * stride * sizeof(float)));
@@ -258,7 +262,7 @@ int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs) {
   }
   if ((st = grow(c, c->partials, c->partials_cap, static_cast<size_t>(std::max<uint32_t>(plan.partial_total, 1)) * MI355_ICP_NSUMS)) != MI355_ICP_OK) return st;
   if (plan.fused) {
-    if ((st = grow(c, c->keys3, c->keys3_cap, (plan.xfilter ? 4 : 3) * static_cast<size_t>(plan.max_split) * plan.out_total)) != MI355_ICP_OK) return st;
+    if ((st = grow(c, c->keys3, c->keys3_cap, (plan.xfilter ? 4 : 3) * static_cast<size_t>(plan.key_rows()) * plan.out_total)) != MI355_ICP_OK) return st;
     if ((st = grow(c, c->overflow_list, c->overflow_list_cap, std::max<size_t>(plan.out_total, 1))) != MI355_ICP_OK) return st;
     if (n_jobs > c->overflow_jobs_cap) {
       if (c->overflow_count) { HIP_TRY(c, hipFree(c->overflow_count)); c->overflow_count = nullptr; }
@@ -321,9 +325,12 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   // The expansion filter (4 issue slots per pair) needs a sorted, tile-centred copy of the targets, built on the device
   // once per upload (~0.2 ms per 100k points): worth it as soon as the filter itself is.
   plan.xfilter = c->scan_fused < 0 ? total_pairs >= 1e9 : c->scan_fused >= 2;
-  plan.xkind = c->scan_fused >= 2 ? c->scan_fused - 2 : 0;
+  // ... and the split-bf16 matrix-core form of it (xkind 3: one issue slot per pair, 2.3x the VALU filter end to end at
+  // 100k<->100k, 1M<->1M and 64 x 50k<->50k: profiles/r01n_baseline_configs.jsonl) is the default wherever it applies
+  plan.xkind = c->scan_fused < 0 ? 3 : (c->scan_fused >= 2 ? c->scan_fused - 2 : 0);
   if (plan.xfilter) plan.scan_ppl = c->scan_ppl ? c->scan_ppl : 4;
   if (plan.xfilter && plan.xkind && plan.scan_ppl != 2) plan.scan_ppl = 4;  // the MFMA kernel spans 128 * {4, 8} points
+  if (plan.xfilter && plan.xkind == 3) plan.scan_ppl = 2;                     // split-bf16 kernel: 512 points per workgroup
   const uint32_t scan_src = static_cast<uint32_t>(kBlockThreads * plan.scan_ppl);
   uint64_t total_src_blocks = 0;
   for (int k = 0; k < n_jobs; ++k)
@@ -365,7 +372,7 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   }
   plan.out_total = static_cast<uint32_t>(out_off);
   plan.partial_total = static_cast<uint32_t>(partial_off);
-  if (static_cast<uint64_t>(plan.max_split) * plan.out_total > 0xFFFF0000ull) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "batch too large");
+  if (static_cast<uint64_t>(plan.key_rows()) * plan.out_total > 0xFFFF0000ull) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "batch too large");
   return MI355_ICP_OK;
 }
 
@@ -475,6 +482,7 @@ int ensure_xtarget(mi355_icp_ctx* c, CloudSet& set) {
   if (!set.xt_planes) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.xt_planes), 7 * stride * sizeof(float)));
   if (!set.xt_perm) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.xt_perm), stride * sizeof(uint32_t)));
   if (!set.xt_table) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.xt_table), 4 * (stride / kTile) * sizeof(float)));
+  if (!set.xt_bf) HIP_TRY(c, hipMalloc(&set.xt_bf, (stride / kTile) * static_cast<size_t>(kXbTileVecs) * 16));
   uint32_t* code = c->xt_scratch;
   uint32_t* index = code + max_n;
   uint32_t* code2 = index + max_n;
@@ -482,12 +490,12 @@ int ensure_xtarget(mi355_icp_ctx* c, CloudSet& set) {
   uint32_t* meta_dev = order + max_n;
   HIP_TRY(c, hipMemcpyAsync(meta_dev, meta.data(), meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // `meta` is a pageable temporary
-  launch_xt_fill(c->stream, set.xt_planes, stride, set.xt_perm);
+  launch_xt_fill(c->stream, set.xt_planes, stride, set.xt_perm, set.xt_bf);
   HIP_TRY(c, hipMemsetAsync(set.xt_table, 0, 4 * (stride / kTile) * sizeof(float), c->stream));
   launch_bbox(c->stream, set.view(), meta_dev, meta_dev + n_clouds, n_clouds, c->xt_box);
   for (int k = 0; k < n_clouds; ++k)
     if (xtarget_build_cloud(c->stream, set.view(), set.clouds[k].off, set.clouds[k].n, c->xt_box + 6 * k, code, index, code2, order,
-                            c->xt_temp, temp_bytes, set.xt_planes, stride, set.xt_perm, set.xt_table) != 0)
+                            c->xt_temp, temp_bytes, set.xt_planes, stride, set.xt_perm, set.xt_table, set.xt_bf) != 0)
       return fail(c, MI355_ICP_ERR_HIP, "rocprim::radix_sort_pairs failed");
   HIP_TRY(c, hipGetLastError());
   set.xt_valid = true;
@@ -498,14 +506,16 @@ int ensure_xtarget(mi355_icp_ctx* c, CloudSet& set) {
 // chunks -> (rarely) the all-exact scan for points whose candidates overflowed the band.  Records ev[1] after the scan.
 int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint32_t bx, uint32_t sbx, DevicePlanes S,
                           DevicePlanes T, bool profile) {
-  const uint32_t rank_stride = plan.max_split * plan.out_total;
+  const uint32_t rank_stride = plan.key_rows() * plan.out_total;
   const CloudSet& X = c->targets;
   const bool xf = plan.xfilter && X.xt_valid && T.x == X.planes;  // only for the level-0 targets the copy was built from
   if (xf) {
     const float* xp = X.xt_planes;
     const size_t st = X.stride;
     const int ppl = plan.scan_ppl == 2 ? 2 : 4;  // the MFMA kernel spans 128 * {4, 8} points per workgroup
-    if (bx && plan.xkind == 0) {
+    if (bx && plan.xkind == 3) {
+      launch_nn_scan_xbf16(c->stream, c->jobs_dev, n_active, bx, S, X.xt_bf, X.xt_table, c->keys3, plan.out_total, rank_stride);
+    } else if (bx && plan.xkind == 0) {
       launch_nn_scan_xfilter(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, xp, xp + st, xp + 2 * st, xp + 3 * st,
                              X.xt_table, c->keys3, plan.out_total, rank_stride);
     } else if (bx && plan.xkind == 1) {
@@ -537,7 +547,8 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
   if (sbx && xf) {
     const float* xp = X.xt_planes;
     const size_t st = X.stride;
-    launch_resolve_xfilter(c->stream, c->jobs_dev, n_active, sbx, S, DevicePlanes{xp + 4 * st, xp + 5 * st, xp + 6 * st}, X.xt_perm,
+    const bool xb = plan.xkind == 3;
+    launch_resolve_xfilter(c->stream, xb ? kXbRun : kFusedChunk, xb ? 2u : 1u, c->jobs_dev, n_active, sbx, S, DevicePlanes{xp + 4 * st, xp + 5 * st, xp + 6 * st}, X.xt_perm,
                            c->keys3, plan.out_total, rank_stride, c->out_index, c->out_dist2, c->overflow_list, c->overflow_count,
                            c->error_flag);
   } else if (sbx) {
@@ -567,7 +578,7 @@ int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, boo
   }
   const DevicePlanes S = c->sources.view(), T = c->targets.view();
   // never launch against a buffer the planner did not size for this launch shape (an out-of-bounds kernel can take the GPU down)
-  const size_t key_need = static_cast<size_t>(plan.max_split) * plan.out_total;
+  const size_t key_need = static_cast<size_t>(plan.fused ? plan.key_rows() : plan.max_split) * plan.out_total;
   if (plan.out_total > c->out_cap || static_cast<size_t>(plan.partial_total) * MI355_ICP_NSUMS > c->partials_cap ||
       (plan.fused ? ((plan.xfilter ? 4 : 3) * key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : key_need > c->keys_cap))
     return fail(c, MI355_ICP_ERR_INTERNAL, "work buffers are smaller than the plan (ensure_buffers not run for this plan)");
@@ -683,8 +694,8 @@ int run_ref_pass(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, fl
     pairs += static_cast<double>(J.src_n) * static_cast<double>(J.tgt_n);
   }
   const DevicePlanes S = level_view(c->sources, level), T = level_view(c->targets, level);
-  const size_t ref_key_need = static_cast<size_t>(plan.max_split) * plan.out_total;
-  if ((plan.fused ? (3 * ref_key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : ref_key_need > c->keys_cap) ||
+  const size_t ref_key_need = static_cast<size_t>(plan.fused ? plan.key_rows() : plan.max_split) * plan.out_total;
+  if ((plan.fused ? ((plan.xfilter ? 4 : 3) * ref_key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : ref_key_need > c->keys_cap) ||
       plan.out_total > c->out_cap || plan.out_total > c->selected_cap || owner_total > c->owner_cap ||
       static_cast<size_t>(plan.partial_total) * kRefSums > c->ref_partials_cap ||
       static_cast<size_t>(plan.partial_total) * MI355_ICP_NSUMS > c->partials_cap)
@@ -774,6 +785,7 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
     if (mode && std::string(mode) == "xfilter") c->scan_fused = 2;
     if (mode && std::string(mode) == "xmfma") c->scan_fused = 3;   // expansion filter on the matrix cores only
     if (mode && std::string(mode) == "xhybrid") c->scan_fused = 4; // VALU and MFMA workgroups side by side
+    if (mode && std::string(mode) == "xbf16") c->scan_fused = 5;   // expansion filter on the matrix cores, split-bf16 operands
     c->mfma_share_pct = env_u32("MI355_ICP_MFMA_SHARE", c->mfma_share_pct);
     if (c->scan_sgpr) c->scan_fused = 0;
   }
@@ -815,6 +827,7 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
     (void)hipFree(set->xt_planes);
     (void)hipFree(set->xt_perm);
     (void)hipFree(set->xt_table);
+    (void)hipFree(set->xt_bf);
   }
   (void)hipFree(c->scene[0]);
   (void)hipFree(c->scene[1]);
@@ -1311,6 +1324,7 @@ int mi355_icp_scene_commit_target(mi355_icp_ctx* c) {
   if (set.xt_planes) { HIP_TRY(c, hipFree(set.xt_planes)); set.xt_planes = nullptr; }
   if (set.xt_perm) { HIP_TRY(c, hipFree(set.xt_perm)); set.xt_perm = nullptr; }
   if (set.xt_table) { HIP_TRY(c, hipFree(set.xt_table)); set.xt_table = nullptr; }
+  if (set.xt_bf) { HIP_TRY(c, hipFree(set.xt_bf)); set.xt_bf = nullptr; }
   set.xt_valid = false;
   set.planes = planes;
   set.stride = padded;

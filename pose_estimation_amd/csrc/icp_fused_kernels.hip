@@ -17,6 +17,9 @@
 // therefore excluded from `make check-isa`.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <cstdint>
 
 #include "icp_internal.h"
@@ -498,6 +501,249 @@ __global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xmfma_kernel(const J
       keys4[3 * static_cast<size_t>(rank_stride) + o] = static_cast<unsigned long long>(__float_as_uint(wu)) << 32;
     }
   }
+}
+
+// =====================================================================================================================
+// The expansion filter on the matrix cores at the bf16 rate: SPLIT-bf16 operands.
+//
+// f32-input MFMA runs on the vector ALUs (measured: no overlap with VALU work, tools/ubench_mfma_valu.hip), so the
+// kernel above buys nothing.  v_mfma_f32_32x32x16_bf16 is a different unit: 1024 products of a K = 16 contraction in 32
+// cycles, of which it holds the vector issue port for 8.  Sixteen K slots are enough for the expansion surrogate of
+// points QUANTISED to two bfloat16 pieces per coordinate (16 significand bits):
+//
+//   qc' = hi + lo of -2 fl(q - c) (times -1/2),   tc' = hi + lo of fl(t - c),   tt' = fl(|tc'|^2) in three pieces
+//   slots 0-11: (th, th, tl, tl) x (qh, ql, qh, ql) per coordinate  = q'.tc' exactly (every product is exact in f32)
+//   slots 12-14: (tt1, tt2, tt3) x (1, 1, 1)                       = tt'          slot 15: 1 x b, a bias (see min16)
+//   s = |qc'|^2 + (MFMA - b)   ~   |qc' - tc'|^2, the squared distance between the QUANTISED points.
+//
+// Moving a point by delta changes a squared distance d^2 by at most 2 d |delta| + |delta|^2 <= eps d^2 + (1 + 1/eps)
+// |delta|^2 for any eps > 0.  With eps = 2^-6 and |delta| <= 2^-16 (|qc| + r) the second term is below 2^-24.9
+// (|qc|^2 + r^2), so
+//        (1 - 2^-6) d^2 - E  <=  s  <=  (1 + 2^-6) d^2 + E,     E = 2^-16 (|qc|^2 + r_tile^2) + 2^-120
+// where E = 256 u also covers every rounding on the way: the float32 centring of q and t and the contract formula
+// itself (the 30.4 u of the VALU filter's derivation), tt', |qc'|^2, the bias and the final additions
+// (< 12 u), and up to 4 u of relative error in each of the MFMA's 16 accumulation steps (sum of |terms| <=
+// 3.1 (|qc|^2 + r^2) with the bias; truncating accumulation would be 2 u per step).  The absolute floor 2^-120 is for
+// the matrix unit flushing subnormal operand pieces, products or sums (17 x 2^-126 at most, plus 6 x 2^-126 (|q'| + r)
+// for flushed low pieces, which the relative part covers once |qc| + r >= 2^-106): squared distances that small make
+// every granule a candidate and the all-exact scan answers.  Hence per granule
+//        L = max((s_min - E) * 0.9845, 0)  <=  exact minimum of the granule  <=  (s_min + E) * 1.0160 = U
+// and the rest is the VALU filter's scheme: three smallest L and the smallest U per source point; the exact resolve
+// re-scans the one or two granules with L <= U_min on the original coordinates; more go to the all-exact scan.
+//
+// Geometry.  A wave computes 32 targets x 32 sources per MFMA.  D: lane l holds source column (l & 31) and the 16 rows
+// 8j + 4(l >> 5) + k, so each HALF of the wave sees half of the rows; the operand image (xtarget_kernels.hip) assigns
+// those rows to one contiguous 128-target run of the sorted copy per 256-target chunk, and each half keeps its own
+// keys - no cross-lane traffic at all; the resolve merges the two key rows like two more target splits.
+// VALU work per pair: the minimum over the 16 accumulator registers (1 issue slot) + ~0.14 slots of bookkeeping.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define MI355_PIN(frag, acc, cm) asm volatile("" : "+v"(frag), "+v"(acc), "+v"(cm))
+__device__ __forceinline__ u32x4 load_frag(const uint4* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+__device__ __forceinline__ void split_bf16(float v, uint32_t& packed, float& value) {
+  const __bf16 hb = static_cast<__bf16>(v);
+  const float hf = static_cast<float>(hb);
+  const __bf16 lb = static_cast<__bf16>(v - hf);
+  const float lf = static_cast<float>(lb);
+  packed = static_cast<uint32_t>(__builtin_bit_cast(unsigned short, hb)) |
+           (static_cast<uint32_t>(__builtin_bit_cast(unsigned short, lb)) << 16);
+  value = hf + lf;
+}
+
+// Minimum of the 16 accumulators as UNSIGNED integers.  The sixteenth K slot adds a per-source bias b >= |qc'|^2 + 2E,
+// so every finite result is a non-negative float (>= E by the bound above) and unsigned order is float order; +inf
+// (padding rows) sorts after every finite value and NaNs of either sign after that.  A float minimum would cost two
+// issue slots per value here: hipcc has to canonicalise MFMA results before v_min_f32 (IEEE mode), the integer one is
+// a single integer op.
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t t = a < b ? a : b;
+  return t < c ? t : c;  // v_min3_u32
+}
+// min(seed, the 16 results): 8 v_min3_u32.  Integer VALU ops take 4 cycles per wave on gfx950 whatever their operand
+// count (tools/ubench_bf16_min.hip), so the three-operand form halves the cost of the minimum: 32 cycles per MFMA.
+__device__ __forceinline__ uint32_t min16(const f32x16& acc, uint32_t seed) {
+  uint32_t b[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) b[k] = __float_as_uint(acc[k]);
+  const uint32_t t0 = umin3(b[0], b[1], b[2]), t1 = umin3(b[3], b[4], b[5]), t2 = umin3(b[6], b[7], b[8]);
+  const uint32_t t3 = umin3(b[9], b[10], b[11]), t4 = umin3(b[12], b[13], b[14]);
+  const uint32_t t5 = umin3(b[15], t0, t1), t6 = umin3(t2, t3, t4);
+  return umin3(t5, t6, seed);
+}
+
+template <int kSets>  // 32-source column sets per wave: a workgroup covers 128 * kSets source points
+__global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xbf16_kernel(const JobDesc* __restrict__ jobs,
+                                                                       const float* __restrict__ sx,
+                                                                       const float* __restrict__ sy,
+                                                                       const float* __restrict__ sz,
+                                                                       const uint4* __restrict__ bf_image,
+                                                                       const float4* __restrict__ tile_table,
+                                                                       unsigned long long* __restrict__ keys4,
+                                                                       uint32_t key_stride, uint32_t rank_stride) {
+  __shared__ uint4 lds[2][kXbTileVecs];  // [buffer][k half][row slot]: 2 x 32 KiB
+  const JobDesc& J = jobs[blockIdx.y];
+  const uint32_t n_split = J.n_split;
+  const uint32_t sb = blockIdx.x / n_split;
+  const uint32_t sp = blockIdx.x - sb * n_split;
+  if (sb >= J.scan_blocks) return;
+  constexpr uint32_t kScanSrcPerBlock = 128 * kSets;
+  const uint32_t tile0 = sp * J.split_q + (sp < J.split_r ? sp : J.split_r);
+  const uint32_t tile1 = tile0 + J.split_q + (sp < J.split_r ? 1u : 0u);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const bool hi = lane >= 32;
+  float pose[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
+  float qx[kSets], qy[kSets], qz[kSets];
+  float l1[kSets], l2[kSets], l3[kSets];
+  uint32_t c1[kSets], c2[kSets], c3[kSets];
+  bool unsafe = false;
+  const uint32_t src_local = (wave * kSets) * 32 + (lane & 31u);
+#pragma unroll
+  for (int m = 0; m < kSets; ++m) {
+    const uint32_t i = J.src_off + sb * kScanSrcPerBlock + src_local + m * 32;  // padded planes: always in bounds
+    transform_point(pose, sx[i], sy[i], sz[i], qx[m], qy[m], qz[m]);
+    l1[m] = l2[m] = l3[m] = __builtin_inff();
+    c1[m] = c2[m] = c3[m] = tile0 * (2 * kXbChunksPerTile);
+  }
+  const uint32_t tile_base = J.tgt_off / kTile;  // tgt_off is a multiple of kTile
+  const uint4* __restrict__ image = bf_image + static_cast<size_t>(tile_base) * kXbTileVecs;
+#pragma unroll
+  for (int k = 0; k < kXbTileVecs / kBlockThreads; ++k)
+    lds[0][k * kBlockThreads + tid] = image[static_cast<size_t>(tile0) * kXbTileVecs + k * kBlockThreads + tid];
+  __syncthreads();
+  uint32_t cur = 0;
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t tile = tile0; tile < tile1; ++tile) {
+    const bool more = tile + 1 < tile1;
+    const float4 tc = tile_table[tile_base + tile];  // centre xyz, r^2 (wave-uniform)
+    uint4 bq[kSets];
+    float adj[kSets], ee[kSets];
+#pragma unroll
+    for (int m = 0; m < kSets; ++m) {
+      uint32_t px, py, pz;
+      float vx, vy, vz;
+      split_bf16(-2.0f * (qx[m] - tc.x), px, vx);
+      split_bf16(-2.0f * (qy[m] - tc.y), py, vy);
+      split_bf16(-2.0f * (qz[m] - tc.z), pz, vz);
+      const float cx = -0.5f * vx, cy = -0.5f * vy, cz = -0.5f * vz;  // the quantised qc'
+      const float qq = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, cx * cx));
+      ee[m] = __builtin_fmaf(7.62939453125e-06f, qq + tc.w, 7.5231638e-37f);  // 2^-17 (|qc'|^2 + r^2) + 2^-120
+      unsafe = unsafe || !(ee[m] < 1.0e37f);                                    // inf / NaN bound: exact scan instead
+      const uint32_t bias = (__float_as_uint(__builtin_fmaf(2.0f, ee[m], qq)) + 0xFFFFu) >> 16;  // bf16, rounded up
+      adj[m] = qq - bf16_value(bias);  // s = MFMA + adj
+      const uint32_t w0 = hi ? pz : px;
+      bq[m] = make_uint4(w0, w0, hi ? 0x3F803F80u : py, hi ? (0x00003F80u | (bias << 16)) : py);
+    }
+    const uint4* __restrict__ A = lds[cur] + (hi ? kTile : 0) + (lane & 31u);
+    const uint4* __restrict__ next = image + static_cast<size_t>(tile + 1) * kXbTileVecs;
+    // Two accumulator sets in flight over the tile's 32 MFMA blocks, one MFMA then the 8 integer minima of an EARLIER
+    // result, alternating in program order: a wave's next MFMA waits at the vector issue port until the matrix pipe
+    // is free (32 cycles), and anything behind it - including the other resident wave's VALU work - waits with it, so
+    // MFMAs issued back to back serialise the two pipes (measured: 38 ms per 2^40 pairs that way, the figure in
+    // DESIGN.md with this schedule).  The loop is kept rolled (unrolled, hipcc hoists every MFMA of a chunk ahead of
+    // the minima and spills their 512 results) and the order is pinned with sched_group_barrier.
+    f32x16 acc_a[kSets], acc_b[kSets];
+    {
+      const uint4 a = A[0];
+#pragma unroll
+      for (int m = 0; m < kSets; ++m)
+        acc_a[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq[m]), zero, 0, 0, 0);
+    }
+    uint32_t cmin[kSets];
+#pragma unroll
+    for (int m = 0; m < kSets; ++m) cmin[m] = 0x7F800000u;
+    uint4 p0, p1;
+    if (more) {  // a quarter of the next tile rides along with each chunk
+      p0 = next[tid];
+      p1 = next[kBlockThreads + tid];
+    }
+    u32x4 frag_b = load_frag(A + 32), frag_a = load_frag(A + 64);  // operands of the NEXT iteration's MFMAs, read one iteration ahead
+#pragma unroll 1
+    for (uint32_t pair = 0; pair < kTile / 64; ++pair) {
+      u32x4 use_b = frag_b, use_a = frag_a;
+      // blocks past the tile's last one do not exist: earlier blocks are read again and their results dropped
+      frag_b = load_frag(A + ((2 * pair + 3) & (kTile / 32 - 1)) * 32);
+      frag_a = load_frag(A + ((2 * pair + 4) & (kTile / 32 - 1)) * 32);
+      // MI355_PIN: an empty asm that "rewrites" the next MFMA's operand, the accumulator the next minima read and the
+      // previous minimum - so step m (one MFMA + 8 minima) can start only when step m - 1's minima are done, which is
+      // the alternation the comment above asks for, expressed as data flow the scheduler cannot undo.
+#pragma unroll
+      for (int m = 0; m < kSets; ++m) {
+        MI355_PIN(use_b, acc_a[m], cmin[(m + kSets - 1) % kSets]);
+        acc_b[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, use_b), __builtin_bit_cast(bf16x8, bq[m]), zero, 0, 0, 0);
+        cmin[m] = min16(acc_a[m], cmin[m]);
+      }
+#pragma unroll
+      for (int m = 0; m < kSets; ++m) {
+        MI355_PIN(use_a, acc_b[m], cmin[(m + kSets - 1) % kSets]);
+        acc_a[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, use_a), __builtin_bit_cast(bf16x8, bq[m]), zero, 0, 0, 0);
+        cmin[m] = min16(acc_b[m], cmin[m]);
+      }
+      if ((pair & 3u) == 3u) {
+        const uint32_t c = pair >> 2;  // 4 pairs of blocks per 256-target chunk
+        const uint32_t run = ((tile * kXbChunksPerTile + c) << 1) | (hi ? 1u : 0u);
+#pragma unroll
+        for (int m = 0; m < kSets; ++m) {
+          const float s = __uint_as_float(cmin[m]) + adj[m];
+          const float lo = __builtin_fmaxf((s - ee[m]) * 0.99902f, 0.0f);
+          cmin[m] = 0x7F800000u;
+          // once the scan has passed a point's neighbourhood its three best granules rarely change: the sorted insert
+          // (12 selects) is skipped unless some lane of the wave needs it
+          if (__builtin_amdgcn_ballot_w64(lo < l3[m]) != 0) {
+            const float o1 = l1[m], o2 = l2[m], o3 = l3[m];
+            const uint32_t i1 = c1[m], i2 = c2[m], i3 = c3[m];
+            const bool d1 = lo < o1, d2 = lo < o2, d3 = lo < o3;
+            const float keep3 = d3 ? lo : o3, keep2 = d2 ? lo : o2;
+            const uint32_t keepi3 = d3 ? run : i3, keepi2 = d2 ? run : i2;
+            l3[m] = d2 ? o2 : keep3;
+            c3[m] = d2 ? i2 : keepi3;
+            l2[m] = d1 ? o1 : keep2;
+            c2[m] = d1 ? i1 : keepi2;
+            l1[m] = d1 ? lo : o1;
+            c1[m] = d1 ? run : i1;
+          }
+        }
+        if (more) {
+          lds[cur ^ 1][c * 2 * kBlockThreads + tid] = p0;
+          lds[cur ^ 1][(c * 2 + 1) * kBlockThreads + tid] = p1;
+          if (c + 1 < kXbChunksPerTile) {
+            p0 = next[(c + 1) * 2 * kBlockThreads + tid];
+            p1 = next[((c + 1) * 2 + 1) * kBlockThreads + tid];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // each wave half publishes its own key row: rows 2 sp (lanes 0-31) and 2 sp + 1 (lanes 32-63)
+  const size_t out = static_cast<size_t>(2 * sp + (hi ? 1u : 0u)) * key_stride + J.out_off + sb * kScanSrcPerBlock + src_local;
+#pragma unroll
+  for (int m = 0; m < kSets; ++m) {
+    const size_t o = out + m * 32;
+    const float w1 = unsafe ? 0.0f : l1[m], w2 = unsafe ? 0.0f : l2[m], w3 = unsafe ? 0.0f : l3[m];
+    keys4[o] = (static_cast<unsigned long long>(__float_as_uint(w1)) << 32) | c1[m];
+    keys4[rank_stride + o] = (static_cast<unsigned long long>(__float_as_uint(w2)) << 32) | c2[m];
+    keys4[2 * static_cast<size_t>(rank_stride) + o] = (static_cast<unsigned long long>(__float_as_uint(w3)) << 32) | c3[m];
+  }
+}
+
+// a workgroup spans 512 source points (kSets = 4, the planner's 2 points per lane)
+void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
+                          const void* bf_image, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
+                          uint32_t rank_stride) {
+  if (!max_blocks_x) return;
+  dim3 grid(max_blocks_x, static_cast<uint32_t>(n_jobs));
+  if (getenv("MI355_ICP_DIAG_OCC")) {
+    int nb = -1;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nn_scan_xbf16_kernel<4>, kBlockThreads, 0);
+    fprintf(stderr, "xbf16 occupancy: %d workgroups per CU (%s), grid %u x %d\n", nb, hipGetErrorString(e), max_blocks_x, n_jobs);
+  }
+  hipLaunchKernelGGL(nn_scan_xbf16_kernel<4>, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x, src.y,
+                     src.z, static_cast<const uint4*>(bf_image), static_cast<const float4*>(tile_table), keys4, key_stride,
+                     rank_stride);
 }
 
 // points_per_lane selects the workgroup's source span exactly as for the VALU kernel (256 * ppl = 128 * kSets points)

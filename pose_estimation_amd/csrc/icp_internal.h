@@ -20,6 +20,23 @@ constexpr int kChunksPerTile = kTile / kChunk;
 constexpr float kTargetPad = 3.0e38f;                    // coordinate of padding targets: d2 overflows to +inf
 constexpr int kFusedChunk = 64;                          // granule of the fused-filter scan (icp_fused_kernels.hip)
 constexpr int kFusedChunksPerTile = kTile / kFusedChunk;
+// split-bf16 matrix-core filter (nn_scan_xbf16_kernel): a 256-target chunk is 8 MFMA blocks of 32 rows; each half of a
+// wave owns the rows of one contiguous 128-target run, which is the granule the scan remembers and the resolve re-scans
+constexpr int kXbChunk = 256;
+constexpr int kXbChunksPerTile = kTile / kXbChunk;
+constexpr int kXbRun = 128;
+constexpr int kXbTileVecs = 2 * kTile;                   // uint4 per tile of the bf16 operand image: [k half][row slot]
+
+#if defined(__HIPCC__)
+// bfloat16 pieces of a float32 (round to nearest even; NaN stays NaN, +-inf stays +-inf).  x ~ hi + lo with
+// |x - (hi + lo)| <= 2^-16 |x|; the filters' bounds are written for whatever (hi, lo) these return.
+__device__ __forceinline__ uint32_t bf16_bits(float x) {
+  const uint32_t u = __float_as_uint(x);
+  const uint32_t r = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+  return x != x ? 0x7FC0u : r;
+}
+__device__ __forceinline__ float bf16_value(uint32_t bits) { return __uint_as_float(bits << 16); }
+#endif
 
 // One alignment job as the kernels see it (read with scalar loads; 112 bytes).
 struct JobDesc {
@@ -98,10 +115,14 @@ void launch_nn_scan_xmfma(void* stream, int points_per_lane, const JobDesc* jobs
                           uint32_t first_block, DevicePlanes src, const float* tcx, const float* tcy, const float* tcz,
                           const float* tt, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
                           uint32_t rank_stride);
-void launch_resolve_xfilter(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
-                            DevicePlanes sorted_original, const uint32_t* perm, const unsigned long long* keys4,
-                            uint32_t key_stride, uint32_t rank_stride, int32_t* out_index, float* out_dist2,
-                            uint32_t* overflow_list, uint32_t* overflow_count, uint32_t* error_flag);
+void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
+                          const void* bf_image, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
+                          uint32_t rank_stride);
+// run_len: targets per remembered granule (kFusedChunk, or kXbRun with two key rows per split: split_mul = 2)
+void launch_resolve_xfilter(void* stream, int run_len, uint32_t split_mul, const JobDesc* jobs_dev, int n_jobs,
+                            uint32_t max_src_blocks, DevicePlanes src, DevicePlanes sorted_original, const uint32_t* perm,
+                            const unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride, int32_t* out_index,
+                            float* out_dist2, uint32_t* overflow_list, uint32_t* overflow_count, uint32_t* error_flag);
 void launch_accumulate(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
                        DevicePlanes tgt, const int32_t* index, const float* dist2, double* partials);
 void launch_gather_points(void* stream, DevicePlanes src, uint32_t src_off, const uint32_t* list, uint32_t n, float* out_planes,
@@ -130,9 +151,9 @@ void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, 
 int xtarget_sort_temp_bytes(uint32_t n, size_t* bytes);
 int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const float* box, uint32_t* code,
                         uint32_t* index, uint32_t* code2, uint32_t* order, void* temp, size_t temp_bytes, float* xt,
-                        size_t stride, uint32_t* perm, float* table);
+                        size_t stride, uint32_t* perm, float* table, void* bf_image);
 void launch_bbox(void* stream, DevicePlanes planes, const uint32_t* cloud_off, const uint32_t* cloud_n, int n_clouds, float* box);
-void launch_xt_fill(void* stream, float* xt, size_t stride, uint32_t* perm);
+void launch_xt_fill(void* stream, float* xt, size_t stride, uint32_t* perm, void* bf_image);
 
 // ---- scene normals (normals_kernels.hip) ----
 constexpr int kMaxNormalNeighbors = 32;

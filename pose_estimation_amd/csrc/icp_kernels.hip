@@ -482,85 +482,121 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_fused_kernel(
   }
 }
 
-// Exact half of the expansion-filter path (nn_scan_xfilter_kernel).  keys4: three smallest lower bounds L (with chunk id)
-// and the smallest upper bound U per split; candidates are the chunks with L <= U_min.  The re-scan reads the SORTED
-// copy of the original coordinates (so, soy, soz: sorted order, uncentred) and maps positions back through perm; ties
-// are resolved on the ORIGINAL index, which is what the oracle's lowest-index rule refers to.
+// Exact half of the expansion-filter paths (nn_scan_xfilter_kernel, nn_scan_xbf16_kernel).  keys4: the three smallest
+// lower bounds L (with granule id) per key row.  The re-scan reads the SORTED copy of the original coordinates (sox, soy,
+// soz: sorted order, uncentred) and maps positions back through perm; ties are resolved on the ORIGINAL index, which is
+// what the oracle's lowest-index rule refers to.
+//
+// Wave-cooperative: each lane first merges the key rows of its own source point; then the wave takes its (up to) 64
+// points one at a time and its 64 lanes read the candidate granule side by side - 256 contiguous bytes per plane per
+// load instead of 64 scattered lines - compute the exact contract distance, and reduce (d2, original index)
+// lexicographically across the wave.
+//
+// Granule 1 (smallest lower bound) is always re-scanned; its exact minimum d* then decides: granule 2 is needed iff
+// L2 <= d* (<=: an exact tie with a lower original index could sit there), and if afterwards L3 <= d*, a fourth granule
+// the scan did not keep could matter too - only then does the all-exact scan answer (overflow list).
+// Wave-wide unsigned minimum as a scalar.  Four DPP butterfly steps inside each row of 16 lanes (xor 1, xor 2, then the
+// two mirrors, which pair equal-valued groups just as xor 4 and xor 8 would), then the four row results are read into
+// SGPRs.  All 64 lanes must be active.  (A __shfl_xor butterfly is six dependent LDS round trips: ~10x the latency.)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  uint32_t o;
+  o = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+  v = o < v ? o : v;
+  o = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+  v = o < v ? o : v;
+  o = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v = o < v ? o : v;
+  o = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x140, 0xF, 0xF, false));  // row_mirror
+  v = o < v ? o : v;
+  const uint32_t r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+  const uint32_t r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+  const uint32_t a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+  return a < b ? a : b;
+}
+
+template <int kRun>  // targets per remembered granule: kFusedChunk (VALU filter) or kXbRun (matrix-core filter)
 __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
-    const JobDesc* __restrict__ jobs, const float* __restrict__ sx, const float* __restrict__ sy,
+    const JobDesc* __restrict__ jobs, uint32_t split_mul, const float* __restrict__ sx, const float* __restrict__ sy,
     const float* __restrict__ sz, const float* __restrict__ sox, const float* __restrict__ soy,
     const float* __restrict__ soz, const uint32_t* __restrict__ perm, const unsigned long long* __restrict__ keys4,
     uint32_t key_stride, uint32_t rank_stride, int32_t* __restrict__ out_index, float* __restrict__ out_dist2,
-    uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ overflow_count, uint32_t* __restrict__ error_flag) {
+    uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ overflow_count) {
+  static_assert(kRun % 64 == 0, "a granule is read 64 targets at a time");
   const JobDesc& J = jobs[blockIdx.y];
-  const uint32_t sb = blockIdx.x;
-  if (sb >= J.src_blocks) return;
+  if (blockIdx.x * kBlockThreads >= J.src_n) return;  // grid.x covers the largest job in groups of 256 points
   float pose[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
-  const uint32_t n_split = J.n_split;
-#pragma unroll 1
-  for (int p = 0; p < kResolvePointsPerLane; ++p) {
-    const uint32_t local = sb * kSrcPerBlock + p * kBlockThreads + threadIdx.x;
-    if (local >= J.src_n) continue;
+  const uint32_t n_rows = J.n_split * split_mul;  // key rows: one per split (two for the matrix-core filter's wave halves)
+  const uint32_t lane = threadIdx.x & 63u;
+  {
+    const uint32_t local = blockIdx.x * kBlockThreads + threadIdx.x;
+    const bool valid = local < J.src_n;
     unsigned long long k1 = ~0ull, k2 = ~0ull, k3 = ~0ull;
-    float umin = __builtin_inff();
-    for (uint32_t sp = 0; sp < n_split; ++sp) {
-      const size_t base = static_cast<size_t>(sp) * key_stride + J.out_off + local;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (valid) {
+      for (uint32_t row = 0; row < n_rows; ++row) {
+        const size_t base = static_cast<size_t>(row) * key_stride + J.out_off + local;
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const unsigned long long k = keys4[static_cast<size_t>(r) * rank_stride + base];
-        const bool l1 = k < k1, l2 = k < k2, l3 = k < k3;
-        k3 = l2 ? k2 : (l3 ? k : k3);
-        k2 = l1 ? k1 : (l2 ? k : k2);
-        k1 = l1 ? k : k1;
-      }
-      umin = __builtin_fminf(umin, __uint_as_float(static_cast<uint32_t>(keys4[3 * static_cast<size_t>(rank_stride) + base] >> 32)));
-    }
-    const bool in2 = __uint_as_float(static_cast<uint32_t>(k2 >> 32)) <= umin;
-    const bool in3 = __uint_as_float(static_cast<uint32_t>(k3 >> 32)) <= umin;
-    if (in3 || !(umin < __builtin_inff())) {  // too many candidate chunks, or no finite bound: the exact scan answers
-      const uint32_t pos = atomicAdd(&overflow_count[blockIdx.y], 1u);
-      overflow_list[J.out_off + pos] = local;
-      continue;
-    }
-    const uint32_t i = J.src_off + local;
-    float qx, qy, qz;
-    transform_point(pose, sx[i], sy[i], sz[i], qx, qy, qz);
-    float best = __builtin_inff();
-    uint32_t best_j = 0xFFFFFFFFu;
-    const int n_cand = in2 ? 2 : 1;
-    for (int cnd = 0; cnd < n_cand; ++cnd) {
-      const uint32_t chunk = static_cast<uint32_t>(cnd == 0 ? k1 : k2);
-      const uint32_t tbase = J.tgt_off + chunk * kFusedChunk;
-      const float4* __restrict__ gx = reinterpret_cast<const float4*>(sox + tbase);
-      const float4* __restrict__ gy = reinterpret_cast<const float4*>(soy + tbase);
-      const float4* __restrict__ gz = reinterpret_cast<const float4*>(soz + tbase);
-      const uint4* __restrict__ gp = reinterpret_cast<const uint4*>(perm + tbase);
-#pragma unroll 4
-      for (int g = 0; g < kFusedChunk / 4; ++g) {
-        const float4 X = gx[g], Y = gy[g], Z = gz[g];
-        const uint4 Pm = gp[g];
-        const float xs[4] = {X.x, X.y, X.z, X.w};
-        const float ys[4] = {Y.x, Y.y, Y.z, Y.w};
-        const float zs[4] = {Z.x, Z.y, Z.z, Z.w};
-        const uint32_t js[4] = {Pm.x, Pm.y, Pm.z, Pm.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float d = dist2(qx, qy, qz, xs[e], ys[e], zs[e]);
-          if (d < best || (d == best && js[e] < best_j)) {
-            best = d;
-            best_j = js[e];
-          }
+        for (int r = 0; r < 3; ++r) {
+          const unsigned long long k = keys4[static_cast<size_t>(r) * rank_stride + base];
+          const bool l1 = k < k1, l2 = k < k2, l3 = k < k3;
+          k3 = l2 ? k2 : (l3 ? k : k3);
+          k2 = l1 ? k1 : (l2 ? k : k2);
+          k1 = l1 ? k : k1;
         }
       }
+      const uint32_t i = J.src_off + local;
+      transform_point(pose, sx[i], sy[i], sz[i], qx, qy, qz);
     }
-    if (best_j == 0xFFFFFFFFu) {
-      atomicOr(error_flag, 1u);
-      best_j = 0;
+    const uint32_t g1 = static_cast<uint32_t>(k1), g2 = static_cast<uint32_t>(k2);
+    const float L2 = __uint_as_float(static_cast<uint32_t>(k2 >> 32)), L3 = __uint_as_float(static_cast<uint32_t>(k3 >> 32));
+    uint32_t res_d = 0x7F800000u, res_j = 0xFFFFFFFFu;  // d2 as bits: exact distances are >= +0, so unsigned order is float order
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+    while (todo) {
+      const int s = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const float ax = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(qx), s));
+      const float ay = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(qy), s));
+      const float az = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(qz), s));
+      const float l2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(L2), s));
+      uint32_t best_d = 0x7F800000u, best_j = 0xFFFFFFFFu;
+      for (int cnd = 0; cnd < 2; ++cnd) {
+        if (cnd == 1 && !(l2 <= __uint_as_float(best_d))) break;
+        const uint32_t granule = __builtin_amdgcn_readlane(cnd == 0 ? g1 : g2, s);
+        const uint32_t tbase = J.tgt_off + granule * kRun + lane;
+        float md = __builtin_inff();
+        uint32_t mj = 0xFFFFFFFFu;
+#pragma unroll
+        for (int it = 0; it < kRun / 64; ++it) {
+          const uint32_t t = tbase + it * 64;
+          const float d = dist2(ax, ay, az, sox[t], soy[t], soz[t]);
+          const uint32_t j = perm[t];
+          if (d < md || (d == md && j < mj)) {
+            md = d;
+            mj = j;
+          }
+        }
+        const uint32_t ud = wave_min_u32(__float_as_uint(md));  // md is never NaN (d < md is false for NaN) nor negative
+        const uint32_t uj = wave_min_u32(__float_as_uint(md) == ud ? mj : 0xFFFFFFFFu);
+        if (ud < best_d || (ud == best_d && uj < best_j)) {
+          best_d = ud;
+          best_j = uj;
+        }
+      }
+      if (lane == static_cast<uint32_t>(s)) {
+        res_d = best_d;
+        res_j = best_j;
+      }
     }
-    out_index[J.out_off + local] = static_cast<int32_t>(best_j);
-    out_dist2[J.out_off + local] = best;
+    if (!valid) return;
+    if (L3 <= __uint_as_float(res_d) || res_j == 0xFFFFFFFFu) {  // a third candidate granule (or more), or nothing finite found
+      const uint32_t pos = atomicAdd(&overflow_count[blockIdx.y], 1u);
+      overflow_list[J.out_off + pos] = local;
+      return;
+    }
+    out_index[J.out_off + local] = static_cast<int32_t>(res_j);
+    out_dist2[J.out_off + local] = __uint_as_float(res_d);
   }
 }
 
@@ -720,14 +756,21 @@ void launch_resolve_fused(void* stream, const JobDesc* jobs_dev, int n_jobs, uin
                      overflow_count, error_flag);
 }
 
-void launch_resolve_xfilter(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
-                            DevicePlanes sorted_original, const uint32_t* perm, const unsigned long long* keys4,
-                            uint32_t key_stride, uint32_t rank_stride, int32_t* out_index, float* out_dist2,
-                            uint32_t* overflow_list, uint32_t* overflow_count, uint32_t* error_flag) {
-  dim3 grid(max_src_blocks, static_cast<uint32_t>(n_jobs));
-  hipLaunchKernelGGL(resolve_xfilter_kernel, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x,
-                     src.y, src.z, sorted_original.x, sorted_original.y, sorted_original.z, perm, keys4, key_stride, rank_stride,
-                     out_index, out_dist2, overflow_list, overflow_count, error_flag);
+void launch_resolve_xfilter(void* stream, int run_len, uint32_t split_mul, const JobDesc* jobs_dev, int n_jobs,
+                            uint32_t max_src_blocks, DevicePlanes src, DevicePlanes sorted_original, const uint32_t* perm,
+                            const unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride, int32_t* out_index,
+                            float* out_dist2, uint32_t* overflow_list, uint32_t* overflow_count, uint32_t* error_flag) {
+  dim3 grid(max_src_blocks * kResolvePointsPerLane, static_cast<uint32_t>(n_jobs));  // one workgroup per 256 points
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (run_len == kXbRun)
+    hipLaunchKernelGGL(resolve_xfilter_kernel<kXbRun>, grid, dim3(kBlockThreads), 0, st, jobs_dev, split_mul, src.x, src.y, src.z,
+                       sorted_original.x, sorted_original.y, sorted_original.z, perm, keys4, key_stride, rank_stride, out_index,
+                       out_dist2, overflow_list, overflow_count);
+  else
+    hipLaunchKernelGGL(resolve_xfilter_kernel<kFusedChunk>, grid, dim3(kBlockThreads), 0, st, jobs_dev, split_mul, src.x, src.y,
+                       src.z, sorted_original.x, sorted_original.y, sorted_original.z, perm, keys4, key_stride, rank_stride,
+                       out_index, out_dist2, overflow_list, overflow_count);
+  (void)error_flag;  // a point with no finite distance goes to the all-exact scan, which raises the flag
 }
 
 void launch_accumulate(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,

@@ -9,7 +9,9 @@
 //   <rocPRIM>        stable radix sort of (code, index)
 //   centre_kernel    one workgroup per 1024-point tile: tile box -> centre c; tc = fl(t - c) (the float32 subtraction the
 //                    bound is written for), tt = fl(|tc|^2) from double, r^2 = max |tc|^2 rounded up; also the sorted
-//                    copy of the original coordinates and the sorted-position -> original-index table
+//                    copy of the original coordinates, the sorted-position -> original-index table, and the bf16
+//                    operand image of the matrix-core filter (nn_scan_xbf16_kernel): tc quantised to two bfloat16
+//                    pieces per coordinate, |tc'|^2 of the QUANTISED point in three, laid out as MFMA A fragments
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __re
                                                                 const float* __restrict__ pz, uint32_t off, uint32_t n,
                                                                 const uint32_t* __restrict__ order, float* __restrict__ xt,
                                                                 size_t stride, uint32_t* __restrict__ perm,
-                                                                float* __restrict__ table) {
+                                                                float* __restrict__ table, uint4* __restrict__ bf_image) {
   __shared__ float slo[4][3], shi[4][3];
   __shared__ double sr2[4];
   const uint32_t t0 = blockIdx.x * kTile;
@@ -149,6 +151,26 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __re
       tcx[6 * stride + s] = z[k];
       perm[off + s] = src[k];
       r2 = n2 > r2 ? n2 : r2;
+      // matrix-core operand image.  Row slot of sorted position w inside its tile: chunk c = w / 256; the chunk's two
+      // 128-target runs belong to the two halves of the wave (hh); within a run, 16 consecutive targets are the rows
+      // 8j + 4hh + k (j, k < 4) of MFMA block blk - exactly the rows whose results land in lanes of half hh.
+      const uint32_t w = k * kBlockThreads + threadIdx.x;
+      const uint32_t cc = w >> 8, hh = (w >> 7) & 1u, u = w & 127u;
+      const uint32_t slot = (cc * 8 + (u >> 4)) * 32 + 8 * ((u >> 2) & 3u) + 4 * hh + (u & 3u);
+      const uint32_t hx = bf16_bits(dx), hy = bf16_bits(dy), hz = bf16_bits(dz);
+      const uint32_t lx = bf16_bits(dx - bf16_value(hx)), ly = bf16_bits(dy - bf16_value(hy)), lz = bf16_bits(dz - bf16_value(hz));
+      const double qx = static_cast<double>(bf16_value(hx)) + bf16_value(lx), qy = static_cast<double>(bf16_value(hy)) + bf16_value(ly),
+                   qz = static_cast<double>(bf16_value(hz)) + bf16_value(lz);
+      const double n2q = qx * qx + qy * qy + qz * qz;
+      const float ttq = static_cast<float>(n2q);
+      const uint32_t t1 = bf16_bits(ttq);
+      const float rem1 = ttq - bf16_value(t1);
+      const uint32_t t2 = bf16_bits(rem1);
+      const uint32_t t3 = bf16_bits(rem1 - bf16_value(t2));
+      uint4* img = bf_image + static_cast<size_t>((off + t0) / kTile) * kXbTileVecs;
+      img[slot] = make_uint4(hx | (hx << 16), lx | (lx << 16), hy | (hy << 16), ly | (ly << 16));
+      img[kTile + slot] = make_uint4(hz | (hz << 16), lz | (lz << 16), t1 | (t2 << 16), t3 | 0x3F800000u);  // slot 15: 1.0 (bias row)
+      r2 = n2q > r2 ? n2q : r2;
     }
   }
 #pragma unroll
@@ -169,9 +191,14 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __re
 }
 
 // fills the padding of all seven planes and the perm table before the per-cloud kernels run
-__global__ __launch_bounds__(kBlockThreads) void xt_fill_kernel(float* __restrict__ xt, size_t stride, uint32_t* __restrict__ perm) {
+__global__ __launch_bounds__(kBlockThreads) void xt_fill_kernel(float* __restrict__ xt, size_t stride, uint32_t* __restrict__ perm,
+                                                                 uint4* __restrict__ bf_image) {
   const size_t i = static_cast<size_t>(blockIdx.x) * kBlockThreads + threadIdx.x;
   if (i >= stride) return;
+  // padding row of the matrix-core image: |tc'|^2 = +inf (bf16 0x7F80), everything else zero
+  const size_t tile = i / kTile, slot = i % kTile;
+  bf_image[tile * kXbTileVecs + slot] = make_uint4(0u, 0u, 0u, 0u);
+  bf_image[tile * kXbTileVecs + kTile + slot] = make_uint4(0u, 0u, 0x7F80u, 0x3F800000u);
   xt[i] = 0.f;
   xt[stride + i] = 0.f;
   xt[2 * stride + i] = 0.f;
@@ -193,7 +220,7 @@ int xtarget_sort_temp_bytes(uint32_t n, size_t* bytes) {
 // Enqueues the whole build for one cloud on `stream`.  code/index/code2/order: n entries each; temp: sort scratch.
 int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const float* box, uint32_t* code,
                         uint32_t* index, uint32_t* code2, uint32_t* order, void* temp, size_t temp_bytes, float* xt,
-                        size_t stride, uint32_t* perm, float* table) {
+                        size_t stride, uint32_t* perm, float* table, void* bf_image) {
   if (!n) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(morton_kernel, dim3((n + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, st, planes.x, planes.y,
@@ -201,7 +228,7 @@ int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_
   size_t tb = temp_bytes;
   if (rocprim::radix_sort_pairs(temp, tb, code, code2, index, order, n, 0, 30, st, false) != hipSuccess) return 1;
   hipLaunchKernelGGL(centre_kernel, dim3((n + kTile - 1) / kTile), dim3(kBlockThreads), 0, st, planes.x, planes.y, planes.z, off, n,
-                     order, xt, stride, perm, table);
+                     order, xt, stride, perm, table, static_cast<uint4*>(bf_image));
   return 0;
 }
 
@@ -210,9 +237,9 @@ void launch_bbox(void* stream, DevicePlanes planes, const uint32_t* cloud_off, c
                      planes.y, planes.z, cloud_off, cloud_n, box);
 }
 
-void launch_xt_fill(void* stream, float* xt, size_t stride, uint32_t* perm) {
+void launch_xt_fill(void* stream, float* xt, size_t stride, uint32_t* perm, void* bf_image) {
   hipLaunchKernelGGL(xt_fill_kernel, dim3(static_cast<uint32_t>((stride + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0,
-                     static_cast<hipStream_t>(stream), xt, stride, perm);
+                     static_cast<hipStream_t>(stream), xt, stride, perm, static_cast<uint4*>(bf_image));
 }
 
 }  // namespace mi355

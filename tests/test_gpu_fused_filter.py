@@ -14,7 +14,7 @@ import synth_twin as st
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["fused", "xfilter", "xmfma", "xhybrid"])
+@pytest.fixture(scope="module", params=["fused", "xfilter", "xmfma", "xhybrid", "xbf16"])
 def fused(request):
     import pose_estimation_amd as pa
     old = os.environ.get("MI355_ICP_SCAN_MODE")

@@ -1,0 +1,90 @@
+// ubench_bf16_min.hip — what one step of nn_scan_xbf16_kernel costs: a v_mfma_f32_32x32x16_bf16 (fresh accumulator)
+// plus the unsigned minimum over the 16 results of an EARLIER MFMA, at 1 and 2 waves per SIMD.
+//   M: MFMA only   V2: 16 v_min_u32 only   V3: the v_min_u32 / v_min3_u32 mix hipcc makes of the same tree   B2/B3: MFMA + minima alternating
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t m3(uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t t = a < b ? a : b;
+  return t < c ? t : c;
+}
+// kPlain: 16 two-operand minima as hipcc mixes them (v_min_u32 / v_min3_u32); otherwise the 8-deep v_min3_u32 tree
+template <bool kPlain>
+__device__ __forceinline__ uint32_t min16(const f32x16& acc, uint32_t seed) {
+  uint32_t b[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) b[k] = __float_as_uint(acc[k]);
+  if (!kPlain) {
+    const uint32_t t0 = m3(b[0], b[1], b[2]), t1 = m3(b[3], b[4], b[5]), t2 = m3(b[6], b[7], b[8]), t3 = m3(b[9], b[10], b[11]);
+    const uint32_t t4 = m3(b[12], b[13], b[14]), t5 = m3(b[15], t0, t1), t6 = m3(t2, t3, t4);
+    return m3(t5, t6, seed);
+  }
+#pragma unroll
+  for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+    for (int k = 0; k < w; ++k) b[k] = b[k] < b[k + w] ? b[k] : b[k + w];
+  return b[0] < seed ? b[0] : seed;
+}
+
+template <int MODE>  // 0 M, 1 V2, 2 V3, 3 B2, 4 B3
+__global__ __launch_bounds__(256, 2) void k(float* out, int iters, const u32x4* in) {
+  f32x16 acc[4];
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[m][i] = threadIdx.x + i + m;
+  u32x4 fa = in[threadIdx.x], fb = in[threadIdx.x + 256];
+  uint32_t cm[4] = {0x7F800000u, 0x7F800000u, 0x7F800000u, 0x7F800000u};
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (MODE == 3 || MODE == 4) asm volatile("" : "+v"(fa), "+v"(acc[(m + 2) & 3]), "+v"(cm[(m + 3) & 3]));
+      if (MODE == 0 || MODE == 3 || MODE == 4)
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), zero, 0, 0, 0);
+      if (MODE == 1 || MODE == 3) cm[m] = min16<true>(acc[(m + 2) & 3], cm[m]);
+      if (MODE == 2 || MODE == 4) cm[m] = min16<false>(acc[(m + 2) & 3], cm[m]);
+      if (MODE == 1 || MODE == 2) asm volatile("" : "+v"(acc[(m + 2) & 3]));  // keep the minima in the loop
+    }
+  }
+  float s = 0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) s += acc[m][0] + acc[m][7] + __uint_as_float(cm[m]);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int MODE>
+float run(float* out, const u32x4* in, int grid, int iters) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  k<MODE><<<grid, 256>>>(out, iters / 4, in);
+  (void)hipEventRecord(e0);
+  k<MODE><<<grid, 256>>>(out, iters, in);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms;
+}
+
+int main() {
+  float* out;
+  u32x4* in;
+  if (hipMalloc(&out, sizeof(float) * 256 * 8 * 256) != hipSuccess || hipMalloc(&in, 16 * 512) != hipSuccess) return 1;
+  (void)hipMemset(in, 0x3c, 16 * 512);
+  const int iters = 100000;  // x 4 steps
+  for (int wps : {1, 2, 3}) {
+    const int grid = 256 * wps;
+    const float m = run<0>(out, in, grid, iters), v2 = run<1>(out, in, grid, iters), v3 = run<2>(out, in, grid, iters);
+    const float b2 = run<3>(out, in, grid, iters), b3 = run<4>(out, in, grid, iters);
+    const double steps = 4.0 * iters * wps;  // steps per SIMD
+    auto cyc = [&](float ms) { return ms * 1e-3 * 2.4e9 / steps; };
+    printf("waves/SIMD=%d  cycles per step per SIMD at 2.4 GHz:  (MFMA only %.1f) | pairwise tree (hipcc: min/min3 mix) %.1f | 8 v_min3_u32 %.1f | MFMA + mix %.1f | MFMA + 8 v_min3_u32 %.1f\n",
+           wps, cyc(m), cyc(v2), cyc(v3), cyc(b2), cyc(b3));
+  }
+  return 0;
+}
