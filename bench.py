@@ -22,9 +22,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (vector)" (= f32 MFMA dense peak)
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide, "BF16/F16 ~2.5 PF dense"
 HBM_PEAK_GBS = 8000.0             # same guide, HBM3E spec
 FLOP_PER_PAIR = 8                 # 3 sub + 3 mul + 2 add (SURVEY.md 8d FLOP model; the min is not counted)
-SCAN_KERNEL = "nn_scan_xfilter_kernel (expansion filter, 4 issue slots per pair) + exact resolve"
+PEAK_CLOCK_HZ = 2.4e9
+N_SIMD = 256 * 4
+
+# The dominant kernel by scan mode (csrc/icp_engine.hip make_plan_on; MI355_ICP_SCAN_MODE forces one).  Each entry:
+# kernel, roofline bound, peak (TFLOP/s), flop EXECUTED per evaluated pair on that unit, vector-issue slots per pair.
+SCAN_MODELS = {
+    "xbf16": ("nn_scan_xbf16_kernel (split-bf16 expansion filter on the matrix cores) + exact resolve", "mfma",
+              BF16_MFMA_PEAK_TFLOPS, 32.0, 9.0 / 1024.0,
+              "Every pair is evaluated by one K=16 bf16 MFMA contraction (32 flop per pair: the expansion surrogate of "
+              "points quantised to two bfloat16 pieces per coordinate) and one vector issue slot per 128 pairs per lane for "
+              "the minimum (8 v_min3_u32 + the MFMA issue per 1024 pairs, 4 cycles each: the binding resource, see "
+              "roofline_issue); the exact unfused float32 formula then decides inside the one or two candidate granules, "
+              "so indices and distances stay bit-identical to the oracle (DESIGN.md 3.1). `achieved` counts the 32 executed "
+              "MFMA flop per pair; by SURVEY 8d's 8-flop model the same run is `model_tflops`, above the FP32 vector peak "
+              "(157.3) that model was priced against."),
+    "xfilter": ("nn_scan_xfilter_kernel (expansion filter, 4 VALU issue slots per pair) + exact resolve", "valu",
+                FP32_VECTOR_PEAK_TFLOPS, 6.0, 4.0 / 64.0,
+                "FP32 vector ALU bound: 3 fma + 1 min per pair on tile-centred coordinates; exact resolve as above."),
+    "fused": ("nn_scan_fused_kernel (7 VALU issue slots per pair) + exact resolve", "valu", FP32_VECTOR_PEAK_TFLOPS, 8.0, 7.0 / 64.0,
+              "FP32 vector ALU bound: 3 sub + 1 mul + 2 fma + 1 min per pair."),
+    "exact": ("nn_scan_kernel (all-exact, 9 VALU issue slots per pair)", "valu", FP32_VECTOR_PEAK_TFLOPS, 8.0, 9.0 / 64.0,
+              "FP32 vector ALU bound: the unfused contract formula, 3 sub + 3 mul + 2 add + 1 min per pair."),
+}
 
 
 def parse():
@@ -149,7 +172,7 @@ def main():
     traffic, traffic_note = None, None
     try:  # PMC counters cannot be read from inside this process; use the committed rocprofv3 pass of this same command
         tj = json.load(open(os.path.join(ROOT, "profiles", "scan_traffic.json")))
-        if ns_local == (1 << 20) and nt == (1 << 20):
+        if ns_local == (1 << 20) and nt == (1 << 20) and not os.environ.get("MI355_ICP_SCAN_MODE"):
             traffic, traffic_note = tj["traffic_bytes_per_launch"], f"profiles/scan_traffic.json ({tj['tag']}): {tj['method']}"
     except Exception:
         pass
@@ -158,6 +181,8 @@ def main():
         scan_ms = prof.nn_scan_ms / max(prof.nn_scan_launches, 1)
         pairs_launch = float(count) * float(nt)
         alg_bytes = 12.0 * count + 12.0 * nt + 8.0 * count   # read both clouds once, write index + d2
+        mode = os.environ.get("MI355_ICP_SCAN_MODE", "") or ("xbf16" if pairs_launch >= 1e9 else "exact")
+        kernel, bound, peak, exec_flop, slots_per_pair, note = SCAN_MODELS.get(mode, SCAN_MODELS["xfilter"])
         out = {
             "metric": "correspondence_pairs_per_sec", "value": pairs_step * a.steps / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
@@ -169,21 +194,24 @@ def main():
                        "n_source_total": ns_total, "n_target": nt, "source_points_per_gpu": ns_local,
                        "collective": collective, "pair_definition": "one (source,target) distance evaluation: Ns*Nt*iterations"},
             "roofline": {
-                "bound": "valu", "kernel": SCAN_KERNEL,
-                "achieved": FLOP_PER_PAIR * pairs_launch / (scan_ms * 1e-3) / 1e12, "peak": FP32_VECTOR_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": FLOP_PER_PAIR * pairs_launch / (scan_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                "bound": bound, "kernel": kernel,
+                "achieved": exec_flop * pairs_launch / (scan_ms * 1e-3) / 1e12, "peak": peak,
+                "unit": "TFLOP/s", "frac": exec_flop * pairs_launch / (scan_ms * 1e-3) / 1e12 / peak,
                 "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_note,
-                "algorithmic_flop_per_launch": FLOP_PER_PAIR * pairs_launch,
-                "avg_launch_ms": scan_ms, "launches": int(prof.nn_scan_launches),
-                "note": "FP32 vector ALU bound. FLOP are counted by the SURVEY 8d model (8 per evaluated pair). The dominant "
-                        "kernel evaluates every pair with the expansion surrogate |qc|^2 + |tc|^2 - 2 qc.tc on tile-centred "
-                        "coordinates (3 fma + 1 min = 4 issue slots, i.e. 6 executed FLOP per pair: attainable 16/8 model-FLOP per "
-                        "slot-pair = 100% of 157.3 by this count); the exact unfused formula (9 slots) then decides inside the one "
-                        "or two candidate chunks, so indices and distances stay bit-identical to the oracle; DESIGN.md 3.1",
-                "executed_flop_per_pair": 6,
+                "algorithmic_flop_per_launch": exec_flop * pairs_launch, "flop_per_pair": exec_flop,
+                "model_flop_per_pair": FLOP_PER_PAIR, "model_tflops": FLOP_PER_PAIR * pairs_launch / (scan_ms * 1e-3) / 1e12,
+                "avg_launch_ms": scan_ms, "launches": int(prof.nn_scan_launches), "note": note,
+            },
+            "roofline_issue": {
+                "bound": "vector issue port", "unit": "pairs/s", "achieved": pairs_launch / (scan_ms * 1e-3),
+                "peak": N_SIMD * PEAK_CLOCK_HZ / (4.0 * slots_per_pair) if mode == "xbf16" else N_SIMD * PEAK_CLOCK_HZ / (2.0 * slots_per_pair),
+                "frac": pairs_launch / (scan_ms * 1e-3) / (N_SIMD * PEAK_CLOCK_HZ / ((4.0 if mode == "xbf16" else 2.0) * slots_per_pair)),
+                "note": "vector instructions per evaluated pair x cycles per wave-instruction (integer and MFMA issue: 4, "
+                        "float32: 2 with >= 2 waves per SIMD; tools/ubench_valu.hip, tools/ubench_bf16_min.hip) at 2.4 GHz on "
+                        "1024 SIMDs; the chip holds 2.0-2.3 GHz under this load",
             },
             "roofline_hbm": {
-                "bound": "hbm", "kernel": SCAN_KERNEL, "achieved": alg_bytes / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": kernel, "achieved": alg_bytes / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": alg_bytes / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "north_star asks for the HBM figure; the scan is compute-bound by ~4 orders of magnitude (DESIGN.md)",

@@ -68,6 +68,7 @@ struct Plan {
   bool xfilter = false;        // expansion-filter scan on the sorted/centred target copy (largest launches); implies fused
   int xkind = 0;               // 0 VALU kernel, 1 f32 MFMA kernel, 2 both side by side, 3 split-bf16 MFMA kernel
   uint32_t key_rows() const { return (xkind == 3 ? 2u : 1u) * max_split; }  // key rows per rank (wave halves publish separately)
+  uint32_t key_ranks() const { return xfilter && xkind != 3 ? 4u : 3u; }       // the VALU expansion kernels also publish U
 };
 
 uint32_t env_u32(const char* name, uint32_t dflt) {
@@ -262,7 +263,7 @@ int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs) {
   }
   if ((st = grow(c, c->partials, c->partials_cap, static_cast<size_t>(std::max<uint32_t>(plan.partial_total, 1)) * MI355_ICP_NSUMS)) != MI355_ICP_OK) return st;
   if (plan.fused) {
-    if ((st = grow(c, c->keys3, c->keys3_cap, (plan.xfilter ? 4 : 3) * static_cast<size_t>(plan.key_rows()) * plan.out_total)) != MI355_ICP_OK) return st;
+    if ((st = grow(c, c->keys3, c->keys3_cap, plan.key_ranks() * static_cast<size_t>(plan.key_rows()) * plan.out_total)) != MI355_ICP_OK) return st;
     if ((st = grow(c, c->overflow_list, c->overflow_list_cap, std::max<size_t>(plan.out_total, 1))) != MI355_ICP_OK) return st;
     if (n_jobs > c->overflow_jobs_cap) {
       if (c->overflow_count) { HIP_TRY(c, hipFree(c->overflow_count)); c->overflow_count = nullptr; }
@@ -580,7 +581,7 @@ int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, boo
   // never launch against a buffer the planner did not size for this launch shape (an out-of-bounds kernel can take the GPU down)
   const size_t key_need = static_cast<size_t>(plan.fused ? plan.key_rows() : plan.max_split) * plan.out_total;
   if (plan.out_total > c->out_cap || static_cast<size_t>(plan.partial_total) * MI355_ICP_NSUMS > c->partials_cap ||
-      (plan.fused ? ((plan.xfilter ? 4 : 3) * key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : key_need > c->keys_cap))
+      (plan.fused ? (plan.key_ranks() * key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : key_need > c->keys_cap))
     return fail(c, MI355_ICP_ERR_INTERNAL, "work buffers are smaller than the plan (ensure_buffers not run for this plan)");
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (plan.fused) {
@@ -695,7 +696,7 @@ int run_ref_pass(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, fl
   }
   const DevicePlanes S = level_view(c->sources, level), T = level_view(c->targets, level);
   const size_t ref_key_need = static_cast<size_t>(plan.fused ? plan.key_rows() : plan.max_split) * plan.out_total;
-  if ((plan.fused ? ((plan.xfilter ? 4 : 3) * ref_key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : ref_key_need > c->keys_cap) ||
+  if ((plan.fused ? (plan.key_ranks() * ref_key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : ref_key_need > c->keys_cap) ||
       plan.out_total > c->out_cap || plan.out_total > c->selected_cap || owner_total > c->owner_cap ||
       static_cast<size_t>(plan.partial_total) * kRefSums > c->ref_partials_cap ||
       static_cast<size_t>(plan.partial_total) * MI355_ICP_NSUMS > c->partials_cap)

@@ -659,16 +659,15 @@ __global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xbf16_kernel(const J
       p0 = next[tid];
       p1 = next[kBlockThreads + tid];
     }
-    u32x4 frag_b = load_frag(A + 32), frag_a = load_frag(A + 64);  // operands of the NEXT iteration's MFMAs, read one iteration ahead
-#pragma unroll 1
-    for (uint32_t pair = 0; pair < kTile / 64; ++pair) {
-      u32x4 use_b = frag_b, use_a = frag_a;
+    // operands of the NEXT step's MFMAs are read one step ahead, into two register sets used alternately (no copies)
+    u32x4 f0_b = load_frag(A + 32), f0_a = load_frag(A + 64), f1_b, f1_a;
+    // MI355_PIN: an empty asm that "rewrites" the next MFMA's operand, the accumulator the next minima read and the
+    // previous minimum - so step m (one MFMA + 8 minima) can start only when step m - 1's minima are done, which is
+    // the alternation the comment above asks for, expressed as data flow the scheduler cannot undo.
+    auto step = [&](uint32_t pair, u32x4& use_b, u32x4& use_a, u32x4& next_b, u32x4& next_a) {
       // blocks past the tile's last one do not exist: earlier blocks are read again and their results dropped
-      frag_b = load_frag(A + ((2 * pair + 3) & (kTile / 32 - 1)) * 32);
-      frag_a = load_frag(A + ((2 * pair + 4) & (kTile / 32 - 1)) * 32);
-      // MI355_PIN: an empty asm that "rewrites" the next MFMA's operand, the accumulator the next minima read and the
-      // previous minimum - so step m (one MFMA + 8 minima) can start only when step m - 1's minima are done, which is
-      // the alternation the comment above asks for, expressed as data flow the scheduler cannot undo.
+      next_b = load_frag(A + ((2 * pair + 3) & (kTile / 32 - 1)) * 32);
+      next_a = load_frag(A + ((2 * pair + 4) & (kTile / 32 - 1)) * 32);
 #pragma unroll
       for (int m = 0; m < kSets; ++m) {
         MI355_PIN(use_b, acc_a[m], cmin[(m + kSets - 1) % kSets]);
@@ -681,8 +680,13 @@ __global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xbf16_kernel(const J
         acc_a[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, use_a), __builtin_bit_cast(bf16x8, bq[m]), zero, 0, 0, 0);
         cmin[m] = min16(acc_b[m], cmin[m]);
       }
-      if ((pair & 3u) == 3u) {
-        const uint32_t c = pair >> 2;  // 4 pairs of blocks per 256-target chunk
+    };
+#pragma unroll 1
+    for (uint32_t pair = 0; pair < kTile / 64; pair += 2) {
+      step(pair, f0_b, f0_a, f1_b, f1_a);
+      step(pair + 1, f1_b, f1_a, f0_b, f0_a);
+      if ((pair & 2u) != 0) {  // a 256-target chunk = 4 pairs of blocks
+        const uint32_t c = pair >> 2;
         const uint32_t run = ((tile * kXbChunksPerTile + c) << 1) | (hi ? 1u : 0u);
 #pragma unroll
         for (int m = 0; m < kSets; ++m) {

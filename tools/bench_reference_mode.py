@@ -28,7 +28,7 @@ def run(name, ns, nt, inits, check=True):
     with pa.IcpEngine(0) as eng:
         eng.set_targets([tgt])
         eng.set_sources([src])
-        eng.align_reference(inits[:1], 8, 0.005, 2.5, 8)  # warm-up, builds the pyramid
+        eng.align_reference(inits, 8, 0.005, 2.5, 8)  # warm-up with the same batch: builds the pyramid, sizes the work buffers
         eng.set_profiling(True)
         eng.reset_profile()
         t0 = time.perf_counter()

@@ -15,7 +15,7 @@ for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
 lines = [f"rocprofv3 PMC summary, tag {tag}: per-kernel mean of each counter over its dispatches",
          "(separate --pmc passes; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them; on gfx950 FETCH_SIZE counts",
          " half of a wide coalesced read: double it before comparing with bytes - MI355X_MICROARCH.md HBM section)", ""]
-for name in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
+for name in ("pmc_sq", "pmc_sq2", "pmc_lds", "pmc_fetch", "pmc_write"):
     for f in glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
@@ -33,15 +33,16 @@ import json
 fetch = write = None
 for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     for f in glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")):
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-                if "nn_scan" in r["Kernel_Name"] and r["Counter_Name"] == key]
+        rows = list(csv.DictReader(open(f)))
+        dominant = "nn_scan_xbf16" if any("nn_scan_xbf16" in r["Kernel_Name"] for r in rows) else "nn_scan"
+        vals = [float(r["Counter_Value"]) for r in rows if dominant in r["Kernel_Name"] and r["Counter_Name"] == key]
         if vals:
             if key == "FETCH_SIZE":
                 fetch = sum(vals) / len(vals)
             else:
                 write = sum(vals) / len(vals)
 if fetch is not None and write is not None:
-    json.dump({"tag": tag, "kernel": "the filter scan bench.py's default workload launches (nn_scan_xfilter_kernel)", "workload": "bench.py default (1048576x1048576, 1 GPU)",
+    json.dump({"tag": tag, "kernel": "the filter scan bench.py's default workload launches (nn_scan_xbf16_kernel)", "workload": "bench.py default (1048576x1048576, 1 GPU)",
                "fetch_size_kib_per_launch": fetch, "write_size_kib_per_launch": write,
                "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"},
