@@ -31,10 +31,23 @@ struct CloudEntry {
   uint32_t padded;  // slots occupied
 };
 
+// Expansion-filter copy of a group of target clouds (built on demand, xtarget_kernels.hip): Morton-sorted, centred per
+// 1024-point tile.  planes: tcx | tcy | tcz | tt | sox | soy | soz, each `stride` floats; perm: sorted position ->
+// original index; table: per tile (centre x, y, z, r^2); bf: bf16 operand image of the matrix-core filter
+// (kXbTileVecs uint4 per tile).
+struct XCopy {
+  float* planes = nullptr;
+  uint32_t* perm = nullptr;
+  float* table = nullptr;
+  void* bf = nullptr;
+  bool valid = false;
+};
+
 struct LevelPlanes {  // compacted copy of every cloud of a set at pyramid level l >= 1 (rows 0, step, 2*step, ...)
   float* planes = nullptr;
   size_t stride = 0;
   std::vector<CloudEntry> clouds;
+  XCopy xt;  // targets only
   DevicePlanes view() const { return DevicePlanes{planes, planes + stride, planes + 2 * stride}; }
 };
 
@@ -44,14 +57,7 @@ struct CloudSet {
   size_t stride = 0;
   std::vector<CloudEntry> clouds;
   std::vector<LevelPlanes> levels;  // levels[l - 1] = level l, built on demand by reference mode
-  // expansion-filter copy of the clouds (targets only, built on demand): Morton-sorted, centred per 1024-point tile.
-  // planes: tcx | tcy | tcz | tt | sox | soy | soz, each `stride` floats; perm: sorted position -> original index;
-  // table: per tile (centre x, y, z, r^2)
-  float* xt_planes = nullptr;
-  uint32_t* xt_perm = nullptr;
-  float* xt_table = nullptr;
-  void* xt_bf = nullptr;     // bf16 operand image of the matrix-core filter: kXbTileVecs uint4 per tile
-  bool xt_valid = false;
+  XCopy xt;  // level-0 expansion-filter copy (targets only)
   DevicePlanes view() const { return DevicePlanes{planes, planes + stride, planes + 2 * stride}; }
   DevicePlanes normal_view() const { return DevicePlanes{normals, normals + stride, normals + 2 * stride}; }
 };
@@ -70,6 +76,14 @@ struct Plan {
   uint32_t key_rows() const { return (xkind == 3 ? 2u : 1u) * max_split; }  // key rows per rank (wave halves publish separately)
   uint32_t key_ranks() const { return xfilter && xkind != 3 ? 4u : 3u; }       // the VALU expansion kernels also publish U
 };
+
+void free_xcopy(XCopy& x) {  // the caller has drained the stream
+  (void)hipFree(x.planes);
+  (void)hipFree(x.perm);
+  (void)hipFree(x.table);
+  (void)hipFree(x.bf);
+  x = XCopy{};
+}
 
 uint32_t env_u32(const char* name, uint32_t dflt) {
   const char* v = std::getenv(name);
@@ -219,14 +233,12 @@ int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* co
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (set.planes) { HIP_TRY(c, hipFree(set.planes)); set.planes = nullptr; }
   if (set.normals) { HIP_TRY(c, hipFree(set.normals)); set.normals = nullptr; }
-  for (auto& lv : set.levels)
+  for (auto& lv : set.levels) {
     if (lv.planes) HIP_TRY(c, hipFree(lv.planes));
+    free_xcopy(lv.xt);
+  }
   set.levels.clear();
-  if (set.xt_planes) { HIP_TRY(c, hipFree(set.xt_planes)); set.xt_planes = nullptr; }
-  if (set.xt_perm) { HIP_TRY(c, hipFree(set.xt_perm)); set.xt_perm = nullptr; }
-  if (set.xt_table) { HIP_TRY(c, hipFree(set.xt_table)); set.xt_table = nullptr; }
-  if (set.xt_bf) { HIP_TRY(c, hipFree(set.xt_bf)); set.xt_bf = nullptr; }
-  set.xt_valid = false;
+  free_xcopy(set.xt);
   set.clouds.clear();
   HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.planes), 3 * stride * sizeof(float)));
   HIP_TRY(c, hipMemcpy(set.planes, host.data(), 3 * stride * sizeof(float), hipMemcpyHostToDevice));
@@ -461,18 +473,17 @@ int run_overflow_fallback(mi355_icp_ctx* c, const Plan& plan, int n_active, cons
   return MI355_ICP_OK;
 }
 
-// Builds, on the device, the expansion-filter copy of every target cloud (see CloudSet::xt_* and xtarget_kernels.hip).
+// Builds, on the device, the expansion-filter copy of a group of target clouds (XCopy, xtarget_kernels.hip).
 // Everything is enqueued on the engine's stream; the scan that follows on the same stream sees it complete.
-int ensure_xtarget(mi355_icp_ctx* c, CloudSet& set) {
-  if (set.xt_valid) return MI355_ICP_OK;
-  const size_t stride = set.stride;
-  const int n_clouds = static_cast<int>(set.clouds.size());
+int ensure_xcopy(mi355_icp_ctx* c, DevicePlanes view, size_t stride, const std::vector<CloudEntry>& clouds, XCopy& x) {
+  if (x.valid) return MI355_ICP_OK;
+  const int n_clouds = static_cast<int>(clouds.size());
   uint32_t max_n = 1;
   std::vector<uint32_t> meta(2 * static_cast<size_t>(n_clouds));
   for (int k = 0; k < n_clouds; ++k) {
-    meta[k] = set.clouds[k].off;
-    meta[n_clouds + k] = set.clouds[k].n;
-    max_n = std::max(max_n, set.clouds[k].n);
+    meta[k] = clouds[k].off;
+    meta[n_clouds + k] = clouds[k].n;
+    max_n = std::max(max_n, clouds[k].n);
   }
   size_t temp_bytes = 0;
   if (xtarget_sort_temp_bytes(max_n, &temp_bytes) != 0) return fail(c, MI355_ICP_ERR_HIP, "rocprim::radix_sort_pairs (size query) failed");
@@ -480,10 +491,10 @@ int ensure_xtarget(mi355_icp_ctx* c, CloudSet& set) {
   if ((st = grow(c, c->xt_scratch, c->xt_scratch_cap, 4 * static_cast<size_t>(max_n) + 2 * static_cast<size_t>(n_clouds))) != MI355_ICP_OK) return st;
   if ((st = grow(c, c->xt_box, c->xt_box_cap, 6 * static_cast<size_t>(n_clouds))) != MI355_ICP_OK) return st;
   if ((st = grow(c, c->xt_temp, c->xt_temp_cap, temp_bytes + 16)) != MI355_ICP_OK) return st;
-  if (!set.xt_planes) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.xt_planes), 7 * stride * sizeof(float)));
-  if (!set.xt_perm) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.xt_perm), stride * sizeof(uint32_t)));
-  if (!set.xt_table) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.xt_table), 4 * (stride / kTile) * sizeof(float)));
-  if (!set.xt_bf) HIP_TRY(c, hipMalloc(&set.xt_bf, (stride / kTile) * static_cast<size_t>(kXbTileVecs) * 16));
+  if (!x.planes) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.planes), 7 * stride * sizeof(float)));
+  if (!x.perm) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.perm), stride * sizeof(uint32_t)));
+  if (!x.table) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.table), 4 * (stride / kTile) * sizeof(float)));
+  if (!x.bf) HIP_TRY(c, hipMalloc(&x.bf, (stride / kTile) * static_cast<size_t>(kXbTileVecs) * 16));
   uint32_t* code = c->xt_scratch;
   uint32_t* index = code + max_n;
   uint32_t* code2 = index + max_n;
@@ -491,36 +502,45 @@ int ensure_xtarget(mi355_icp_ctx* c, CloudSet& set) {
   uint32_t* meta_dev = order + max_n;
   HIP_TRY(c, hipMemcpyAsync(meta_dev, meta.data(), meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // `meta` is a pageable temporary
-  launch_xt_fill(c->stream, set.xt_planes, stride, set.xt_perm, set.xt_bf);
-  HIP_TRY(c, hipMemsetAsync(set.xt_table, 0, 4 * (stride / kTile) * sizeof(float), c->stream));
-  launch_bbox(c->stream, set.view(), meta_dev, meta_dev + n_clouds, n_clouds, c->xt_box);
+  launch_xt_fill(c->stream, x.planes, stride, x.perm, x.bf);
+  HIP_TRY(c, hipMemsetAsync(x.table, 0, 4 * (stride / kTile) * sizeof(float), c->stream));
+  launch_bbox(c->stream, view, meta_dev, meta_dev + n_clouds, n_clouds, c->xt_box);
   for (int k = 0; k < n_clouds; ++k)
-    if (xtarget_build_cloud(c->stream, set.view(), set.clouds[k].off, set.clouds[k].n, c->xt_box + 6 * k, code, index, code2, order,
-                            c->xt_temp, temp_bytes, set.xt_planes, stride, set.xt_perm, set.xt_table, set.xt_bf) != 0)
+    if (xtarget_build_cloud(c->stream, view, clouds[k].off, clouds[k].n, c->xt_box + 6 * k, code, index, code2, order, c->xt_temp,
+                            temp_bytes, x.planes, stride, x.perm, x.table, x.bf) != 0)
       return fail(c, MI355_ICP_ERR_HIP, "rocprim::radix_sort_pairs failed");
   HIP_TRY(c, hipGetLastError());
-  set.xt_valid = true;
+  x.valid = true;
   return MI355_ICP_OK;
 }
+
+int ensure_xtarget(mi355_icp_ctx* c, CloudSet& set) { return ensure_xcopy(c, set.view(), set.stride, set.clouds, set.xt); }
 
 // Fused-filter path up to "index and dist2 of every point are final": filter scan -> exact resolve of the candidate
 // chunks -> (rarely) the all-exact scan for points whose candidates overflowed the band.  Records ev[1] after the scan.
 int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint32_t bx, uint32_t sbx, DevicePlanes S,
                           DevicePlanes T, bool profile) {
   const uint32_t rank_stride = plan.key_rows() * plan.out_total;
-  const CloudSet& X = c->targets;
-  const bool xf = plan.xfilter && X.xt_valid && T.x == X.planes;  // only for the level-0 targets the copy was built from
+  // the expansion-filter copy that was built from exactly these target planes (level 0 or a pyramid level), if any
+  const XCopy* Xp = nullptr;
+  size_t xstride = 0;
+  if (T.x == c->targets.planes) { Xp = &c->targets.xt; xstride = c->targets.stride; }
+  for (const LevelPlanes& lv : c->targets.levels)
+    if (T.x == lv.planes) { Xp = &lv.xt; xstride = lv.stride; }
+  const bool xf = plan.xfilter && Xp && Xp->valid;
+  const XCopy none;
+  const XCopy& X = xf ? *Xp : none;
   if (xf) {
-    const float* xp = X.xt_planes;
-    const size_t st = X.stride;
+    const float* xp = X.planes;
+    const size_t st = xstride;
     const int ppl = plan.scan_ppl == 2 ? 2 : 4;  // the MFMA kernel spans 128 * {4, 8} points per workgroup
     if (bx && plan.xkind == 3) {
-      launch_nn_scan_xbf16(c->stream, c->jobs_dev, n_active, bx, S, X.xt_bf, X.xt_table, c->keys3, plan.out_total, rank_stride);
+      launch_nn_scan_xbf16(c->stream, c->jobs_dev, n_active, bx, S, X.bf, X.table, c->keys3, plan.out_total, rank_stride);
     } else if (bx && plan.xkind == 0) {
       launch_nn_scan_xfilter(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, xp, xp + st, xp + 2 * st, xp + 3 * st,
-                             X.xt_table, c->keys3, plan.out_total, rank_stride);
+                             X.table, c->keys3, plan.out_total, rank_stride);
     } else if (bx && plan.xkind == 1) {
-      launch_nn_scan_xmfma(c->stream, ppl, c->jobs_dev, n_active, bx, 0, S, xp, xp + st, xp + 2 * st, xp + 3 * st, X.xt_table,
+      launch_nn_scan_xmfma(c->stream, ppl, c->jobs_dev, n_active, bx, 0, S, xp, xp + st, xp + 2 * st, xp + 3 * st, X.table,
                            c->keys3, plan.out_total, rank_stride);
     } else if (bx) {
       // both pipes at once: scan blocks [0, first) on the vector ALU, [first, ...) on the matrix cores, in two streams
@@ -534,9 +554,9 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
       HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
       if (first)
         launch_nn_scan_xfilter(c->stream, ppl, c->jobs_dev, n_active, first * split, S, xp, xp + st, xp + 2 * st, xp + 3 * st,
-                               X.xt_table, c->keys3, plan.out_total, rank_stride);
+                               X.table, c->keys3, plan.out_total, rank_stride);
       launch_nn_scan_xmfma(c->stream2, ppl, c->jobs_dev, n_active, (max_scan_blocks - first) * split, first, S, xp, xp + st,
-                           xp + 2 * st, xp + 3 * st, X.xt_table, c->keys3, plan.out_total, rank_stride);
+                           xp + 2 * st, xp + 3 * st, X.table, c->keys3, plan.out_total, rank_stride);
       HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
       HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     }
@@ -546,10 +566,10 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
   HIP_TRY(c, hipMemsetAsync(c->overflow_count, 0, static_cast<size_t>(n_active) * sizeof(uint32_t), c->stream));
   if (sbx && xf) {
-    const float* xp = X.xt_planes;
-    const size_t st = X.stride;
+    const float* xp = X.planes;
+    const size_t st = xstride;
     const bool xb = plan.xkind == 3;
-    launch_resolve_xfilter(c->stream, xb ? kXbRun : kFusedChunk, xb ? 2u : 1u, c->jobs_dev, n_active, sbx, S, DevicePlanes{xp + 4 * st, xp + 5 * st, xp + 6 * st}, X.xt_perm,
+    launch_resolve_xfilter(c->stream, xb ? kXbRun : kFusedChunk, xb ? 2u : 1u, c->jobs_dev, n_active, sbx, S, DevicePlanes{xp + 4 * st, xp + 5 * st, xp + 6 * st}, X.perm,
                            c->keys3, plan.out_total, rank_stride, c->out_index, c->out_dist2, c->overflow_list, c->overflow_count,
                            c->error_flag);
   } else if (sbx) {
@@ -650,6 +670,13 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
     set.levels.push_back(lv);
   }
   return MI355_ICP_OK;
+}
+
+// the expansion-filter copy of pyramid level `level` of the targets (level 0: the uploaded clouds), built once per upload
+int ensure_level_xcopy(mi355_icp_ctx* c, CloudSet& set, int level) {
+  if (level == 0) return ensure_xtarget(c, set);
+  LevelPlanes& lv = set.levels[static_cast<size_t>(level) - 1];
+  return ensure_xcopy(c, lv.view(), lv.stride, lv.clouds, lv.xt);
 }
 
 const std::vector<CloudEntry>& level_clouds(const CloudSet& set, int level) { return level ? set.levels[level - 1].clouds : set.clouds; }
@@ -824,11 +851,11 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   for (CloudSet* set : {&c->targets, &c->sources}) {
     (void)hipFree(set->planes);
     (void)hipFree(set->normals);
-    for (auto& lv : set->levels) (void)hipFree(lv.planes);
-    (void)hipFree(set->xt_planes);
-    (void)hipFree(set->xt_perm);
-    (void)hipFree(set->xt_table);
-    (void)hipFree(set->xt_bf);
+    for (auto& lv : set->levels) {
+      (void)hipFree(lv.planes);
+      free_xcopy(lv.xt);
+    }
+    free_xcopy(set->xt);
   }
   (void)hipFree(c->scene[0]);
   (void)hipFree(c->scene[1]);
@@ -1029,7 +1056,7 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
       owner_total += level_clouds(c->targets, level)[ptid[a]].padded;
     }
     if ((st = ensure_ref_buffers(c, plan, static_cast<size_t>(np), owner_total)) != MI355_ICP_OK) return st;
-    if (level == 0 && plan.xfilter && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;  // coarser levels: fused filter
+    if (plan.xfilter && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
 
     const double tolp = static_cast<double>(rp->tolerance) * static_cast<double>(level + 1) * static_cast<double>(level + 1);
     const int maxit = static_cast<int>(std::floor(static_cast<double>(rp->iterations) / static_cast<double>(level + 1) + 0.5));
@@ -1117,7 +1144,7 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
   if ((st = ensure_buffers(c, plan, 1)) != MI355_ICP_OK) return st;
   const size_t owner_total = level_clouds(c->targets, level)[target_id].padded;
   if ((st = ensure_ref_buffers(c, plan, 1, owner_total)) != MI355_ICP_OK) return st;
-  if (level == 0 && plan.xfilter && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;
+  if (plan.xfilter && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
   JobDesc J = plan.jobs[0];
   RefJobDesc R{};
@@ -1319,14 +1346,12 @@ int mi355_icp_scene_commit_target(mi355_icp_ctx* c) {
   }
   if (set.planes) HIP_TRY(c, hipFree(set.planes));
   if (set.normals) { HIP_TRY(c, hipFree(set.normals)); set.normals = nullptr; }
-  for (auto& lv : set.levels)
+  for (auto& lv : set.levels) {
     if (lv.planes) HIP_TRY(c, hipFree(lv.planes));
+    free_xcopy(lv.xt);
+  }
   set.levels.clear();
-  if (set.xt_planes) { HIP_TRY(c, hipFree(set.xt_planes)); set.xt_planes = nullptr; }
-  if (set.xt_perm) { HIP_TRY(c, hipFree(set.xt_perm)); set.xt_perm = nullptr; }
-  if (set.xt_table) { HIP_TRY(c, hipFree(set.xt_table)); set.xt_table = nullptr; }
-  if (set.xt_bf) { HIP_TRY(c, hipFree(set.xt_bf)); set.xt_bf = nullptr; }
-  set.xt_valid = false;
+  free_xcopy(set.xt);
   set.planes = planes;
   set.stride = padded;
   set.clouds.assign(1, CloudEntry{0, n, padded});
