@@ -181,7 +181,7 @@ def main():
         scan_ms = prof.nn_scan_ms / max(prof.nn_scan_launches, 1)
         pairs_launch = float(count) * float(nt)
         alg_bytes = 12.0 * count + 12.0 * nt + 8.0 * count   # read both clouds once, write index + d2
-        mode = os.environ.get("MI355_ICP_SCAN_MODE", "") or ("xbf16" if pairs_launch >= 1e9 else "exact")
+        mode = os.environ.get("MI355_ICP_SCAN_MODE", "") or ("xbf16" if pairs_launch >= 2.5e8 else "exact")
         kernel, bound, peak, exec_flop, slots_per_pair, note = SCAN_MODELS.get(mode, SCAN_MODELS["xfilter"])
         out = {
             "metric": "correspondence_pairs_per_sec", "value": pairs_step * a.steps / elapsed, "unit": "pairs/s",

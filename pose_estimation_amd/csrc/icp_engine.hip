@@ -157,7 +157,7 @@ struct mi355_icp_ctx {
   uint32_t mfma_share_pct = 65;      // hybrid: per cent of the scan workgroups that run on the matrix cores
   hipStream_t stream2 = nullptr;     // hybrid: the MFMA workgroups are launched here, beside the VALU ones
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int scan_fused = -1;               // -1 auto (by pairs per launch: >= 1e9 the split-bf16 expansion filter), 0 exact, 1 fused, 2 xfilter,
+  int scan_fused = -1;               // -1 auto (by pairs per launch: >= 2.5e8 the split-bf16 expansion filter), 0 exact, 1 fused, 2 xfilter,
                                      // 3 xmfma, 4 xhybrid, 5 xbf16 (MI355_ICP_SCAN_MODE)
   // fused-filter path
   unsigned long long* keys3 = nullptr; size_t keys3_cap = 0;
@@ -330,14 +330,15 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   // makes the coarsest workgroups; below ~4e11 pairs per launch the finer 2-point workgroups balance the 256 CUs
   // better and win (profiles/r01b_scan_ab_sizes.txt: 1M<->1M 135 vs 141 ms; 64x50k<->50k 24.3 vs 21.5 ms).
   plan.scan_ppl = c->scan_ppl ? c->scan_ppl : (total_pairs >= 4e11 ? 8 : 2);
-  // The fused filter (7 issue slots per pair instead of 9, exact results by construction: icp_fused_kernels.hip) wins
-  // wherever the scan dominates the pass (profiles/r01h_scan_ab_fused_vs_exact.txt: +21 % at 1M<->1M, +17 % at
-  // 64x50k, +13 % at 100k<->100k); tiny launches keep the all-exact scan: its resolve re-scans half as many targets and
-  // it needs no overflow-count round trip to the host.
-  plan.fused = c->scan_fused < 0 ? total_pairs >= 1e9 : c->scan_fused >= 1;
-  // The expansion filter (4 issue slots per pair) needs a sorted, tile-centred copy of the targets, built on the device
-  // once per upload (~0.2 ms per 100k points): worth it as soon as the filter itself is.
-  plan.xfilter = c->scan_fused < 0 ? total_pairs >= 1e9 : c->scan_fused >= 2;
+  // A filter scan in front of the exact test (exact results by construction: icp_fused_kernels.hip) wins wherever the
+  // scan dominates the pass; tiny launches keep the all-exact scan, which needs no sorted copy of the targets and no
+  // overflow-count round trip to the host.  Threshold from profiles/r01o_planner_threshold.txt: with the matrix-core
+  // filter the pass is already 23 % shorter at 16k<->16k (2.7e8 pairs), 42 % at 32k<->32k.
+  constexpr double kFilterPairs = 2.5e8;
+  plan.fused = c->scan_fused < 0 ? total_pairs >= kFilterPairs : c->scan_fused >= 1;
+  // The expansion filters need a sorted, tile-centred copy of the targets, built on the device once per upload
+  // (~0.2 ms per 100k points): worth it as soon as the filter itself is.
+  plan.xfilter = c->scan_fused < 0 ? total_pairs >= kFilterPairs : c->scan_fused >= 2;
   // ... and the split-bf16 matrix-core form of it (xkind 3: one issue slot per pair, 2.3x the VALU filter end to end at
   // 100k<->100k, 1M<->1M and 64 x 50k<->50k: profiles/r01n_baseline_configs.jsonl) is the default wherever it applies
   plan.xkind = c->scan_fused < 0 ? 3 : (c->scan_fused >= 2 ? c->scan_fused - 2 : 0);

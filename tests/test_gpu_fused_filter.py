@@ -1,6 +1,6 @@
 """The filter scans (icp_fused_kernels.hip: the fused surrogate, and the expansion surrogate on the sorted/centred target
 copy) must give bit-identical results to the all-exact path and the oracle: each is forced on for every size here (the
-planner only picks them above 1e9 / 4e11 pairs), including data built to stress their error bands - near-ties spread
+planner only picks a filter above 2.5e8 pairs per launch), including data built to stress their error bands - near-ties spread
 over many chunks (overflow -> exact fallback), two-chunk near-ties, exact duplicates, lattices, clouds far from the
 origin (cancellation), subnormal and overflowing distances."""
 import os
