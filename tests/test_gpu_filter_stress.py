@@ -1,0 +1,68 @@
+"""Randomised A/B of the matrix-core filter path against the all-exact scan (both on the GPU, bit-for-bit): clouds of
+random size, scale (1e-4 .. 1e4), offset from the origin, anisotropy and clustering, under random rigid poses.  The
+exact engine is itself pinned to the oracle by test_gpu_parity.py; this battery is about the filter's error band
+(icp_fused_kernels.hip) on geometry the named tests do not cover.  MI355_ICP_STRESS_CASES raises the case count."""
+import os
+
+import numpy as np
+import pytest
+
+import synth_twin as st
+
+pytestmark = pytest.mark.gpu
+CASES = int(os.environ.get("MI355_ICP_STRESS_CASES", "24"))
+
+
+def engine_with_mode(mode):
+    import pose_estimation_amd as pa
+    old = os.environ.get("MI355_ICP_SCAN_MODE")
+    os.environ["MI355_ICP_SCAN_MODE"] = mode
+    try:
+        return pa.IcpEngine(0)
+    finally:
+        if old is None:
+            os.environ.pop("MI355_ICP_SCAN_MODE")
+        else:
+            os.environ["MI355_ICP_SCAN_MODE"] = old
+
+
+def random_cloud(rng, n):
+    kind = rng.integers(0, 4)
+    if kind == 0:      # volume
+        p = rng.standard_normal((n, 3))
+    elif kind == 1:    # surface of a bumpy sphere
+        u = rng.standard_normal((n, 3))
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        p = u * (1.0 + 0.1 * np.sin(5 * u[:, :1]) * np.cos(3 * u[:, 1:2]))
+    elif kind == 2:    # a few tight clusters far apart
+        centres = rng.standard_normal((rng.integers(2, 9), 3)) * 10.0
+        p = centres[rng.integers(0, len(centres), n)] + rng.standard_normal((n, 3)) * 0.01
+    else:              # jittered lattice: many near-ties
+        side = int(np.ceil(n ** (1 / 3)))
+        g = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n].astype(np.float64)
+        p = g + rng.standard_normal((n, 3)) * 1e-4
+    p = p * rng.uniform(0.2, 1.0, 3)                                   # anisotropy
+    p = p * 10.0 ** rng.uniform(-4, 4) + rng.standard_normal(3) * 10.0 ** rng.uniform(-2, 3)
+    return p.astype(np.float32)
+
+
+def test_matrix_core_filter_equals_the_exact_scan_on_random_geometry():
+    rng = np.random.default_rng(20261004)
+    with engine_with_mode("xbf16") as fast, engine_with_mode("exact") as exact:
+        for case in range(CASES):
+            ns, nt = int(rng.integers(100, 30000)), int(rng.integers(100, 60000))
+            tgt = random_cloud(rng, nt)
+            if rng.random() < 0.5:     # sources near the targets (the ICP situation) ...
+                src = (tgt[rng.integers(0, nt, ns)] * np.float32(1.0 + 1e-3 * rng.standard_normal())).astype(np.float32)
+                pose = st.rigid_transform(rng.uniform(0, 0.5), rng.standard_normal(3), rng.standard_normal(3) * 1e-3 * np.abs(tgt).max())
+            else:                       # ... or anywhere
+                src = random_cloud(rng, ns)
+                pose = st.rigid_transform(rng.uniform(0, 180), rng.standard_normal(3), rng.standard_normal(3))
+            out = []
+            for eng in (fast, exact):
+                eng.set_targets([tgt])
+                eng.set_sources([src])
+                out.append(eng.correspond(pose[None]))
+            assert np.array_equal(out[0][0], out[1][0]), f"case {case}: indices differ ({ns} x {nt})"
+            assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32)), f"case {case}: distances differ"
+            np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-11, atol=0)
