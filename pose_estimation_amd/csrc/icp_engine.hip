@@ -169,6 +169,9 @@ struct mi355_icp_ctx {
   JobDesc* jobs2_dev = nullptr;        JobDesc* jobs2_host = nullptr; size_t jobs2_cap = 0;
   uint64_t overflow_points_total = 0;  // statistics
   uint32_t target_blocks = 12288;    // planner: aim for about this many scan workgroups per launch
+  uint32_t target_blocks_mfma = 4096; // ... for the matrix-core filter: its workgroups span 512 points and publish two key
+                                     // rows per split, so fewer, longer ones cost less key traffic (100k<->100k: resolve
+                                     // 82 -> 35 us at equal scan time; profiles/r01o_target_blocks.txt)
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
 };
 
@@ -351,8 +354,9 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
     total_src_blocks += (src_clouds[source_ids ? source_ids[k] : 0].n + scan_src - 1) / scan_src;
   float max_d2 = std::numeric_limits<float>::infinity();
   if (max_corr > 0.0f) max_d2 = max_corr * max_corr;  // float32 product, as the oracle
+  const uint64_t blocks_goal = plan.xfilter && plan.xkind == 3 ? c->target_blocks_mfma : c->target_blocks;
   const uint32_t want_split = static_cast<uint32_t>(
-      std::max<uint64_t>(1, (c->target_blocks + std::max<uint64_t>(total_src_blocks, 1) - 1) / std::max<uint64_t>(total_src_blocks, 1)));
+      std::max<uint64_t>(1, (blocks_goal + std::max<uint64_t>(total_src_blocks, 1) - 1) / std::max<uint64_t>(total_src_blocks, 1)));
   uint64_t out_off = 0, partial_off = 0;
   for (int k = 0; k < n_jobs; ++k) {
     const CloudEntry& S = src_clouds[source_ids ? source_ids[k] : 0];
@@ -519,8 +523,11 @@ int ensure_xtarget(mi355_icp_ctx* c, CloudSet& set) { return ensure_xcopy(c, set
 
 // Fused-filter path up to "index and dist2 of every point are final": filter scan -> exact resolve of the candidate
 // chunks -> (rarely) the all-exact scan for points whose candidates overflowed the band.  Records ev[1] after the scan.
+// `defer`: the points the resolve could not settle are answered on the device (overflow_exact_kernel, up to kOverflowCap
+// per job) and the counts are only copied back, to be looked at after the pass's final synchronisation
+// (overflow_settled); otherwise the host reads the counts here and runs the gathered all-exact scan for them.
 int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint32_t bx, uint32_t sbx, DevicePlanes S,
-                          DevicePlanes T, bool profile) {
+                          DevicePlanes T, bool profile, bool defer) {
   const uint32_t rank_stride = plan.key_rows() * plan.out_total;
   // the expansion-filter copy that was built from exactly these target planes (level 0 or a pyramid level), if any
   const XCopy* Xp = nullptr;
@@ -579,6 +586,12 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
   }
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(c->overflow_count_host, c->overflow_count, static_cast<size_t>(n_active) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  if (defer) {
+    if (sbx) launch_overflow_exact(c->stream, c->jobs_dev, n_active, kOverflowCap, S, T, c->overflow_list, c->overflow_count, c->out_index,
+                                   c->out_dist2, c->error_flag);
+    HIP_TRY(c, hipGetLastError());
+    return MI355_ICP_OK;
+  }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   bool any = false;
   for (int k = 0; k < n_active; ++k) any = any || c->overflow_count_host[k] != 0;
@@ -586,9 +599,44 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
   return MI355_ICP_OK;
 }
 
+// After the final synchronisation of a pass that deferred its overflow handling: were all counts within what the device
+// pass covers?  (If not, the caller repeats the pass with the host path.)  Books the points either way.
+bool overflow_settled(mi355_icp_ctx* c, int n_active) {
+  bool ok = true;
+  for (int k = 0; k < n_active; ++k) ok = ok && c->overflow_count_host[k] <= kOverflowCap;
+  if (ok)
+    for (int k = 0; k < n_active; ++k) {
+      c->overflow_points_total += c->overflow_count_host[k];
+      c->prof.overflow_points += c->overflow_count_host[k];
+    }
+  return ok;
+}
+
+// The device-side pass streams the whole target cloud once per overflow point (12 B per target and point, out of L2 /
+// Infinity Cache).  That beats a host round trip + gathered tiled scan as long as the cloud is small: at 1M targets
+// and the ~250 points a pass leaves there, it costs 0.4 ms against 0.2 ms (profiles/r01o_overflow_paths.txt).
+bool defer_pays(const mi355_icp_ctx* c, int n_active) {
+  uint32_t tiles = 0;
+  for (int k = 0; k < n_active; ++k) tiles = std::max(tiles, c->jobs_host[k].tgt_tiles);
+  return tiles <= 256;
+}
+
+int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only, bool defer, bool* retry);
+
 // Enqueues one correspondence pass for the first n_active descriptors of jobs_host and leaves
 // their sums in sums_host (synchronises the stream).  `local_only` skips the collective.
 int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only) {
+  // with a communicator attached the collective sits between the kernels and the synchronisation, so a rank cannot
+  // repeat its pass afterwards: read the overflow counts first, as before
+  const bool defer = plan.fused && !(c->comm && !local_only) && defer_pays(c, n_active);
+  bool retry = false;
+  int st = run_pass_once(c, plan, n_active, profile, local_only, defer, &retry);
+  if (st == MI355_ICP_OK && retry) st = run_pass_once(c, plan, n_active, profile, local_only, false, &retry);
+  return st;
+}
+
+int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only, bool defer, bool* retry) {
+  *retry = false;
   HIP_TRY(c, hipMemcpyAsync(c->jobs_dev, c->jobs_host, static_cast<size_t>(n_active) * sizeof(JobDesc), hipMemcpyHostToDevice, c->stream));
   uint32_t bx = 0, sbx = 0;
   double pairs = 0.0;
@@ -606,7 +654,7 @@ int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, boo
     return fail(c, MI355_ICP_ERR_INTERNAL, "work buffers are smaller than the plan (ensure_buffers not run for this plan)");
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (plan.fused) {
-    const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile);
+    const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile, defer);
     if (fst != MI355_ICP_OK) return fst;
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if (sbx) launch_accumulate(c->stream, c->jobs_dev, n_active, sbx, S, T, c->out_index, c->out_dist2, c->partials);
@@ -626,6 +674,10 @@ int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, boo
   }
   HIP_TRY(c, hipMemcpyAsync(c->sums_host, c->sums_dev, static_cast<size_t>(n_active) * MI355_ICP_NSUMS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (defer && !overflow_settled(c, n_active)) {
+    *retry = true;
+    return MI355_ICP_OK;
+  }
   c->prof.iterations += 1;
   c->prof.pairs_evaluated += pairs;
   if (profile) {
@@ -710,8 +762,20 @@ int ensure_ref_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs, size_t
 
 // One reference-mode pass for the first n_active descriptors of jobs_host / rjobs_host on pyramid level `level`.
 // Leaves the 29 sums per job in ref_sums_host and the thresholds in thr_host (synchronises the stream).
+int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, float rejection_scale, size_t owner_total,
+                      bool profile, bool defer, bool* retry);
+
 int run_ref_pass(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, float rejection_scale, size_t owner_total,
                  bool profile) {
+  bool retry = false;
+  int st = run_ref_pass_once(c, plan, level, n_active, rejection_scale, owner_total, profile, plan.fused && defer_pays(c, n_active), &retry);
+  if (st == MI355_ICP_OK && retry) st = run_ref_pass_once(c, plan, level, n_active, rejection_scale, owner_total, profile, false, &retry);
+  return st;
+}
+
+int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, float rejection_scale, size_t owner_total,
+                      bool profile, bool defer, bool* retry) {
+  *retry = false;
   HIP_TRY(c, hipMemcpyAsync(c->jobs_dev, c->jobs_host, static_cast<size_t>(n_active) * sizeof(JobDesc), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->rjobs_dev, c->rjobs_host, static_cast<size_t>(n_active) * sizeof(RefJobDesc), hipMemcpyHostToDevice, c->stream));
   uint32_t bx = 0, sbx = 0;
@@ -731,7 +795,7 @@ int run_ref_pass(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, fl
     return fail(c, MI355_ICP_ERR_INTERNAL, "work buffers are smaller than the plan (reference mode)");
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (plan.fused) {
-    const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile);
+    const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile, defer);
     if (fst != MI355_ICP_OK) return fst;
   } else {
     if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
@@ -756,6 +820,10 @@ int run_ref_pass(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, fl
   HIP_TRY(c, hipMemcpyAsync(c->ref_sums_host, c->ref_sums_dev, static_cast<size_t>(n_active) * kRefSums * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->thr_host, c->thr_dev, static_cast<size_t>(n_active) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (defer && !overflow_settled(c, n_active)) {
+    *retry = true;
+    return MI355_ICP_OK;
+  }
   c->prof.iterations += 1;
   c->prof.pairs_evaluated += pairs;
   if (profile) {
@@ -819,6 +887,7 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
     if (c->scan_sgpr) c->scan_fused = 0;
   }
   c->target_blocks = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks);
+  c->target_blocks_mfma = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks_mfma);  // the same override serves A/B runs of either
   c->min_tiles_per_split = env_u32("MI355_ICP_MIN_TILES_PER_SPLIT", c->min_tiles_per_split);
   auto bail = [&](const char* what, hipError_t err) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(err);

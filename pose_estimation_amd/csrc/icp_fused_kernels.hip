@@ -17,9 +17,6 @@
 // therefore excluded from `make check-isa`.
 #include <hip/hip_runtime.h>
 
-#include <cstdio>
-#include <cstdlib>
-
 #include <cstdint>
 
 #include "icp_internal.h"
@@ -740,11 +737,6 @@ void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uin
                           uint32_t rank_stride) {
   if (!max_blocks_x) return;
   dim3 grid(max_blocks_x, static_cast<uint32_t>(n_jobs));
-  if (getenv("MI355_ICP_DIAG_OCC")) {
-    int nb = -1;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nn_scan_xbf16_kernel<4>, kBlockThreads, 0);
-    fprintf(stderr, "xbf16 occupancy: %d workgroups per CU (%s), grid %u x %d\n", nb, hipGetErrorString(e), max_blocks_x, n_jobs);
-  }
   hipLaunchKernelGGL(nn_scan_xbf16_kernel<4>, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x, src.y,
                      src.z, static_cast<const uint4*>(bf_image), static_cast<const float4*>(tile_table), keys4, key_stride,
                      rank_stride);

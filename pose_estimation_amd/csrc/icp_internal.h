@@ -123,6 +123,10 @@ void launch_resolve_xfilter(void* stream, int run_len, uint32_t split_mul, const
                             uint32_t max_src_blocks, DevicePlanes src, DevicePlanes sorted_original, const uint32_t* perm,
                             const unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride, int32_t* out_index,
                             float* out_dist2, uint32_t* overflow_list, uint32_t* overflow_count, uint32_t* error_flag);
+constexpr uint32_t kOverflowCap = 1024;  // overflow points per job the device-side exact pass takes without the host
+void launch_overflow_exact(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t cap, DevicePlanes src, DevicePlanes tgt,
+                           const uint32_t* overflow_list, const uint32_t* overflow_count, int32_t* out_index, float* out_dist2,
+                           uint32_t* error_flag);
 void launch_accumulate(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
                        DevicePlanes tgt, const int32_t* index, const float* dist2, double* partials);
 void launch_gather_points(void* stream, DevicePlanes src, uint32_t src_off, const uint32_t* list, uint32_t n, float* out_planes,

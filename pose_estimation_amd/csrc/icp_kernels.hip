@@ -31,6 +31,8 @@
 //     whose unsigned minimum is the lowest distance, then the lowest chunk.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdint>
 
 #include "icp_internal.h"
@@ -442,6 +444,10 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_fused_kernel(
     if (in3) {  // too many candidate chunks (or everything is +inf): let the exact scan answer
       const uint32_t pos = atomicAdd(&overflow_count[blockIdx.y], 1u);
       overflow_list[J.out_off + pos] = local;
+      // a valid placeholder: the kernels that follow in the stream must stay in bounds even if this point's answer only
+      // arrives after the host has looked at the counts (more than kOverflowCap points: the pass is repeated)
+      out_index[J.out_off + local] = 0;
+      out_dist2[J.out_off + local] = __builtin_inff();
       continue;
     }
     const uint32_t i = J.src_off + local;
@@ -552,51 +558,153 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
     const uint32_t g1 = static_cast<uint32_t>(k1), g2 = static_cast<uint32_t>(k2);
     const float L2 = __uint_as_float(static_cast<uint32_t>(k2 >> 32)), L3 = __uint_as_float(static_cast<uint32_t>(k3 >> 32));
     uint32_t res_d = 0x7F800000u, res_j = 0xFFFFFFFFu;  // d2 as bits: exact distances are >= +0, so unsigned order is float order
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
-    while (todo) {
-      const int s = __builtin_ctzll(todo);
-      todo &= todo - 1;
-      const float ax = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(qx), s));
-      const float ay = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(qy), s));
-      const float az = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(qz), s));
-      const float l2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(L2), s));
-      uint32_t best_d = 0x7F800000u, best_j = 0xFFFFFFFFu;
-      for (int cnd = 0; cnd < 2; ++cnd) {
-        if (cnd == 1 && !(l2 <= __uint_as_float(best_d))) break;
-        const uint32_t granule = __builtin_amdgcn_readlane(cnd == 0 ? g1 : g2, s);
-        const uint32_t tbase = J.tgt_off + granule * kRun + lane;
+    // Exact (d2, original index)-minimum of one granule for each of kN points (held by lanes s[k]); results are
+    // wave-uniform.  All loads of the step are issued before the first distance is computed, so the kN chains share
+    // one memory round trip.
+    auto scan_granules = [&](auto n_tag, const int* s, uint32_t granule_of_lane, uint32_t* ud, uint32_t* uj) {
+      constexpr int kN = decltype(n_tag)::value;
+      constexpr int kIt = kRun / 64;
+      float ax[kN], ay[kN], az[kN], X[kN][kIt], Y[kN][kIt], Z[kN][kIt];
+      uint32_t Pm[kN][kIt];
+#pragma unroll
+      for (int k = 0; k < kN; ++k) {
+        ax[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(qx), s[k]));
+        ay[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(qy), s[k]));
+        az[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(qz), s[k]));
+        const uint32_t tbase = J.tgt_off + __builtin_amdgcn_readlane(granule_of_lane, s[k]) * kRun + lane;
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+          X[k][it] = sox[tbase + it * 64];
+          Y[k][it] = soy[tbase + it * 64];
+          Z[k][it] = soz[tbase + it * 64];
+          Pm[k][it] = perm[tbase + it * 64];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kN; ++k) {
         float md = __builtin_inff();
         uint32_t mj = 0xFFFFFFFFu;
 #pragma unroll
-        for (int it = 0; it < kRun / 64; ++it) {
-          const uint32_t t = tbase + it * 64;
-          const float d = dist2(ax, ay, az, sox[t], soy[t], soz[t]);
-          const uint32_t j = perm[t];
-          if (d < md || (d == md && j < mj)) {
+        for (int it = 0; it < kIt; ++it) {
+          const float d = dist2(ax[k], ay[k], az[k], X[k][it], Y[k][it], Z[k][it]);
+          if (d < md || (d == md && Pm[k][it] < mj)) {
             md = d;
-            mj = j;
+            mj = Pm[k][it];
           }
         }
-        const uint32_t ud = wave_min_u32(__float_as_uint(md));  // md is never NaN (d < md is false for NaN) nor negative
-        const uint32_t uj = wave_min_u32(__float_as_uint(md) == ud ? mj : 0xFFFFFFFFu);
-        if (ud < best_d || (ud == best_d && uj < best_j)) {
-          best_d = ud;
-          best_j = uj;
-        }
+        ud[k] = wave_min_u32(__float_as_uint(md));  // md is never NaN (d < md is false for NaN) nor negative
+        uj[k] = wave_min_u32(__float_as_uint(md) == ud[k] ? mj : 0xFFFFFFFFu);
       }
-      if (lane == static_cast<uint32_t>(s)) {
-        res_d = best_d;
-        res_j = best_j;
+    };
+    // Phase A: granule 1 of every point, four points per step (one at a time, a wave's 64 points are 64 dependent
+    // memory round trips: 0.15 ms at any size).  A step with fewer than four points left repeats its first one.
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+    while (todo) {
+      int s[4];
+      bool real[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        real[k] = todo != 0;
+        s[k] = real[k] ? __builtin_ctzll(todo) : s[0];
+        todo &= todo - (todo != 0);
+      }
+      uint32_t ud[4], uj[4];
+      scan_granules(std::integral_constant<int, 4>{}, s, g1, ud, uj);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (real[k] && lane == static_cast<uint32_t>(s[k])) {
+          res_d = ud[k];
+          res_j = uj[k];
+        }
+    }
+    // Phase B: the points whose second granule could still hold the minimum or a tie (a few per cent)
+    todo = __builtin_amdgcn_ballot_w64(valid && L2 <= __uint_as_float(res_d));
+    while (todo) {
+      const int s = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      uint32_t ud, uj;
+      scan_granules(std::integral_constant<int, 1>{}, &s, g2, &ud, &uj);
+      if (lane == static_cast<uint32_t>(s) && (ud < res_d || (ud == res_d && uj < res_j))) {
+        res_d = ud;
+        res_j = uj;
       }
     }
     if (!valid) return;
     if (L3 <= __uint_as_float(res_d) || res_j == 0xFFFFFFFFu) {  // a third candidate granule (or more), or nothing finite found
       const uint32_t pos = atomicAdd(&overflow_count[blockIdx.y], 1u);
       overflow_list[J.out_off + pos] = local;
+      out_index[J.out_off + local] = 0;  // valid placeholder, see resolve_fused_kernel
+      out_dist2[J.out_off + local] = __builtin_inff();
       return;
     }
     out_index[J.out_off + local] = static_cast<int32_t>(res_j);
     out_dist2[J.out_off + local] = __uint_as_float(res_d);
+  }
+}
+
+// The points the filter paths could not settle (three or more candidate granules): one workgroup per listed point scans
+// EVERY target with the contract formula and reduces (d2, index) lexicographically - the all-exact answer, without the
+// host having to read the count first.  grid.x is a fixed cap; workgroups past the job's count leave at once, and a
+// count above the cap is handled by the host path (run_overflow_fallback) after the pass's single synchronisation.
+__global__ __launch_bounds__(kTile) void overflow_exact_kernel(
+    const JobDesc* __restrict__ jobs, const float* __restrict__ sx, const float* __restrict__ sy,
+    const float* __restrict__ sz, const float* __restrict__ tx, const float* __restrict__ ty,
+    const float* __restrict__ tz, const uint32_t* __restrict__ overflow_list,
+    const uint32_t* __restrict__ overflow_count, int32_t* __restrict__ out_index, float* __restrict__ out_dist2,
+    uint32_t* __restrict__ error_flag) {
+  __shared__ uint32_t sd[kTile / 64], sj[kTile / 64];
+  const JobDesc& J = jobs[blockIdx.y];
+  if (blockIdx.x >= overflow_count[blockIdx.y]) return;
+  const uint32_t local = overflow_list[J.out_off + blockIdx.x];
+  float pose[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
+  const uint32_t i = J.src_off + local;
+  float qx, qy, qz;
+  transform_point(pose, sx[i], sy[i], sz[i], qx, qy, qz);
+  float best = __builtin_inff();
+  uint32_t best_j = 0xFFFFFFFFu;
+  // 1024 threads, one target of every tile each (padding targets sit at 3e38: their distance overflows to +inf); four
+  // tiles in flight - the workgroup is alone on its CU when few points are listed, so memory latency has to be covered
+  // from inside the thread
+  const uint32_t n_tiles = J.tgt_tiles;
+  for (uint32_t tile = 0; tile < n_tiles; tile += 4) {
+    float d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t t = J.tgt_off + (tile + k < n_tiles ? tile + k : tile) * kTile + threadIdx.x;
+      d[k] = dist2(qx, qy, qz, tx[t], ty[t], tz[t]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t t = (tile + k) * kTile + threadIdx.x;  // increasing: a later equal distance never replaces an earlier one
+      if (tile + k < n_tiles && (d[k] < best || (d[k] == best && t < best_j))) {
+        best = d[k];
+        best_j = t;
+      }
+    }
+  }
+  // best is never NaN (d < best and d == best are false for NaN) nor negative: unsigned order of the bits is float order
+  const uint32_t wd = wave_min_u32(__float_as_uint(best));
+  const uint32_t wj = wave_min_u32(__float_as_uint(best) == wd ? best_j : 0xFFFFFFFFu);
+  if ((threadIdx.x & 63u) == 0) {
+    sd[threadIdx.x >> 6] = wd;
+    sj[threadIdx.x >> 6] = wj;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t d = sd[0], j = sj[0];
+    for (int w = 1; w < kTile / 64; ++w)
+      if (sd[w] < d || (sd[w] == d && sj[w] < j)) {
+        d = sd[w];
+        j = sj[w];
+      }
+    if (j == 0xFFFFFFFFu || j >= J.tgt_n) {  // nothing but NaN / padding: same report as the all-exact resolve
+      atomicOr(error_flag, 1u);
+      j = 0;
+    }
+    out_index[J.out_off + local] = static_cast<int32_t>(j);
+    out_dist2[J.out_off + local] = __uint_as_float(d);
   }
 }
 
@@ -771,6 +879,14 @@ void launch_resolve_xfilter(void* stream, int run_len, uint32_t split_mul, const
                        src.z, sorted_original.x, sorted_original.y, sorted_original.z, perm, keys4, key_stride, rank_stride,
                        out_index, out_dist2, overflow_list, overflow_count);
   (void)error_flag;  // a point with no finite distance goes to the all-exact scan, which raises the flag
+}
+
+void launch_overflow_exact(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t cap, DevicePlanes src, DevicePlanes tgt,
+                           const uint32_t* overflow_list, const uint32_t* overflow_count, int32_t* out_index, float* out_dist2,
+                           uint32_t* error_flag) {
+  hipLaunchKernelGGL(overflow_exact_kernel, dim3(cap, static_cast<uint32_t>(n_jobs)), dim3(kTile), 0,
+                     static_cast<hipStream_t>(stream), jobs_dev, src.x, src.y, src.z, tgt.x, tgt.y, tgt.z, overflow_list, overflow_count,
+                     out_index, out_dist2, error_flag);
 }
 
 void launch_accumulate(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
