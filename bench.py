@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--collective", choices=["native", "torch"], default="native",
                     help="N > 1: RCCL all-reduce issued inside the engine (native) or by torch.distributed")
     ap.add_argument("--force-dist", action="store_true", help="exercise the distributed code path even at N = 1")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): --n-source points PER GPU, so N = 8 is BASELINE config[4] 8M<->1M; strong: "
+                         "--n-source points in total, slab-sharded over the ranks")
     return ap.parse_args()
 
 
@@ -111,8 +114,9 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import synth_twin as st  # seeds / named configurations only
 
-    ns_local, nt = a.n_source, a.n_target
-    ns_total = ns_local * world
+    nt = a.n_target
+    ns_total = a.n_source * world if a.scaling == "weak" else a.n_source
+    ns_local = a.n_source if a.scaling == "weak" else (ns_total + world - 1) // world
     T = st.perturbation(-1)
     tgt = pa.synth_cloud(st.TARGET_SEED, nt)
     begin, count = pa.slab_range(ns_total, rank, world)
@@ -186,7 +190,7 @@ def main():
         out = {
             "metric": "correspondence_pairs_per_sec", "value": pairs_step * a.steps / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "icp_iters_per_sec": a.steps / elapsed,
             "correspondences_per_sec": float(ns_total) * a.steps / elapsed,
             "config": {"workload": f"{ns_total}x{nt} point-to-point ICP, exact brute-force NN "

@@ -40,6 +40,7 @@ struct XCopy {
   uint32_t* perm = nullptr;
   float* table = nullptr;
   void* bf = nullptr;
+  float* sub = nullptr;  // per 64-point run (centre x, y, z, r^2) on the uncentred coordinates: the pruned k-NN scan
   bool valid = false;
 };
 
@@ -82,6 +83,7 @@ void free_xcopy(XCopy& x) {  // the caller has drained the stream
   (void)hipFree(x.perm);
   (void)hipFree(x.table);
   (void)hipFree(x.bf);
+  (void)hipFree(x.sub);
   x = XCopy{};
 }
 
@@ -132,6 +134,8 @@ struct mi355_icp_ctx {
   float* scene[2] = {nullptr, nullptr}; size_t scene_cap = 0;
   uint32_t scene_n = 0; int scene_cur = 0; bool scene_loaded = false;
   float* scene_planes = nullptr; size_t scene_planes_cap = 0;    // SoA copy of the scene for the k-NN scan
+  XCopy scene_xt; size_t scene_xt_stride = 0;                    // its Morton-sorted copy with per-tile spheres (pruned k-NN)
+  bool knn_brute = false;                                        // MI355_ICP_KNN_MODE=brute: the exhaustive scan (A/B, tests)
   float* scene_normal_planes = nullptr; size_t scene_normal_planes_cap = 0;
   float* scene_normals_aos = nullptr; size_t scene_normals_aos_cap = 0;
   float* knn_d = nullptr; size_t knn_d_cap = 0;
@@ -500,6 +504,7 @@ int ensure_xcopy(mi355_icp_ctx* c, DevicePlanes view, size_t stride, const std::
   if (!x.perm) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.perm), stride * sizeof(uint32_t)));
   if (!x.table) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.table), 4 * (stride / kTile) * sizeof(float)));
   if (!x.bf) HIP_TRY(c, hipMalloc(&x.bf, (stride / kTile) * static_cast<size_t>(kXbTileVecs) * 16));
+  if (!x.sub) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.sub), (stride / 64) * 4 * sizeof(float)));
   uint32_t* code = c->xt_scratch;
   uint32_t* index = code + max_n;
   uint32_t* code2 = index + max_n;
@@ -512,7 +517,7 @@ int ensure_xcopy(mi355_icp_ctx* c, DevicePlanes view, size_t stride, const std::
   launch_bbox(c->stream, view, meta_dev, meta_dev + n_clouds, n_clouds, c->xt_box);
   for (int k = 0; k < n_clouds; ++k)
     if (xtarget_build_cloud(c->stream, view, clouds[k].off, clouds[k].n, c->xt_box + 6 * k, code, index, code2, order, c->xt_temp,
-                            temp_bytes, x.planes, stride, x.perm, x.table, x.bf) != 0)
+                            temp_bytes, x.planes, stride, x.perm, x.table, x.bf, x.sub) != 0)
       return fail(c, MI355_ICP_ERR_HIP, "rocprim::radix_sort_pairs failed");
   HIP_TRY(c, hipGetLastError());
   x.valid = true;
@@ -886,6 +891,10 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
     c->mfma_share_pct = env_u32("MI355_ICP_MFMA_SHARE", c->mfma_share_pct);
     if (c->scan_sgpr) c->scan_fused = 0;
   }
+  {
+    const char* km = std::getenv("MI355_ICP_KNN_MODE");
+    c->knn_brute = km && std::string(km) == "brute";
+  }
   c->target_blocks = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks);
   c->target_blocks_mfma = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks_mfma);  // the same override serves A/B runs of either
   c->min_tiles_per_split = env_u32("MI355_ICP_MIN_TILES_PER_SPLIT", c->min_tiles_per_split);
@@ -930,6 +939,7 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   (void)hipFree(c->scene[0]);
   (void)hipFree(c->scene[1]);
   (void)hipFree(c->scene_planes);
+  free_xcopy(c->scene_xt);
   (void)hipFree(c->scene_normal_planes);
   (void)hipFree(c->scene_normals_aos);
   (void)hipFree(c->knn_d);
@@ -1361,6 +1371,7 @@ int mi355_icp_scene_normals(mi355_icp_ctx* c, int k, int flip_viewpoint, const f
   if (split >= 8) split -= split % 8;
   else if (split >= 4) split = 4;
   else if (split >= 2) split = 2;
+  if (!c->knn_brute) split = 1;  // the pruned scan keeps one list per point
   const uint32_t q_stride = qblocks * kBlockThreads;
   const size_t list_len = static_cast<size_t>(split) * kk * q_stride;
   if ((st = grow(c, c->knn_d, c->knn_d_cap, list_len)) != MI355_ICP_OK) return st;
@@ -1375,7 +1386,23 @@ int mi355_icp_scene_normals(mi355_icp_ctx* c, int k, int flip_viewpoint, const f
   const float vp[3] = {viewpoint ? viewpoint[0] : 0.f, viewpoint ? viewpoint[1] : 0.f, viewpoint ? viewpoint[2] : 0.f};
   const bool profile = c->profile_always;
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-  launch_knn_scan(c->stream, k, P, n, n_tiles, split, c->knn_d, c->knn_i, q_stride);
+  if (c->knn_brute) {
+    launch_knn_scan(c->stream, k, P, n, n_tiles, split, c->knn_d, c->knn_i, q_stride);
+  } else {
+    // Morton-sorted copy of the scene with per-tile bounding spheres (the same builder the ICP targets use), then the
+    // pruned exact scan on it (normals_kernels.hip)
+    if (c->scene_xt_stride != padded) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      free_xcopy(c->scene_xt);
+      c->scene_xt_stride = padded;
+    }
+    c->scene_xt.valid = false;
+    const std::vector<CloudEntry> one{CloudEntry{0, n, padded}};
+    if ((st = ensure_xcopy(c, P, padded, one, c->scene_xt)) != MI355_ICP_OK) return st;
+    const float* xp = c->scene_xt.planes;
+    launch_knn_pruned(c->stream, k, DevicePlanes{xp + 4 * static_cast<size_t>(padded), xp + 5 * static_cast<size_t>(padded), xp + 6 * static_cast<size_t>(padded)},
+                      c->scene_xt.perm, c->scene_xt.table, c->scene_xt.sub, n, n_tiles, c->knn_d, c->knn_i, q_stride);
+  }
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
   launch_normals(c->stream, k, P, n, k_eff, split, c->knn_d, c->knn_i, q_stride, flip_viewpoint ? 1 : 0, vp, c->scene_normals_aos,
                  c->scene_normal_planes, padded, out_neighbors ? c->knn_out : nullptr);

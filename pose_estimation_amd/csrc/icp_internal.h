@@ -155,7 +155,7 @@ void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, 
 int xtarget_sort_temp_bytes(uint32_t n, size_t* bytes);
 int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const float* box, uint32_t* code,
                         uint32_t* index, uint32_t* code2, uint32_t* order, void* temp, size_t temp_bytes, float* xt,
-                        size_t stride, uint32_t* perm, float* table, void* bf_image);
+                        size_t stride, uint32_t* perm, float* table, void* bf_image, void* sub_table);
 void launch_bbox(void* stream, DevicePlanes planes, const uint32_t* cloud_off, const uint32_t* cloud_n, int n_clouds, float* box);
 void launch_xt_fill(void* stream, float* xt, size_t stride, uint32_t* perm, void* bf_image);
 
@@ -163,6 +163,8 @@ void launch_xt_fill(void* stream, float* xt, size_t stride, uint32_t* perm, void
 constexpr int kMaxNormalNeighbors = 32;
 void launch_knn_scan(void* stream, int k, DevicePlanes planes, uint32_t n, uint32_t n_tiles, uint32_t n_split,
                      float* list_d, int32_t* list_i, uint32_t q_stride);
+void launch_knn_pruned(void* stream, int k, DevicePlanes sorted, const uint32_t* perm, const void* table, const void* sub_table, uint32_t n,
+                       uint32_t n_tiles, float* list_d, int32_t* list_i, uint32_t q_stride);
 void launch_normals(void* stream, int k, DevicePlanes planes, uint32_t n, uint32_t k_eff, uint32_t n_split,
                     const float* list_d, const int32_t* list_i, uint32_t q_stride, int flip, const float* viewpoint,
                     float* out_aos, float* out_planes, size_t plane_stride, int32_t* out_knn);

@@ -111,7 +111,8 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __re
                                                                 const float* __restrict__ pz, uint32_t off, uint32_t n,
                                                                 const uint32_t* __restrict__ order, float* __restrict__ xt,
                                                                 size_t stride, uint32_t* __restrict__ perm,
-                                                                float* __restrict__ table, uint4* __restrict__ bf_image) {
+                                                                float* __restrict__ table, uint4* __restrict__ bf_image,
+                                                                float4* __restrict__ sub_table) {
   __shared__ float slo[4][3], shi[4][3];
   __shared__ double sr2[4];
   const uint32_t t0 = blockIdx.x * kTile;
@@ -130,6 +131,38 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __re
       lo[0] = __builtin_fminf(lo[0], x[k]); hi[0] = __builtin_fmaxf(hi[0], x[k]);
       lo[1] = __builtin_fminf(lo[1], y[k]); hi[1] = __builtin_fmaxf(hi[1], y[k]);
       lo[2] = __builtin_fminf(lo[2], z[k]); hi[2] = __builtin_fmaxf(hi[2], z[k]);
+    }
+  }
+  // bounding spheres of the 64-point runs (a wave's lanes at one k hold 64 consecutive sorted positions): the pruned
+  // k-NN scan skips runs no query of a wave can reach.  An empty run (padding only) sits at 3e38 with radius 0.
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool real = src[k] != 0xFFFFFFFFu;
+    float blo[3] = {real ? x[k] : __builtin_inff(), real ? y[k] : __builtin_inff(), real ? z[k] : __builtin_inff()};
+    float bhi[3] = {real ? x[k] : -__builtin_inff(), real ? y[k] : -__builtin_inff(), real ? z[k] : -__builtin_inff()};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        blo[a] = __builtin_fminf(blo[a], __shfl_xor(blo[a], off, 64));
+        bhi[a] = __builtin_fmaxf(bhi[a], __shfl_xor(bhi[a], off, 64));
+      }
+    const bool any = blo[0] <= bhi[0];
+    const float sx_ = any ? 0.5f * blo[0] + 0.5f * bhi[0] : kTargetPad, sy_ = any ? 0.5f * blo[1] + 0.5f * bhi[1] : kTargetPad,
+                sz_ = any ? 0.5f * blo[2] + 0.5f * bhi[2] : kTargetPad;
+    double rr = 0.0;
+    if (real) {
+      const double ex = static_cast<double>(x[k]) - sx_, ey = static_cast<double>(y[k]) - sy_, ez = static_cast<double>(z[k]) - sz_;
+      rr = ex * ex + ey * ey + ez * ez;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double other = __shfl_xor(rr, off, 64);
+      rr = other > rr ? other : rr;
+    }
+    if ((threadIdx.x & 63u) == 0) {
+      const float rf = __uint_as_float(__float_as_uint(static_cast<float>(rr)) + 1u);  // next float up (rr >= 0, finite)
+      sub_table[static_cast<size_t>((off + t0) / 64) + k * 4 + (threadIdx.x >> 6)] = make_float4(sx_, sy_, sz_, any ? rf : 0.0f);
     }
   }
   block_minmax<kBlockThreads>(lo, hi, slo, shi);
@@ -220,7 +253,7 @@ int xtarget_sort_temp_bytes(uint32_t n, size_t* bytes) {
 // Enqueues the whole build for one cloud on `stream`.  code/index/code2/order: n entries each; temp: sort scratch.
 int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const float* box, uint32_t* code,
                         uint32_t* index, uint32_t* code2, uint32_t* order, void* temp, size_t temp_bytes, float* xt,
-                        size_t stride, uint32_t* perm, float* table, void* bf_image) {
+                        size_t stride, uint32_t* perm, float* table, void* bf_image, void* sub_table) {
   if (!n) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(morton_kernel, dim3((n + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, st, planes.x, planes.y,
@@ -228,7 +261,7 @@ int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_
   size_t tb = temp_bytes;
   if (rocprim::radix_sort_pairs(temp, tb, code, code2, index, order, n, 0, 30, st, false) != hipSuccess) return 1;
   hipLaunchKernelGGL(centre_kernel, dim3((n + kTile - 1) / kTile), dim3(kBlockThreads), 0, st, planes.x, planes.y, planes.z, off, n,
-                     order, xt, stride, perm, table, static_cast<uint4*>(bf_image));
+                     order, xt, stride, perm, table, static_cast<uint4*>(bf_image), static_cast<float4*>(sub_table));
   return 0;
 }
 

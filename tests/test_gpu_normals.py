@@ -89,3 +89,46 @@ def test_cpp_harness_full_pipeline_on_device(engine):
     gt = np.linalg.inv(st.perturbation(-1))
     for k in range(3):
         assert np.linalg.norm(poses[k] - gt) < 6e-3, k
+
+
+def engine_with_knn_mode(mode):
+    import os
+    import pose_estimation_amd as pa
+    old = os.environ.get("MI355_ICP_KNN_MODE")
+    os.environ["MI355_ICP_KNN_MODE"] = mode
+    try:
+        return pa.IcpEngine(0)
+    finally:
+        if old is None:
+            os.environ.pop("MI355_ICP_KNN_MODE")
+        else:
+            os.environ["MI355_ICP_KNN_MODE"] = old
+
+
+def test_exhaustive_knn_scan_still_matches_the_oracle():
+    """The default is the pruned scan on the Morton-sorted copy; MI355_ICP_KNN_MODE=brute keeps the exhaustive one alive."""
+    with engine_with_knn_mode("brute") as eng:
+        for n in (21, 1025, 5000):
+            check(eng, st.synth_cloud_np(st.TARGET_SEED, n), kd=n > 3000)
+
+
+def test_pruned_knn_on_geometry_that_stresses_the_tile_bounds(engine):
+    """Distant tight clusters (huge tile spheres in Morton order), duplicated points (ties at distance 0 across tiles),
+    a flat sheet far from the origin, and 300k points: neighbour lists must still be the oracle's."""
+    rng = np.random.default_rng(11)
+    centres = rng.standard_normal((7, 3)) * 50.0
+    clusters = (centres[rng.integers(0, 7, 30000)] + rng.standard_normal((30000, 3)) * 0.02).astype(np.float32)
+    check(engine, clusters)
+    dup = st.synth_cloud_np(st.TARGET_SEED + 1, 4000)
+    dup = np.concatenate([dup] * 6)[rng.permutation(24000)]              # every point six times: k = 20 ties everywhere
+    engine.scene_load(dup)
+    _, nb = engine.scene_normals(20, False, (0, 0, 0), want_neighbors=True)
+    idx, _ = ora.knn_self(dup, 20, use_kdtree=True, nthreads=ora.max_threads())
+    assert np.array_equal(nb, idx)
+    sheet = (rng.uniform(-1, 1, (50000, 3)) * np.float32([1, 1, 1e-4]) + np.float32([1000.0, -500.0, 250.0])).astype(np.float32)
+    check(engine, sheet)
+    big = st.synth_cloud_np(st.TARGET_SEED + 2, 300_000)
+    engine.scene_load(big)
+    _, nb = engine.scene_normals(20, False, (0, 0, 0), want_neighbors=True)
+    idx, _ = ora.knn_self(big, 20, use_kdtree=True, nthreads=ora.max_threads())
+    assert np.array_equal(nb, idx)
