@@ -133,6 +133,8 @@ struct mi355_icp_ctx {
   // scene preparation (packed AoS xyz, ping-pong)
   float* scene[2] = {nullptr, nullptr}; size_t scene_cap = 0;
   uint32_t scene_n = 0; int scene_cur = 0; bool scene_loaded = false;
+  float* upload_raw = nullptr; size_t upload_raw_cap = 0;        // staging for the caller's rows (one cloud at a time)
+  uint32_t* upload_flags = nullptr; size_t upload_flags_cap = 0; // per cloud: a non-finite value was met
   float* scene_planes = nullptr; size_t scene_planes_cap = 0;    // SoA copy of the scene for the k-NN scan
   XCopy scene_xt; size_t scene_xt_stride = 0;                    // its Morton-sorted copy with per-tile spheres (pruned k-NN)
   bool knn_brute = false;                                        // MI355_ICP_KNN_MODE=brute: the exhaustive scan (A/B, tests)
@@ -193,6 +195,9 @@ int fail(mi355_icp_ctx* c, int code, const std::string& msg) {
       return fail((ctx), MI355_ICP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
   } while (0)
 
+template <typename T>
+int grow(mi355_icp_ctx* c, T*& ptr, size_t& cap, size_t need);
+
 int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* const* xyz, const size_t* n_points,
                   size_t stride_bytes, uint32_t pad_multiple, float pad_value, bool allow_empty, const char* what) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
@@ -211,33 +216,50 @@ int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* co
     total += padded;
   }
   const size_t stride = static_cast<size_t>(std::max<uint64_t>(total, pad_multiple));
-  std::vector<float> host(3 * stride, pad_value);
-  const size_t fstride = stride_bytes / 4;
+  const uint32_t fstride = static_cast<uint32_t>(stride_bytes / 4);
   const bool with_normals = fstride >= 6;  // rows of xyz + normal (N x 6), opencv_surface_match.cpp:22,57-59
-  std::vector<float> host_n(with_normals ? 3 * stride : 0, 0.0f);
-  for (int k = 0; k < n_clouds; ++k) {
-    const float* src = xyz[k];
-    float* px = host.data() + entries[k].off;
-    float* py = px + stride;
-    float* pz = py + stride;
-    bool finite = true;
-    for (size_t i = 0; i < entries[k].n; ++i) {
-      const float x = src[i * fstride], y = src[i * fstride + 1], z = src[i * fstride + 2];
-      finite = finite && std::isfinite(x) && std::isfinite(y) && std::isfinite(z);
-      px[i] = x; py[i] = y; pz[i] = z;
-      if (with_normals) {
-        float* pn = host_n.data() + entries[k].off + i;
-        const float a = src[i * fstride + 3], b = src[i * fstride + 4], cc = src[i * fstride + 5];
-        finite = finite && std::isfinite(a) && std::isfinite(b) && std::isfinite(cc);
-        pn[0] = a; pn[stride] = b; pn[2 * stride] = cc;
-      }
-    }
-    if (!finite)
-      return fail(c, MI355_ICP_ERR_NONFINITE_INPUT,
-                  std::string(what) + ": cloud " + std::to_string(k) + " holds NaN/Inf (strip them first, as the reference does at pose_estimation.cpp:248)");
-  }
+  // The caller's rows go to the device as they are and are re-laid out to SoA planes, padded and checked for NaN/Inf
+  // THERE (rows_to_planes_kernel): 12 B per point over PCIe and one pass at HBM speed, instead of a scalar host loop
+  // over every point plus a second copy.  The new planes replace the old ones only if every cloud was finite.
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  size_t raw_floats = 1;
+  for (int k = 0; k < n_clouds; ++k) raw_floats = std::max(raw_floats, static_cast<size_t>(entries[k].n) * fstride);
+  int st;
+  if ((st = grow(c, c->upload_raw, c->upload_raw_cap, raw_floats)) != MI355_ICP_OK) return st;
+  if ((st = grow(c, c->upload_flags, c->upload_flags_cap, static_cast<size_t>(n_clouds))) != MI355_ICP_OK) return st;
+  float *planes = nullptr, *normals = nullptr;
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&planes), 3 * stride * sizeof(float)));
+  if (with_normals && hipMalloc(reinterpret_cast<void**>(&normals), 3 * stride * sizeof(float)) != hipSuccess) {
+    (void)hipFree(planes);
+    return fail(c, MI355_ICP_ERR_HIP, "hipMalloc (normal planes) failed");
+  }
+  auto drop_new = [&]() { (void)hipFree(planes); (void)hipFree(normals); };
+  bool ok = hipMemsetAsync(c->upload_flags, 0, static_cast<size_t>(n_clouds) * sizeof(uint32_t), c->stream) == hipSuccess;
+  if (total == 0) {  // only empty clouds: planes of padding
+    ok = ok && hipMemsetAsync(planes, 0, 3 * stride * sizeof(float), c->stream) == hipSuccess;
+    if (normals) ok = ok && hipMemsetAsync(normals, 0, 3 * stride * sizeof(float), c->stream) == hipSuccess;
+  }
+  for (int k = 0; k < n_clouds && ok; ++k) {
+    if (entries[k].n)  // pageable source: returns once the rows have left the caller's buffer, ordered on the stream
+      ok = hipMemcpyAsync(c->upload_raw, xyz[k], static_cast<size_t>(entries[k].n) * stride_bytes, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    launch_rows_to_planes(c->stream, c->upload_raw, fstride, entries[k].n, planes, normals, stride, entries[k].off, entries[k].padded,
+                          pad_value, c->upload_flags, static_cast<uint32_t>(k));
+  }
+  std::vector<uint32_t> flags(static_cast<size_t>(n_clouds), 0u);
+  ok = ok && hipGetLastError() == hipSuccess &&
+       hipMemcpyAsync(flags.data(), c->upload_flags, flags.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+       hipStreamSynchronize(c->stream) == hipSuccess;
+  if (!ok) {
+    drop_new();
+    return fail(c, MI355_ICP_ERR_HIP, std::string(what) + ": upload failed: " + hipGetErrorString(hipGetLastError()));
+  }
+  for (int k = 0; k < n_clouds; ++k)
+    if (flags[k]) {
+      drop_new();
+      return fail(c, MI355_ICP_ERR_NONFINITE_INPUT,
+                  std::string(what) + ": cloud " + std::to_string(k) + " holds NaN/Inf (strip them first, as the reference does at pose_estimation.cpp:248)");
+    }
   if (set.planes) { HIP_TRY(c, hipFree(set.planes)); set.planes = nullptr; }
   if (set.normals) { HIP_TRY(c, hipFree(set.normals)); set.normals = nullptr; }
   for (auto& lv : set.levels) {
@@ -246,13 +268,8 @@ int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* co
   }
   set.levels.clear();
   free_xcopy(set.xt);
-  set.clouds.clear();
-  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.planes), 3 * stride * sizeof(float)));
-  HIP_TRY(c, hipMemcpy(set.planes, host.data(), 3 * stride * sizeof(float), hipMemcpyHostToDevice));
-  if (with_normals) {
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.normals), 3 * stride * sizeof(float)));
-    HIP_TRY(c, hipMemcpy(set.normals, host_n.data(), 3 * stride * sizeof(float), hipMemcpyHostToDevice));
-  }
+  set.planes = planes;
+  set.normals = normals;
   set.stride = stride;
   set.clouds = std::move(entries);
   return MI355_ICP_OK;
@@ -939,6 +956,8 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   (void)hipFree(c->scene[0]);
   (void)hipFree(c->scene[1]);
   (void)hipFree(c->scene_planes);
+  (void)hipFree(c->upload_raw);
+  (void)hipFree(c->upload_flags);
   free_xcopy(c->scene_xt);
   (void)hipFree(c->scene_normal_planes);
   (void)hipFree(c->scene_normals_aos);

@@ -85,6 +85,8 @@ struct SceneFilterSet {
 };
 void launch_scene_compact(void* stream, const float* in, uint32_t n, const SceneFilterSet& filters, float* out,
                           unsigned long long* state, uint32_t* counters, uint32_t n_tiles);
+void launch_rows_to_planes(void* stream, const float* rows, uint32_t fstride, uint32_t n, float* planes, float* normals, size_t stride,
+                           uint32_t off, uint32_t n_padded, float pad, uint32_t* flags, uint32_t cloud);
 void launch_scene_to_planes(void* stream, const float* in, uint32_t n, float* planes, size_t stride, uint32_t off,
                             uint32_t n_padded, float pad, uint32_t* counters);
 

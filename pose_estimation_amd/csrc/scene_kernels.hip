@@ -224,6 +224,46 @@ __global__ __launch_bounds__(kBlockThreads) void scene_to_planes_kernel(const fl
   planes[2 * stride + off + i] = z;
 }
 
+// Upload path: caller rows (fstride floats each: xyz, optionally + normal + anything) -> SoA planes at plane offset `off`,
+// slots [n, n_padded) filled with `pad` (normals: 0).  Sets flags[cloud] if a coordinate or normal is not finite.
+__global__ __launch_bounds__(kBlockThreads) void rows_to_planes_kernel(const float* __restrict__ rows, uint32_t fstride, uint32_t n,
+                                                                        float* __restrict__ planes, float* __restrict__ normals,
+                                                                        size_t stride, uint32_t off, uint32_t n_padded, float pad,
+                                                                        uint32_t* __restrict__ flags, uint32_t cloud) {
+  const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
+  if (i >= n_padded) return;
+  float x = pad, y = pad, z = pad, a = 0.f, b = 0.f, c = 0.f;
+  if (i < n) {
+    const float* r = rows + static_cast<size_t>(i) * fstride;
+    x = r[0];
+    y = r[1];
+    z = r[2];
+    bool ok = __builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z);
+    if (normals) {
+      a = r[3];
+      b = r[4];
+      c = r[5];
+      ok = ok && __builtin_isfinite(a) && __builtin_isfinite(b) && __builtin_isfinite(c);
+    }
+    if (!ok) atomicOr(&flags[cloud], 1u);
+  }
+  planes[off + i] = x;
+  planes[stride + off + i] = y;
+  planes[2 * stride + off + i] = z;
+  if (normals) {
+    normals[off + i] = a;
+    normals[stride + off + i] = b;
+    normals[2 * stride + off + i] = c;
+  }
+}
+
+void launch_rows_to_planes(void* stream, const float* rows, uint32_t fstride, uint32_t n, float* planes, float* normals, size_t stride,
+                           uint32_t off, uint32_t n_padded, float pad, uint32_t* flags, uint32_t cloud) {
+  if (!n_padded) return;
+  hipLaunchKernelGGL(rows_to_planes_kernel, dim3((n_padded + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0,
+                     static_cast<hipStream_t>(stream), rows, fstride, n, planes, normals, stride, off, n_padded, pad, flags, cloud);
+}
+
 void launch_scene_compact(void* stream, const float* in, uint32_t n, const SceneFilterSet& filters, float* out,
                           unsigned long long* state, uint32_t* counters, uint32_t n_tiles) {
   if (!n_tiles) return;
