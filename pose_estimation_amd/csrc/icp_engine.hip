@@ -158,7 +158,7 @@ struct mi355_icp_ctx {
   int scan_ppl = 0;                  // scan points-per-lane override (2, 4, 8); 0 = planner decides per call
   bool scan_sgpr = false;            // experimental scalar-load scan (MI355_ICP_SCAN_MODE=sgpr)
   uint32_t* xt_scratch = nullptr; size_t xt_scratch_cap = 0;  // Morton codes / indices while building the sorted target copy
-  float* xt_box = nullptr;        size_t xt_box_cap = 0;
+  uint32_t* xt_box = nullptr;     size_t xt_box_cap = 0;  // per cloud: bounding box as order-preserving keys
   unsigned char* xt_temp = nullptr; size_t xt_temp_cap = 0;   // rocPRIM sort scratch
   uint32_t mfma_share_pct = 65;      // hybrid: per cent of the scan workgroups that run on the matrix cores
   hipStream_t stream2 = nullptr;     // hybrid: the MFMA workgroups are launched here, beside the VALU ones
@@ -531,7 +531,7 @@ int ensure_xcopy(mi355_icp_ctx* c, DevicePlanes view, size_t stride, const std::
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // `meta` is a pageable temporary
   launch_xt_fill(c->stream, x.planes, stride, x.perm, x.bf);
   HIP_TRY(c, hipMemsetAsync(x.table, 0, 4 * (stride / kTile) * sizeof(float), c->stream));
-  launch_bbox(c->stream, view, meta_dev, meta_dev + n_clouds, n_clouds, c->xt_box);
+  launch_bbox(c->stream, view, meta_dev, meta_dev + n_clouds, n_clouds, max_n, c->xt_box);
   for (int k = 0; k < n_clouds; ++k)
     if (xtarget_build_cloud(c->stream, view, clouds[k].off, clouds[k].n, c->xt_box + 6 * k, code, index, code2, order, c->xt_temp,
                             temp_bytes, x.planes, stride, x.perm, x.table, x.bf, x.sub) != 0)

@@ -155,10 +155,11 @@ void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, 
 
 // ---- sorted / tile-centred target copy for the expansion filter (xtarget_kernels.hip) ----
 int xtarget_sort_temp_bytes(uint32_t n, size_t* bytes);
-int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const float* box, uint32_t* code,
+int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const uint32_t* box, uint32_t* code,
                         uint32_t* index, uint32_t* code2, uint32_t* order, void* temp, size_t temp_bytes, float* xt,
                         size_t stride, uint32_t* perm, float* table, void* bf_image, void* sub_table);
-void launch_bbox(void* stream, DevicePlanes planes, const uint32_t* cloud_off, const uint32_t* cloud_n, int n_clouds, float* box);
+void launch_bbox(void* stream, DevicePlanes planes, const uint32_t* cloud_off, const uint32_t* cloud_n, int n_clouds, uint32_t max_n,
+                 uint32_t* box);
 void launch_xt_fill(void* stream, float* xt, size_t stride, uint32_t* perm, void* bf_image);
 
 // ---- scene normals (normals_kernels.hip) ----

@@ -4,7 +4,7 @@
 // ANY centre (only the number of candidate chunks, i.e. speed, depends on compactness) - so the sort may use a library
 // primitive: rocprim::radix_sort_pairs (stable, hence deterministic).
 //
-//   bbox_kernel      one workgroup per cloud: bounding box (the Morton grid)
+//   bbox_kernel      bounding box of every cloud (the Morton grid): strided workgroups, merged with integer atomics
 //   morton_kernel    30-bit code per point (10 bits per axis inside the box)
 //   <rocPRIM>        stable radix sort of (code, index)
 //   centre_kernel    one workgroup per 1024-point tile: tile box -> centre c; tc = fl(t - c) (the float32 subtraction the
@@ -14,6 +14,7 @@
 //                    pieces per coordinate, |tc'|^2 of the QUANTISED point in three, laid out as MFMA A fragments
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 
@@ -65,14 +66,27 @@ __device__ __forceinline__ void block_minmax(float (&lo)[3], float (&hi)[3], flo
 
 }  // namespace
 
-// grid = n_clouds, block = 1024.  box[cloud] = {lo x, y, z, hi x, y, z}
+// Order-preserving float <-> uint32 keys, so the bounding box can be reduced with integer atomics across workgroups.
+__device__ __forceinline__ uint32_t ordered_key(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_value(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+// box[cloud] = {lo x, y, z, hi x, y, z} as ordered keys
+__global__ void bbox_init_kernel(uint32_t* __restrict__ box, uint32_t n_entries) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_entries) box[i] = (i % 6 < 3) ? 0xFFFFFFFFu : 0u;
+}
+
+// grid = (chunks, n_clouds), block = 1024: each workgroup reduces a strided share of its cloud and merges it with atomics
 __global__ __launch_bounds__(1024) void bbox_kernel(const float* __restrict__ px, const float* __restrict__ py,
                                                      const float* __restrict__ pz, const uint32_t* __restrict__ cloud_off,
-                                                     const uint32_t* __restrict__ cloud_n, float* __restrict__ box) {
+                                                     const uint32_t* __restrict__ cloud_n, uint32_t* __restrict__ box) {
   __shared__ float slo[16][3], shi[16][3];
-  const uint32_t off = cloud_off[blockIdx.x], n = cloud_n[blockIdx.x];
+  const uint32_t off = cloud_off[blockIdx.y], n = cloud_n[blockIdx.y];
   float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-  for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+  for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
     const float p[3] = {px[off + i], py[off + i], pz[off + i]};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -81,16 +95,16 @@ __global__ __launch_bounds__(1024) void bbox_kernel(const float* __restrict__ px
     }
   }
   block_minmax<1024>(lo, hi, slo, shi);
-  if (threadIdx.x < 3) {
-    box[6 * blockIdx.x + threadIdx.x] = lo[threadIdx.x];
-    box[6 * blockIdx.x + 3 + threadIdx.x] = hi[threadIdx.x];
+  if (threadIdx.x < 3 && lo[threadIdx.x] <= hi[threadIdx.x]) {  // this workgroup saw at least one point
+    atomicMin(&box[6 * blockIdx.y + threadIdx.x], ordered_key(lo[threadIdx.x]));
+    atomicMax(&box[6 * blockIdx.y + 3 + threadIdx.x], ordered_key(hi[threadIdx.x]));
   }
 }
 
 // one thread per point of one cloud
 __global__ __launch_bounds__(kBlockThreads) void morton_kernel(const float* __restrict__ px, const float* __restrict__ py,
                                                                 const float* __restrict__ pz, uint32_t off, uint32_t n,
-                                                                const float* __restrict__ box, uint32_t* __restrict__ code,
+                                                                const uint32_t* __restrict__ box, uint32_t* __restrict__ code,
                                                                 uint32_t* __restrict__ index) {
   const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
   if (i >= n) return;
@@ -98,7 +112,7 @@ __global__ __launch_bounds__(kBlockThreads) void morton_kernel(const float* __re
   uint32_t q[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float lo = box[k], ext = box[3 + k] - box[k];
+    const float lo = ordered_value(box[k]), ext = ordered_value(box[3 + k]) - lo;
     const float f = ext > 0.f ? (p[k] - lo) / ext * 1023.0f : 0.f;
     q[k] = static_cast<uint32_t>(__builtin_fminf(__builtin_fmaxf(f, 0.f), 1023.f));
   }
@@ -251,7 +265,7 @@ int xtarget_sort_temp_bytes(uint32_t n, size_t* bytes) {
 }
 
 // Enqueues the whole build for one cloud on `stream`.  code/index/code2/order: n entries each; temp: sort scratch.
-int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const float* box, uint32_t* code,
+int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const uint32_t* box, uint32_t* code,
                         uint32_t* index, uint32_t* code2, uint32_t* order, void* temp, size_t temp_bytes, float* xt,
                         size_t stride, uint32_t* perm, float* table, void* bf_image, void* sub_table) {
   if (!n) return 0;
@@ -265,9 +279,14 @@ int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_
   return 0;
 }
 
-void launch_bbox(void* stream, DevicePlanes planes, const uint32_t* cloud_off, const uint32_t* cloud_n, int n_clouds, float* box) {
-  hipLaunchKernelGGL(bbox_kernel, dim3(static_cast<uint32_t>(n_clouds)), dim3(1024), 0, static_cast<hipStream_t>(stream), planes.x,
-                     planes.y, planes.z, cloud_off, cloud_n, box);
+void launch_bbox(void* stream, DevicePlanes planes, const uint32_t* cloud_off, const uint32_t* cloud_n, int n_clouds, uint32_t max_n,
+                 uint32_t* box) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const uint32_t entries = 6u * static_cast<uint32_t>(n_clouds);
+  hipLaunchKernelGGL(bbox_init_kernel, dim3((entries + 255) / 256), dim3(256), 0, st, box, entries);
+  const uint32_t chunks = std::min<uint32_t>(128u, std::max<uint32_t>(1u, (max_n + 8191u) / 8192u));  // >= 8 points per thread
+  hipLaunchKernelGGL(bbox_kernel, dim3(chunks, static_cast<uint32_t>(n_clouds)), dim3(1024), 0, st, planes.x, planes.y, planes.z,
+                     cloud_off, cloud_n, box);
 }
 
 void launch_xt_fill(void* stream, float* xt, size_t stride, uint32_t* perm, void* bf_image) {
