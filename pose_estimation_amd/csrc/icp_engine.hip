@@ -178,6 +178,7 @@ struct mi355_icp_ctx {
   uint32_t target_blocks_mfma = 4096; // ... for the matrix-core filter: its workgroups span 512 points and publish two key
                                      // rows per split, so fewer, longer ones cost less key traffic (100k<->100k: resolve
                                      // 82 -> 35 us at equal scan time; profiles/r01o_target_blocks.txt)
+  int xbf16_shape = 0;               // 0: <4 sets, 256 threads> workgroups, 1: <2 sets, 512 threads> (MI355_ICP_XBF16_SHAPE)
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
 };
 
@@ -565,7 +566,7 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
     const size_t st = xstride;
     const int ppl = plan.scan_ppl == 2 ? 2 : 4;  // the MFMA kernel spans 128 * {4, 8} points per workgroup
     if (bx && plan.xkind == 3) {
-      launch_nn_scan_xbf16(c->stream, c->jobs_dev, n_active, bx, S, X.bf, X.table, c->keys3, plan.out_total, rank_stride);
+      launch_nn_scan_xbf16(c->stream, c->jobs_dev, n_active, bx, S, X.bf, X.table, c->keys3, plan.out_total, rank_stride, c->xbf16_shape);
     } else if (bx && plan.xkind == 0) {
       launch_nn_scan_xfilter(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, xp, xp + st, xp + 2 * st, xp + 3 * st,
                              X.table, c->keys3, plan.out_total, rank_stride);
@@ -912,6 +913,7 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
     const char* km = std::getenv("MI355_ICP_KNN_MODE");
     c->knn_brute = km && std::string(km) == "brute";
   }
+  c->xbf16_shape = static_cast<int>(env_u32("MI355_ICP_XBF16_SHAPE", static_cast<uint32_t>(c->xbf16_shape)));
   c->target_blocks = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks);
   c->target_blocks_mfma = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks_mfma);  // the same override serves A/B runs of either
   c->min_tiles_per_split = env_u32("MI355_ICP_MIN_TILES_PER_SPLIT", c->min_tiles_per_split);

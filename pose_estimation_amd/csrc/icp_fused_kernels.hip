@@ -569,8 +569,10 @@ __device__ __forceinline__ uint32_t min16(const f32x16& acc, uint32_t seed) {
   return umin3(t5, t6, seed);
 }
 
-template <int kSets>  // 32-source column sets per wave: a workgroup covers 128 * kSets source points
-__global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xbf16_kernel(const JobDesc* __restrict__ jobs,
+// kSets: 32-source column sets per wave; kThreads: workgroup size.  A workgroup covers kThreads / 2 * kSets source points:
+// <4, 256> (4 waves, 2 workgroups per CU = 2 waves per SIMD at <= 256 registers) or <2, 512> (4 waves per SIMD at <= 128).
+template <int kSets, int kThreads>
+__global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDesc* __restrict__ jobs,
                                                                        const float* __restrict__ sx,
                                                                        const float* __restrict__ sy,
                                                                        const float* __restrict__ sz,
@@ -584,7 +586,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xbf16_kernel(const J
   const uint32_t sb = blockIdx.x / n_split;
   const uint32_t sp = blockIdx.x - sb * n_split;
   if (sb >= J.scan_blocks) return;
-  constexpr uint32_t kScanSrcPerBlock = 128 * kSets;
+  constexpr uint32_t kScanSrcPerBlock = (kThreads / 64) * 32 * kSets;
+  constexpr int kPf = 2 * kBlockThreads / kThreads;  // uint4 per thread and chunk of the next tile (a quarter of it: 512)
   const uint32_t tile0 = sp * J.split_q + (sp < J.split_r ? sp : J.split_r);
   const uint32_t tile1 = tile0 + J.split_q + (sp < J.split_r ? 1u : 0u);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -607,8 +610,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xbf16_kernel(const J
   const uint32_t tile_base = J.tgt_off / kTile;  // tgt_off is a multiple of kTile
   const uint4* __restrict__ image = bf_image + static_cast<size_t>(tile_base) * kXbTileVecs;
 #pragma unroll
-  for (int k = 0; k < kXbTileVecs / kBlockThreads; ++k)
-    lds[0][k * kBlockThreads + tid] = image[static_cast<size_t>(tile0) * kXbTileVecs + k * kBlockThreads + tid];
+  for (int k = 0; k < kXbTileVecs / kThreads; ++k)
+    lds[0][k * kThreads + tid] = image[static_cast<size_t>(tile0) * kXbTileVecs + k * kThreads + tid];
   __syncthreads();
   uint32_t cur = 0;
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -651,10 +654,10 @@ __global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xbf16_kernel(const J
     uint32_t cmin[kSets];
 #pragma unroll
     for (int m = 0; m < kSets; ++m) cmin[m] = 0x7F800000u;
-    uint4 p0, p1;
+    uint4 pf[kPf];
     if (more) {  // a quarter of the next tile rides along with each chunk
-      p0 = next[tid];
-      p1 = next[kBlockThreads + tid];
+#pragma unroll
+      for (int k = 0; k < kPf; ++k) pf[k] = next[k * kThreads + tid];
     }
     // operands of the NEXT step's MFMAs are read one step ahead, into two register sets used alternately (no copies)
     u32x4 f0_b = load_frag(A + 32), f0_a = load_frag(A + 64), f1_b, f1_a;
@@ -707,11 +710,11 @@ __global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xbf16_kernel(const J
           }
         }
         if (more) {
-          lds[cur ^ 1][c * 2 * kBlockThreads + tid] = p0;
-          lds[cur ^ 1][(c * 2 + 1) * kBlockThreads + tid] = p1;
+#pragma unroll
+          for (int k = 0; k < kPf; ++k) lds[cur ^ 1][(c * kPf + k) * kThreads + tid] = pf[k];
           if (c + 1 < kXbChunksPerTile) {
-            p0 = next[(c + 1) * 2 * kBlockThreads + tid];
-            p1 = next[((c + 1) * 2 + 1) * kBlockThreads + tid];
+#pragma unroll
+            for (int k = 0; k < kPf; ++k) pf[k] = next[((c + 1) * kPf + k) * kThreads + tid];
           }
         }
       }
@@ -731,15 +734,20 @@ __global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xbf16_kernel(const J
   }
 }
 
-// a workgroup spans 512 source points (kSets = 4, the planner's 2 points per lane)
+// a workgroup spans 512 source points either way (the planner's 2 points per lane); shape 1 = <2 sets, 512 threads>
 void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
                           const void* bf_image, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
-                          uint32_t rank_stride) {
+                          uint32_t rank_stride, int shape) {
   if (!max_blocks_x) return;
   dim3 grid(max_blocks_x, static_cast<uint32_t>(n_jobs));
-  hipLaunchKernelGGL(nn_scan_xbf16_kernel<4>, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x, src.y,
-                     src.z, static_cast<const uint4*>(bf_image), static_cast<const float4*>(tile_table), keys4, key_stride,
-                     rank_stride);
+  if (shape == 1)
+    hipLaunchKernelGGL((nn_scan_xbf16_kernel<2, 512>), grid, dim3(512), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x, src.y,
+                       src.z, static_cast<const uint4*>(bf_image), static_cast<const float4*>(tile_table), keys4, key_stride,
+                       rank_stride);
+  else
+    hipLaunchKernelGGL((nn_scan_xbf16_kernel<4, 256>), grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x,
+                       src.y, src.z, static_cast<const uint4*>(bf_image), static_cast<const float4*>(tile_table), keys4, key_stride,
+                       rank_stride);
 }
 
 // points_per_lane selects the workgroup's source span exactly as for the VALU kernel (256 * ppl = 128 * kSets points)

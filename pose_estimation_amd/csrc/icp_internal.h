@@ -119,7 +119,7 @@ void launch_nn_scan_xmfma(void* stream, int points_per_lane, const JobDesc* jobs
                           uint32_t rank_stride);
 void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
                           const void* bf_image, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
-                          uint32_t rank_stride);
+                          uint32_t rank_stride, int shape);
 // run_len: targets per remembered granule (kFusedChunk, or kXbRun with two key rows per split: split_mul = 2)
 void launch_resolve_xfilter(void* stream, int run_len, uint32_t split_mul, const JobDesc* jobs_dev, int n_jobs,
                             uint32_t max_src_blocks, DevicePlanes src, DevicePlanes sorted_original, const uint32_t* perm,

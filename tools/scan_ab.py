@@ -15,7 +15,7 @@ import numpy as np  # noqa: E402
 import pose_estimation_amd as pa  # noqa: E402
 import synth_twin as st  # noqa: E402
 
-KEYS = {"MODE": "MI355_ICP_SCAN_MODE", "PPL": "MI355_ICP_SCAN_PPL", "TARGET_BLOCKS": "MI355_ICP_TARGET_BLOCKS", "MIN_TILES": "MI355_ICP_MIN_TILES_PER_SPLIT"}
+KEYS = {"MODE": "MI355_ICP_SCAN_MODE", "PPL": "MI355_ICP_SCAN_PPL", "TARGET_BLOCKS": "MI355_ICP_TARGET_BLOCKS", "MIN_TILES": "MI355_ICP_MIN_TILES_PER_SPLIT", "SHAPE": "MI355_ICP_XBF16_SHAPE"}
 
 
 def main():
