@@ -40,7 +40,8 @@ struct XCopy {
   uint32_t* perm = nullptr;
   float* table = nullptr;
   void* bf = nullptr;
-  float* sub = nullptr;  // per 64-point run (centre x, y, z, r^2) on the uncentred coordinates: the pruned k-NN scan
+  float* sub = nullptr;  // per 64-point run (centre x, y, z, r^2) on the uncentred coordinates: the pruned scans
+  float* super = nullptr;  // per 16 tiles: a sphere around their spheres (first level of the pruned scans' tile search)
   bool valid = false;
 };
 
@@ -74,6 +75,7 @@ struct Plan {
   bool fused = false;          // fused-filter scan + exact resolve (large launches) instead of the all-exact scan
   bool xfilter = false;        // expansion-filter scan on the sorted/centred target copy (largest launches); implies fused
   int xkind = 0;               // 0 VALU kernel, 1 f32 MFMA kernel, 2 both side by side, 3 split-bf16 MFMA kernel
+  bool pruned = false;         // OPTIONAL exact pruned scan (MI355_ICP_SCAN_MODE=pruned), never chosen by the planner
   uint32_t key_rows() const { return (xkind == 3 ? 2u : 1u) * max_split; }  // key rows per rank (wave halves publish separately)
   uint32_t key_ranks() const { return xfilter && xkind != 3 ? 4u : 3u; }       // the VALU expansion kernels also publish U
 };
@@ -84,6 +86,7 @@ void free_xcopy(XCopy& x) {  // the caller has drained the stream
   (void)hipFree(x.table);
   (void)hipFree(x.bf);
   (void)hipFree(x.sub);
+  (void)hipFree(x.super);
   x = XCopy{};
 }
 
@@ -367,6 +370,11 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   // ... and the split-bf16 matrix-core form of it (xkind 3: one issue slot per pair, 2.3x the VALU filter end to end at
   // 100k<->100k, 1M<->1M and 64 x 50k<->50k: profiles/r01n_baseline_configs.jsonl) is the default wherever it applies
   plan.xkind = c->scan_fused < 0 ? 3 : (c->scan_fused >= 2 ? c->scan_fused - 2 : 0);
+  if (c->scan_fused == 6) {  // the optional pruned scan: no keys, no filters, no splits
+    plan.pruned = true;
+    plan.fused = plan.xfilter = false;
+    plan.xkind = 0;
+  }
   if (plan.xfilter) plan.scan_ppl = c->scan_ppl ? c->scan_ppl : 4;
   if (plan.xfilter && plan.xkind && plan.scan_ppl != 2) plan.scan_ppl = 4;  // the MFMA kernel spans 128 * {4, 8} points
   if (plan.xfilter && plan.xkind == 3) plan.scan_ppl = 2;                     // split-bf16 kernel: 512 points per workgroup
@@ -412,6 +420,10 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   }
   plan.out_total = static_cast<uint32_t>(out_off);
   plan.partial_total = static_cast<uint32_t>(partial_off);
+  if (plan.pruned)  // the pruned kernel keeps a bitmap of needed tiles in LDS
+    for (const JobDesc& J : plan.jobs)
+      if (J.tgt_tiles > kPrunedMaxTiles) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "MI355_ICP_SCAN_MODE=pruned: a target cloud has more than 16M points");
+
   if (static_cast<uint64_t>(plan.key_rows()) * plan.out_total > 0xFFFF0000ull) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "batch too large");
   return MI355_ICP_OK;
 }
@@ -523,6 +535,7 @@ int ensure_xcopy(mi355_icp_ctx* c, DevicePlanes view, size_t stride, const std::
   if (!x.table) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.table), 4 * (stride / kTile) * sizeof(float)));
   if (!x.bf) HIP_TRY(c, hipMalloc(&x.bf, (stride / kTile) * static_cast<size_t>(kXbTileVecs) * 16));
   if (!x.sub) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.sub), (stride / 64) * 4 * sizeof(float)));
+  if (!x.super) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.super), (stride / kTile / kSuperTiles + 1) * 4 * sizeof(float)));
   uint32_t* code = c->xt_scratch;
   uint32_t* index = code + max_n;
   uint32_t* code2 = index + max_n;
@@ -537,12 +550,36 @@ int ensure_xcopy(mi355_icp_ctx* c, DevicePlanes view, size_t stride, const std::
     if (xtarget_build_cloud(c->stream, view, clouds[k].off, clouds[k].n, c->xt_box + 6 * k, code, index, code2, order, c->xt_temp,
                             temp_bytes, x.planes, stride, x.perm, x.table, x.bf, x.sub) != 0)
       return fail(c, MI355_ICP_ERR_HIP, "rocprim::radix_sort_pairs failed");
+  launch_super_tiles(c->stream, x.table, static_cast<uint32_t>(stride / kTile), x.super);
   HIP_TRY(c, hipGetLastError());
   x.valid = true;
   return MI355_ICP_OK;
 }
 
 int ensure_xtarget(mi355_icp_ctx* c, CloudSet& set) { return ensure_xcopy(c, set.view(), set.stride, set.clouds, set.xt); }
+
+// the sorted copy that was built from exactly these planes (level 0 or a pyramid level of `set`), if any
+const XCopy* find_xcopy(const CloudSet& set, const float* planes, size_t* stride) {
+  if (planes == set.planes) { *stride = set.stride; return &set.xt; }
+  for (const LevelPlanes& lv : set.levels)
+    if (planes == lv.planes) { *stride = lv.stride; return &lv.xt; }
+  return nullptr;
+}
+
+// OPTIONAL pruned scan: index and dist2 of every point, straight from the sorted copies of both clouds
+int run_pruned_index_phase(mi355_icp_ctx* c, int n_active, uint32_t sbx, DevicePlanes S, DevicePlanes T) {
+  size_t sstride = 0, tstride = 0;
+  const XCopy* xs = find_xcopy(c->sources, S.x, &sstride);
+  const XCopy* xt = find_xcopy(c->targets, T.x, &tstride);
+  if (!xs || !xt || !xs->valid || !xt->valid) return fail(c, MI355_ICP_ERR_INTERNAL, "pruned scan: sorted copies missing");
+  const float* sp = xs->planes;
+  const float* tp = xt->planes;
+  launch_nn_pruned(c->stream, c->jobs_dev, n_active, sbx, DevicePlanes{sp + 4 * sstride, sp + 5 * sstride, sp + 6 * sstride}, xs->perm,
+                   DevicePlanes{tp + 4 * tstride, tp + 5 * tstride, tp + 6 * tstride}, xt->perm, xt->table, xt->sub, xt->super,
+                   c->out_index, c->out_dist2, c->error_flag);
+  HIP_TRY(c, hipGetLastError());
+  return MI355_ICP_OK;
+}
 
 // Fused-filter path up to "index and dist2 of every point are final": filter scan -> exact resolve of the candidate
 // chunks -> (rarely) the all-exact scan for points whose candidates overflowed the band.  Records ev[1] after the scan.
@@ -673,10 +710,16 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
   // never launch against a buffer the planner did not size for this launch shape (an out-of-bounds kernel can take the GPU down)
   const size_t key_need = static_cast<size_t>(plan.fused ? plan.key_rows() : plan.max_split) * plan.out_total;
   if (plan.out_total > c->out_cap || static_cast<size_t>(plan.partial_total) * MI355_ICP_NSUMS > c->partials_cap ||
-      (plan.fused ? (plan.key_ranks() * key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : key_need > c->keys_cap))
+      (plan.pruned ? false : plan.fused ? (plan.key_ranks() * key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : key_need > c->keys_cap))
     return fail(c, MI355_ICP_ERR_INTERNAL, "work buffers are smaller than the plan (ensure_buffers not run for this plan)");
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-  if (plan.fused) {
+  if (plan.pruned) {
+    const int fst = run_pruned_index_phase(c, n_active, sbx, S, T);
+    if (fst != MI355_ICP_OK) return fst;
+    if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    if (sbx) launch_accumulate(c->stream, c->jobs_dev, n_active, sbx, S, T, c->out_index, c->out_dist2, c->partials);
+  } else if (plan.fused) {
     const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile, defer);
     if (fst != MI355_ICP_OK) return fst;
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
@@ -811,13 +854,17 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
   }
   const DevicePlanes S = level_view(c->sources, level), T = level_view(c->targets, level);
   const size_t ref_key_need = static_cast<size_t>(plan.fused ? plan.key_rows() : plan.max_split) * plan.out_total;
-  if ((plan.fused ? (plan.key_ranks() * ref_key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : ref_key_need > c->keys_cap) ||
+  if ((plan.pruned ? false : plan.fused ? (plan.key_ranks() * ref_key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : ref_key_need > c->keys_cap) ||
       plan.out_total > c->out_cap || plan.out_total > c->selected_cap || owner_total > c->owner_cap ||
       static_cast<size_t>(plan.partial_total) * kRefSums > c->ref_partials_cap ||
       static_cast<size_t>(plan.partial_total) * MI355_ICP_NSUMS > c->partials_cap)
     return fail(c, MI355_ICP_ERR_INTERNAL, "work buffers are smaller than the plan (reference mode)");
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-  if (plan.fused) {
+  if (plan.pruned) {
+    const int fst = run_pruned_index_phase(c, n_active, sbx, S, T);
+    if (fst != MI355_ICP_OK) return fst;
+    if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  } else if (plan.fused) {
     const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile, defer);
     if (fst != MI355_ICP_OK) return fst;
   } else {
@@ -906,6 +953,7 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
     if (mode && std::string(mode) == "xmfma") c->scan_fused = 3;   // expansion filter on the matrix cores only
     if (mode && std::string(mode) == "xhybrid") c->scan_fused = 4; // VALU and MFMA workgroups side by side
     if (mode && std::string(mode) == "xbf16") c->scan_fused = 5;   // expansion filter on the matrix cores, split-bf16 operands
+    if (mode && std::string(mode) == "pruned") c->scan_fused = 6;  // exact scan with tile/run pruning (not brute force)
     c->mfma_share_pct = env_u32("MI355_ICP_MFMA_SHARE", c->mfma_share_pct);
     if (c->scan_sgpr) c->scan_fused = 0;
   }
@@ -1028,7 +1076,8 @@ int mi355_icp_align(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const i
   int st = make_plan(c, n_jobs, source_ids, target_ids, params->max_correspondence_distance, plan);
   if (st != MI355_ICP_OK) return st;
   if ((st = ensure_buffers(c, plan, static_cast<size_t>(n_jobs))) != MI355_ICP_OK) return st;
-  if (plan.xfilter && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;
+  if ((plan.xfilter || plan.pruned) && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;
+  if (plan.pruned && (st = ensure_xtarget(c, c->sources)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
 
   struct JobState { double pose[16]; double prev_mse = 0.0; double residual = 0.0; int iters = 0; int status = MI355_ICP_OK; int converged = 0; };
@@ -1086,7 +1135,8 @@ int mi355_icp_correspond(mi355_icp_ctx* c, int n_jobs, const int* source_ids, co
   int st = make_plan(c, n_jobs, source_ids, target_ids, max_correspondence_distance, plan);
   if (st != MI355_ICP_OK) return st;
   if ((st = ensure_buffers(c, plan, static_cast<size_t>(n_jobs))) != MI355_ICP_OK) return st;
-  if (plan.xfilter && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;
+  if ((plan.xfilter || plan.pruned) && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;
+  if (plan.pruned && (st = ensure_xtarget(c, c->sources)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
   for (int k = 0; k < n_jobs; ++k) {
     JobDesc J = plan.jobs[static_cast<size_t>(k)];
@@ -1157,7 +1207,8 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
       owner_total += level_clouds(c->targets, level)[ptid[a]].padded;
     }
     if ((st = ensure_ref_buffers(c, plan, static_cast<size_t>(np), owner_total)) != MI355_ICP_OK) return st;
-    if (plan.xfilter && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
+    if ((plan.xfilter || plan.pruned) && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
+    if (plan.pruned && (st = ensure_level_xcopy(c, c->sources, level)) != MI355_ICP_OK) return st;
 
     const double tolp = static_cast<double>(rp->tolerance) * static_cast<double>(level + 1) * static_cast<double>(level + 1);
     const int maxit = static_cast<int>(std::floor(static_cast<double>(rp->iterations) / static_cast<double>(level + 1) + 0.5));
@@ -1245,7 +1296,8 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
   if ((st = ensure_buffers(c, plan, 1)) != MI355_ICP_OK) return st;
   const size_t owner_total = level_clouds(c->targets, level)[target_id].padded;
   if ((st = ensure_ref_buffers(c, plan, 1, owner_total)) != MI355_ICP_OK) return st;
-  if (plan.xfilter && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
+  if ((plan.xfilter || plan.pruned) && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
+  if (plan.pruned && (st = ensure_level_xcopy(c, c->sources, level)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
   JobDesc J = plan.jobs[0];
   RefJobDesc R{};
@@ -1392,7 +1444,8 @@ int mi355_icp_scene_normals(mi355_icp_ctx* c, int k, int flip_viewpoint, const f
   if (split >= 8) split -= split % 8;
   else if (split >= 4) split = 4;
   else if (split >= 2) split = 2;
-  if (!c->knn_brute) split = 1;  // the pruned scan keeps one list per point
+  const bool knn_brute = c->knn_brute || n_tiles > kPrunedMaxTiles;  // the pruned scan's tile bitmap lives in LDS
+  if (!knn_brute) split = 1;  // the pruned scan keeps one list per point
   const uint32_t q_stride = qblocks * kBlockThreads;
   const size_t list_len = static_cast<size_t>(split) * kk * q_stride;
   if ((st = grow(c, c->knn_d, c->knn_d_cap, list_len)) != MI355_ICP_OK) return st;
@@ -1407,7 +1460,7 @@ int mi355_icp_scene_normals(mi355_icp_ctx* c, int k, int flip_viewpoint, const f
   const float vp[3] = {viewpoint ? viewpoint[0] : 0.f, viewpoint ? viewpoint[1] : 0.f, viewpoint ? viewpoint[2] : 0.f};
   const bool profile = c->profile_always;
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-  if (c->knn_brute) {
+  if (knn_brute) {
     launch_knn_scan(c->stream, k, P, n, n_tiles, split, c->knn_d, c->knn_i, q_stride);
   } else {
     // Morton-sorted copy of the scene with per-tile bounding spheres (the same builder the ICP targets use), then the
@@ -1422,7 +1475,7 @@ int mi355_icp_scene_normals(mi355_icp_ctx* c, int k, int flip_viewpoint, const f
     if ((st = ensure_xcopy(c, P, padded, one, c->scene_xt)) != MI355_ICP_OK) return st;
     const float* xp = c->scene_xt.planes;
     launch_knn_pruned(c->stream, k, DevicePlanes{xp + 4 * static_cast<size_t>(padded), xp + 5 * static_cast<size_t>(padded), xp + 6 * static_cast<size_t>(padded)},
-                      c->scene_xt.perm, c->scene_xt.table, c->scene_xt.sub, n, n_tiles, c->knn_d, c->knn_i, q_stride);
+                      c->scene_xt.perm, c->scene_xt.table, c->scene_xt.sub, c->scene_xt.super, n, n_tiles, c->knn_d, c->knn_i, q_stride);
   }
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
   launch_normals(c->stream, k, P, n, k_eff, split, c->knn_d, c->knn_i, q_stride, flip_viewpoint ? 1 : 0, vp, c->scene_normals_aos,

@@ -36,6 +36,47 @@ __device__ __forceinline__ uint32_t bf16_bits(float x) {
   return x != x ? 0x7FC0u : r;
 }
 __device__ __forceinline__ float bf16_value(uint32_t bits) { return __uint_as_float(bits << 16); }
+
+// ---- sphere bounds of the pruned scans (nn_pruned_kernel, knn_pruned_kernel) ----
+// Lower bound of the contract squared distance from the point o to any point of the sphere c = (centre, r^2), with every
+// rounding pushed DOWN: relative margins of 2^-18 against float32 errors of a few 2^-24 (v_sqrt_f32 directly: its 1 ulp
+// is far inside the margins, and the correctly rounded sqrtf expands to fused multiply-adds, which `make check-isa` bans
+// from icp_kernels.hip).  0 when o may be inside the sphere; NaN when nothing can be said (overflow).
+__device__ __forceinline__ float sphere_lower_bound(float ox, float oy, float oz, float4 c) {
+  const float dx = ox - c.x, dy = oy - c.y, dz = oz - c.z;
+  float a = dx * dx;
+  const float b = dy * dy, e = dz * dz;
+  a = a + b;
+  a = a + e;
+  const float D = __builtin_amdgcn_sqrtf(a) * 0.999996185f;                                  // (1 - 2^-18)
+  const float gap = D - __builtin_amdgcn_sqrtf(c.w) * 1.000003815f - 1.17549435e-38f;        // (1 + 2^-18), FLT_MIN
+  float lb = gap * gap;
+  lb = lb * 0.999996185f;
+  return gap > 0.0f ? lb : (gap <= 0.0f ? 0.0f : gap);
+}
+// can the sphere hold a point at squared distance <= dk from o?  (NaN bounds answer yes)
+__device__ __forceinline__ bool sphere_reachable(float ox, float oy, float oz, float4 c, float dk) {
+  return !(sphere_lower_bound(ox, oy, oz, c) > dk);
+}
+constexpr int kSuperTiles = 16;          // tiles per super-tile sphere (the first level of the pruned scans' tile search)
+constexpr uint32_t kPrunedMaxTiles = 16384;  // bitmap of needed tiles held in LDS: 16M points per cloud
+
+// Marks in `need` (LDS bitmap, tile index relative to tile_base) every tile of [tile_base, tile_base + n_tiles) that some
+// lane of this wave can still reach with its current dk: super-tile spheres first, then the 16 tiles of a reachable one.
+__device__ __forceinline__ void mark_reachable_tiles(float qx, float qy, float qz, float dk, const float4* __restrict__ super_table,
+                                                     const float4* __restrict__ tile_table, uint32_t tile_base, uint32_t n_tiles,
+                                                     uint32_t* need) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t s0 = tile_base / kSuperTiles, s1 = (tile_base + n_tiles - 1) / kSuperTiles;
+  for (uint32_t sidx = s0; sidx <= s1; ++sidx) {
+    if (__builtin_amdgcn_ballot_w64(sphere_reachable(qx, qy, qz, super_table[sidx], dk)) == 0) continue;
+    const uint32_t t0 = sidx * kSuperTiles > tile_base ? sidx * kSuperTiles : tile_base;
+    const uint32_t t1 = (sidx + 1) * kSuperTiles < tile_base + n_tiles ? (sidx + 1) * kSuperTiles : tile_base + n_tiles;
+    for (uint32_t t = t0; t < t1; ++t)
+      if (__builtin_amdgcn_ballot_w64(sphere_reachable(qx, qy, qz, tile_table[t], dk)) != 0 && lane == 0)
+        atomicOr(&need[(t - tile_base) >> 5], 1u << ((t - tile_base) & 31u));
+  }
+}
 #endif
 
 // One alignment job as the kernels see it (read with scalar loads; 112 bytes).
@@ -125,6 +166,9 @@ void launch_resolve_xfilter(void* stream, int run_len, uint32_t split_mul, const
                             uint32_t max_src_blocks, DevicePlanes src, DevicePlanes sorted_original, const uint32_t* perm,
                             const unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride, int32_t* out_index,
                             float* out_dist2, uint32_t* overflow_list, uint32_t* overflow_count, uint32_t* error_flag);
+void launch_nn_pruned(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes sorted_src,
+                      const uint32_t* src_perm, DevicePlanes sorted_tgt, const uint32_t* tgt_perm, const void* tgt_table,
+                      const void* tgt_sub, const void* tgt_super, int32_t* out_index, float* out_dist2, uint32_t* error_flag);
 constexpr uint32_t kOverflowCap = 1024;  // overflow points per job the device-side exact pass takes without the host
 void launch_overflow_exact(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t cap, DevicePlanes src, DevicePlanes tgt,
                            const uint32_t* overflow_list, const uint32_t* overflow_count, int32_t* out_index, float* out_dist2,
@@ -158,6 +202,7 @@ int xtarget_sort_temp_bytes(uint32_t n, size_t* bytes);
 int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const uint32_t* box, uint32_t* code,
                         uint32_t* index, uint32_t* code2, uint32_t* order, void* temp, size_t temp_bytes, float* xt,
                         size_t stride, uint32_t* perm, float* table, void* bf_image, void* sub_table);
+void launch_super_tiles(void* stream, const float* table, uint32_t n_tiles_total, float* super_table);
 void launch_bbox(void* stream, DevicePlanes planes, const uint32_t* cloud_off, const uint32_t* cloud_n, int n_clouds, uint32_t max_n,
                  uint32_t* box);
 void launch_xt_fill(void* stream, float* xt, size_t stride, uint32_t* perm, void* bf_image);
@@ -166,7 +211,8 @@ void launch_xt_fill(void* stream, float* xt, size_t stride, uint32_t* perm, void
 constexpr int kMaxNormalNeighbors = 32;
 void launch_knn_scan(void* stream, int k, DevicePlanes planes, uint32_t n, uint32_t n_tiles, uint32_t n_split,
                      float* list_d, int32_t* list_i, uint32_t q_stride);
-void launch_knn_pruned(void* stream, int k, DevicePlanes sorted, const uint32_t* perm, const void* table, const void* sub_table, uint32_t n,
+void launch_knn_pruned(void* stream, int k, DevicePlanes sorted, const uint32_t* perm, const void* table, const void* sub_table,
+                       const void* super_table, uint32_t n,
                        uint32_t n_tiles, float* list_d, int32_t* list_i, uint32_t q_stride);
 void launch_normals(void* stream, int k, DevicePlanes planes, uint32_t n, uint32_t k_eff, uint32_t n_split,
                     const float* list_d, const int32_t* list_i, uint32_t q_stride, int flip, const float* viewpoint,

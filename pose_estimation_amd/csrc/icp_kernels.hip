@@ -708,6 +708,208 @@ __global__ __launch_bounds__(kTile) void overflow_exact_kernel(
   }
 }
 
+// =====================================================================================================================
+// OPTIONAL exact nearest neighbour WITH pruning (MI355_ICP_SCAN_MODE=pruned; never the default: north_star's metric is
+// brute force, and bench.py measures that).  Same results - the (d2, original index)-lexicographic minimum of the
+// contract formula over ALL targets - from a fraction of the distance evaluations:
+//   * sources and targets both have a Morton-sorted copy (xtarget_kernels.hip) with a bounding sphere per 1024-point
+//     tile and per 64-point run; a workgroup takes 256 consecutive SORTED source points - a rigid pose keeps them
+//     spatially coherent - transforms them with the contract transform and bounds them by a sphere (cq, rq);
+//   * every tile holds a point within (|cq - c| + rq + r) of every query: the smallest such bound picks the first tile,
+//     which is scanned exhaustively; afterwards each lane's best distance is exact and an upper bound of its minimum;
+//   * a tile (or 64-point run) whose nearest possible point is farther than a lane's best can hold neither its minimum
+//     nor a tie with it, so: tiles are listed once against the workgroup's largest best (dk), visited nearest first
+//     through LDS with dk refreshed after every visit (the walk stops at the first tile out of reach), and each wave
+//     scans only the runs one of its lanes can still reach.
+// All bound arithmetic rounds towards "needed" (relative margins of 2^-18 against float32 errors of a few 2^-24; NaN and
+// overflow compare false = needed).  Known weakness: a workgroup whose run straddles a Morton jump has a huge sphere and
+// visits most tiles (58 of 4096 workgroups at 1M<->1M); the k-NN kernel's per-lane tile search avoids that but measured
+// slower here, where the seed tiles are poorer than a scene point's own tile.
+// (v_sqrt_f32 directly: its 1 ulp is far inside the margins, and the correctly rounded sqrtf expands to fused
+// multiply-adds, which `make check-isa` bans from this file wholesale)
+__device__ __forceinline__ bool sphere_needed(float ox, float oy, float oz, float orad, float4 c, float dk) {
+  const float D = __builtin_amdgcn_sqrtf(dist2(ox, oy, oz, c.x, c.y, c.z)) * 0.999996185f;                  // (1 - 2^-18)
+  const float gap = D - (orad + __builtin_amdgcn_sqrtf(c.w)) * 1.000003815f - 1.17549435e-38f;             // (1 + 2^-18), FLT_MIN
+  float lb = gap * gap;
+  lb = lb * 0.999996185f;
+  return !(gap > 0.0f && lb > dk);
+}
+
+// lower bound (rounded down, see above) of the squared distance from any point of the sphere (o, orad) to any point of the
+// sphere c = (centre, r^2); 0 when the spheres may touch; NaN when nothing can be said (overflow) - callers treat NaN as 0
+__device__ __forceinline__ float sphere_pair_lower_bound(float ox, float oy, float oz, float orad, float4 c) {
+  const float D = __builtin_amdgcn_sqrtf(dist2(ox, oy, oz, c.x, c.y, c.z)) * 0.999996185f;
+  const float gap = D - (orad + __builtin_amdgcn_sqrtf(c.w)) * 1.000003815f - 1.17549435e-38f;
+  float lb = gap * gap;
+  lb = lb * 0.999996185f;
+  return gap > 0.0f ? lb : (gap <= 0.0f ? 0.0f : gap);  // gap NaN -> NaN
+}
+
+__global__ __launch_bounds__(kBlockThreads) void nn_pruned_kernel(
+    const JobDesc* __restrict__ jobs, const float* __restrict__ ssx, const float* __restrict__ ssy,
+    const float* __restrict__ ssz, const uint32_t* __restrict__ sperm, const float* __restrict__ tsx,
+    const float* __restrict__ tsy, const float* __restrict__ tsz, const uint32_t* __restrict__ tperm,
+    const float4* __restrict__ ttable, const float4* __restrict__ tsub, int32_t* __restrict__ out_index,
+    float* __restrict__ out_dist2, uint32_t* __restrict__ error_flag) {
+  constexpr uint32_t kMaxCand = 1024;
+  __shared__ float4 lds[4][kTile / 4];  // x, y, z (sorted order) and original indices of one target tile
+  __shared__ float4 lds_sphere[kTile / 64 + 1];  // ... the bounding spheres of its 16 runs and its own
+  __shared__ unsigned long long cand[kMaxCand], sorted[kMaxCand];  // (lower-bound bits << 32 | tile)
+  __shared__ uint32_t n_cand;
+  __shared__ uint32_t red_a[kBlockThreads / 64];
+  __shared__ float red[7][kBlockThreads / 64];
+  __shared__ unsigned long long first_key[kBlockThreads / 64];
+  const JobDesc& J = jobs[blockIdx.y];
+  if (blockIdx.x * kBlockThreads >= J.src_n) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t pos = blockIdx.x * kBlockThreads + tid;
+  const uint32_t pc = J.src_off + (pos < J.src_n ? pos : J.src_n - 1);  // out-of-range lanes shadow the last point
+  float pose[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
+  float qx, qy, qz;
+  transform_point(pose, ssx[pc], ssy[pc], ssz[pc], qx, qy, qz);
+  const uint32_t n_tiles = J.tgt_tiles, tile_base = J.tgt_off / kTile;
+  float best = __builtin_inff();
+  uint32_t best_j = 0xFFFFFFFFu;
+  const float4* __restrict__ gx = reinterpret_cast<const float4*>(tsx + J.tgt_off);
+  const float4* __restrict__ gy = reinterpret_cast<const float4*>(tsy + J.tgt_off);
+  const float4* __restrict__ gz = reinterpret_cast<const float4*>(tsz + J.tgt_off);
+  const float4* __restrict__ gp = reinterpret_cast<const float4*>(tperm + J.tgt_off);
+  // stage one target tile through LDS; every wave scans the 64-point runs one of its lanes can still reach
+  auto scan_tile = [&](uint32_t tile) {
+    const uint32_t g0 = tile * (kTile / 4) + tid;
+    lds[0][tid] = gx[g0];
+    lds[1][tid] = gy[g0];
+    lds[2][tid] = gz[g0];
+    lds[3][tid] = gp[g0];
+    // the spheres travel with the tile: fetched one by one from global memory by every wave, their latency was most of
+    // a visit's cost
+    if (tid < kTile / 64) lds_sphere[tid] = tsub[(tile_base + tile) * (kTile / 64) + tid];
+    if (tid == kTile / 64) lds_sphere[tid] = ttable[tile_base + tile];
+    __syncthreads();
+    if (__builtin_amdgcn_ballot_w64(sphere_needed(qx, qy, qz, 0.0f, lds_sphere[kTile / 64], best)) != 0) {
+      for (uint32_t sub = 0; sub < kTile / 64; ++sub) {
+        const bool reach = sphere_needed(qx, qy, qz, 0.0f, lds_sphere[sub], best);
+        if (__builtin_amdgcn_ballot_w64(reach) == 0) continue;
+#pragma unroll 4
+        for (uint32_t g = sub * 16; g < sub * 16 + 16; ++g) {
+          const float4 X = lds[0][g], Y = lds[1][g], Z = lds[2][g], P = lds[3][g];
+          const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+          const uint32_t js[4] = {__float_as_uint(P.x), __float_as_uint(P.y), __float_as_uint(P.z), __float_as_uint(P.w)};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = dist2(qx, qy, qz, xs[e], ys[e], zs[e]);
+            if (d < best || (d == best && js[e] < best_j)) {
+              best = d;
+              best_j = js[e];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  };
+  // dk: the largest best distance over the workgroup's lanes (best is never NaN nor negative: unsigned order of the
+  // bits is float order), wave-uniform DPP reductions + one LDS hop
+  auto block_dk = [&]() {
+    const uint32_t wk = ~wave_min_u32(~__float_as_uint(best));
+    if (lane == 0) red_a[wave] = wk;
+    __syncthreads();
+    uint32_t r = red_a[0];
+#pragma unroll
+    for (int w = 1; w < kBlockThreads / 64; ++w) r = red_a[w] > r ? red_a[w] : r;
+    __syncthreads();
+    return r;
+  };
+  // the workgroup's query sphere
+  float v[6] = {qx, qy, qz, -qx, -qy, -qz};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v[k] = __builtin_fmaxf(v[k], __shfl_xor(v[k], off, 64));
+    if (lane == 0) red[k][wave] = v[k];
+  }
+  if (tid == 0) n_cand = 0;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    v[k] = red[k][0];
+#pragma unroll
+    for (int w = 1; w < kBlockThreads / 64; ++w) v[k] = __builtin_fmaxf(v[k], red[k][w]);
+  }
+  const float cqx = 0.5f * v[0] - 0.5f * v[3], cqy = 0.5f * v[1] - 0.5f * v[4], cqz = 0.5f * v[2] - 0.5f * v[5];
+  float rq2 = dist2(qx, qy, qz, cqx, cqy, cqz);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) rq2 = __builtin_fmaxf(rq2, __shfl_xor(rq2, off, 64));
+  if (lane == 0) red[6][wave] = rq2;
+  __syncthreads();
+  rq2 = red[6][0];
+#pragma unroll
+  for (int w = 1; w < kBlockThreads / 64; ++w) rq2 = __builtin_fmaxf(rq2, red[6][w]);
+  const float rq = __builtin_amdgcn_sqrtf(rq2) * 1.000003815f;
+  // first tile: the one whose farthest possible point is nearest (any tile would do for correctness)
+  unsigned long long fk = ~0ull;
+  for (uint32_t t = tid; t < n_tiles; t += kBlockThreads) {
+    const float4 c = ttable[tile_base + t];
+    const float u = __builtin_amdgcn_sqrtf(dist2(cqx, cqy, cqz, c.x, c.y, c.z)) + rq + __builtin_amdgcn_sqrtf(c.w);
+    const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(u)) << 32) | t;  // u >= 0 or NaN (sorts last)
+    fk = key < fk ? key : fk;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(fk, off, 64);
+    fk = o < fk ? o : fk;
+  }
+  if (lane == 0) first_key[wave] = fk;
+  __syncthreads();
+  fk = first_key[0];
+#pragma unroll
+  for (int w = 1; w < kBlockThreads / 64; ++w) fk = first_key[w] < fk ? first_key[w] : fk;
+  const uint32_t first = static_cast<uint32_t>(fk);
+  scan_tile(first);
+  uint32_t dk_bits = block_dk();
+  // every other tile whose lower bound does not exceed dk, nearest first
+  for (uint32_t t = tid; t < n_tiles; t += kBlockThreads) {
+    if (t == first) continue;
+    const float lb = sphere_pair_lower_bound(cqx, cqy, cqz, rq, ttable[tile_base + t]);
+    const uint32_t lbb = lb >= 0.0f ? __float_as_uint(lb) : 0u;  // NaN: nothing known, treat as 0
+    if (lbb <= dk_bits) {
+      const uint32_t slot = atomicAdd(&n_cand, 1u);
+      if (slot < kMaxCand) cand[slot] = (static_cast<unsigned long long>(lbb) << 32) | t;
+    }
+  }
+  __syncthreads();
+  const uint32_t nc = n_cand;
+  if (nc > kMaxCand) {  // more candidates than the list holds: visit every tile
+    for (uint32_t t = 0; t < n_tiles; ++t)
+      if (t != first) scan_tile(t);
+  } else {
+    for (uint32_t i = tid; i < nc; i += kBlockThreads) {  // rank sort (keys are distinct: the tile id is part of them)
+      const unsigned long long key = cand[i];
+      uint32_t rank = 0;
+      for (uint32_t k = 0; k < nc; ++k) rank += cand[k] < key ? 1u : 0u;
+      sorted[rank] = key;
+    }
+    __syncthreads();
+    for (uint32_t k = 0; k < nc; ++k) {
+      const unsigned long long key = sorted[k];
+      if (static_cast<uint32_t>(key >> 32) > dk_bits) break;  // this tile and all later ones are out of reach (uniform)
+      scan_tile(static_cast<uint32_t>(key));
+      dk_bits = block_dk();
+    }
+  }
+  if (pos < J.src_n) {
+    const uint32_t orig = sperm[J.src_off + pos];
+    if (best_j == 0xFFFFFFFFu) {  // nothing but NaN distances: same report as the all-exact resolve
+      atomicOr(error_flag, 1u);
+      best_j = 0;
+    }
+    out_index[J.out_off + orig] = static_cast<int32_t>(best_j);
+    out_dist2[J.out_off + orig] = best;
+  }
+}
+
 // N2 for the fused path: accumulation over ALL points after every index is known (fixed order: same bits every run)
 __global__ __launch_bounds__(kBlockThreads) void accumulate_kernel(const JobDesc* __restrict__ jobs,
                                                                     const float* __restrict__ sx, const float* __restrict__ sy,
@@ -887,6 +1089,17 @@ void launch_overflow_exact(void* stream, const JobDesc* jobs_dev, int n_jobs, ui
   hipLaunchKernelGGL(overflow_exact_kernel, dim3(cap, static_cast<uint32_t>(n_jobs)), dim3(kTile), 0,
                      static_cast<hipStream_t>(stream), jobs_dev, src.x, src.y, src.z, tgt.x, tgt.y, tgt.z, overflow_list, overflow_count,
                      out_index, out_dist2, error_flag);
+}
+
+void launch_nn_pruned(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes sorted_src,
+                      const uint32_t* src_perm, DevicePlanes sorted_tgt, const uint32_t* tgt_perm, const void* tgt_table,
+                      const void* tgt_sub, const void* tgt_super, int32_t* out_index, float* out_dist2, uint32_t* error_flag) {
+  if (!max_src_blocks) return;
+  dim3 grid(max_src_blocks * kResolvePointsPerLane, static_cast<uint32_t>(n_jobs));  // one workgroup per 256 sorted points
+  hipLaunchKernelGGL(nn_pruned_kernel, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, sorted_src.x,
+                     sorted_src.y, sorted_src.z, src_perm, sorted_tgt.x, sorted_tgt.y, sorted_tgt.z, tgt_perm,
+                     static_cast<const float4*>(tgt_table), static_cast<const float4*>(tgt_sub), out_index, out_dist2, error_flag);
+  (void)tgt_super;  // the k-NN scan's per-lane tile search uses it; here it measured slower than the workgroup sphere
 }
 
 void launch_accumulate(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,

@@ -153,32 +153,28 @@ __device__ __forceinline__ void list_insert_lex(float (&d)[K], int32_t (&ix)[K],
   }
 }
 
-// Exact K nearest neighbours WITH tile pruning (scene normals are not under north_star's brute-force mandate; the ICP
-// scan is).  Works on the Morton-sorted copy of the scene (xtarget_kernels.hip): a workgroup takes 256 CONSECUTIVE
-// sorted positions - spatially coherent queries - and
+// Exact K nearest neighbours WITH pruning (scene normals are not under north_star's brute-force mandate; the ICP scan
+// is).  Works on the Morton-sorted copy of the scene (xtarget_kernels.hip), which carries a bounding sphere per 64-point
+// run, per 1024-point tile and per 16 tiles.  A workgroup takes 256 CONSECUTIVE sorted positions - spatially coherent
+// queries - and
 //   1. scans its own tile exhaustively, which fills every lane's K-list with near neighbours;
-//   2. bounds its queries by a sphere (cq, rq) and takes the largest K-th distance dk over its lanes; a tile with
-//      bounding sphere (c, r) can only matter if its nearest possible point is within dk of some query:
-//            gap = |cq - c| - rq - r,   tile needed unless gap > 0 and gap^2 > dk
-//      evaluated with every rounding pushed towards "needed" (relative margins of 2^-18 against float32 errors of a
-//      few 2^-24; NaN / overflow compare false, i.e. "needed"), each thread testing n_tiles / 256 tiles;
-//   3. scans the surviving tiles exhaustively (typically 5-15 of ~1000 at 1M points), each wave skipping a tile none of
-//      its own lanes needs by the same test with its lane's current dk.
-// A pruned tile holds no point that is closer than, or tied with, any lane's K-th neighbour, so the lists are exactly
+//   2. lets every lane mark the tiles whose sphere its current K-th distance still reaches (sphere_lower_bound,
+//      icp_internal.h: every rounding pushed towards "reachable"; super-tile spheres first);
+//   3. stages the union tile by tile through LDS, each wave scanning only the runs one of its own lanes still reaches.
+// A pruned tile or run holds no point that is closer than, or tied with, any lane's K-th neighbour, so the lists are exactly
 // those of the exhaustive scan: (d2, original index)-sorted, the oracle's order.  Results are stored at the ORIGINAL index.
 template <int K>
 __global__ __launch_bounds__(kBlockThreads) void knn_pruned_kernel(const float* __restrict__ sox, const float* __restrict__ soy,
                                                                     const float* __restrict__ soz, const uint32_t* __restrict__ perm,
                                                                     const float4* __restrict__ table,
-                                                                    const float4* __restrict__ sub_table, uint32_t n, uint32_t n_tiles,
-                                                                    float* __restrict__ list_d, int32_t* __restrict__ list_i,
-                                                                    uint32_t q_stride) {
-  constexpr uint32_t kMaxCand = 2048;
-  __shared__ float4 lds[4][kTile / 4];  // x, y, z (sorted order, uncentred) and original indices of one tile
-  __shared__ uint32_t cand[kMaxCand];
-  __shared__ uint32_t n_cand;
-  __shared__ float red[8][kBlockThreads / 64];
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+                                                                    const float4* __restrict__ sub_table,
+                                                                    const float4* __restrict__ super_table, uint32_t n,
+                                                                    uint32_t n_tiles, float* __restrict__ list_d,
+                                                                    int32_t* __restrict__ list_i, uint32_t q_stride) {
+  __shared__ float4 lds[4][kTile / 4];           // x, y, z (sorted order, uncentred) and original indices of one tile
+  __shared__ float4 lds_sphere[kTile / 64 + 1];  // ... the bounding spheres of its 16 runs and its own
+  __shared__ uint32_t need[kPrunedMaxTiles / 32];
+  const uint32_t tid = threadIdx.x;
   const uint32_t pos = blockIdx.x * kBlockThreads + tid;
   const uint32_t pc = pos < n ? pos : n - 1;  // out-of-range lanes shadow the last point and store nothing
   const float qx = sox[pc], qy = soy[pc], qz = soz[pc];
@@ -194,89 +190,52 @@ __global__ __launch_bounds__(kBlockThreads) void knn_pruned_kernel(const float* 
   const float4* __restrict__ gy = reinterpret_cast<const float4*>(soy);
   const float4* __restrict__ gz = reinterpret_cast<const float4*>(soz);
   const float4* __restrict__ gp = reinterpret_cast<const float4*>(perm);
-  // can the tile with bounding sphere (c, r2) hold a point within sqrt(dk) of a query inside the sphere (o, orad)?
-  auto needed = [&](float ox, float oy, float oz, float orad, float4 c, float dk) {
-    const float D = __builtin_sqrtf(dist2(ox, oy, oz, c.x, c.y, c.z)) * 0.999996185f;                  // (1 - 2^-18)
-    const float gap = D - (orad + __builtin_sqrtf(c.w)) * 1.000003815f - 1.17549435e-38f;             // (1 + 2^-18), FLT_MIN
-    return !(gap > 0.0f && gap * gap * 0.999996185f > dk);
-  };
-  // exhaustive scan of one tile; `skip` (wave-uniform) lets a wave sit a tile out but keeps it in the barriers
-  auto scan_tile = [&](uint32_t tile, bool skip) {
+  // stage one tile through LDS (its spheres travel with it); every wave scans the 64-point runs one of its lanes can
+  // still reach with its current K-th distance
+  auto scan_tile = [&](uint32_t tile) {
     const uint32_t g0 = tile * (kTile / 4) + tid;
     lds[0][tid] = gx[g0];
     lds[1][tid] = gy[g0];
     lds[2][tid] = gz[g0];
     lds[3][tid] = gp[g0];
+    if (tid < kTile / 64) lds_sphere[tid] = sub_table[tile * (kTile / 64) + tid];
+    if (tid == kTile / 64) lds_sphere[tid] = table[tile];
     __syncthreads();
-    if (!skip) {
+    if (__builtin_amdgcn_ballot_w64(sphere_reachable(qx, qy, qz, lds_sphere[kTile / 64], d[K - 1])) != 0) {
       for (uint32_t sub = 0; sub < kTile / 64; ++sub) {
-        // a 64-point run none of this wave's queries can reach is skipped (same test, the run's own sphere)
-        const bool reach = needed(qx, qy, qz, 0.0f, sub_table[tile * (kTile / 64) + sub], d[K - 1]);
-        if (__builtin_amdgcn_ballot_w64(reach) == 0) continue;
+        if (__builtin_amdgcn_ballot_w64(sphere_reachable(qx, qy, qz, lds_sphere[sub], d[K - 1])) == 0) continue;
 #pragma unroll 2
-      for (uint32_t g = sub * 16; g < sub * 16 + 16; ++g) {
-        const float4 X = lds[0][g], Y = lds[1][g], Z = lds[2][g], P = lds[3][g];
-        const float d0 = dist2(qx, qy, qz, X.x, Y.x, Z.x);
-        const float d1 = dist2(qx, qy, qz, X.y, Y.y, Z.y);
-        const float d2 = dist2(qx, qy, qz, X.z, Y.z, Z.z);
-        const float d3 = dist2(qx, qy, qz, X.w, Y.w, Z.w);
-        const float m = __builtin_fminf(__builtin_fminf(d0, d1), __builtin_fminf(d2, d3));
-        if (m <= d[K - 1]) {  // rare once the list has warmed up (<=: an equal distance with a lower index still enters)
-          list_insert_lex<K>(d, ix, d0, static_cast<int32_t>(__float_as_uint(P.x)));
-          list_insert_lex<K>(d, ix, d1, static_cast<int32_t>(__float_as_uint(P.y)));
-          list_insert_lex<K>(d, ix, d2, static_cast<int32_t>(__float_as_uint(P.z)));
-          list_insert_lex<K>(d, ix, d3, static_cast<int32_t>(__float_as_uint(P.w)));
+        for (uint32_t g = sub * 16; g < sub * 16 + 16; ++g) {
+          const float4 X = lds[0][g], Y = lds[1][g], Z = lds[2][g], P = lds[3][g];
+          const float d0 = dist2(qx, qy, qz, X.x, Y.x, Z.x);
+          const float d1 = dist2(qx, qy, qz, X.y, Y.y, Z.y);
+          const float d2 = dist2(qx, qy, qz, X.z, Y.z, Z.z);
+          const float d3 = dist2(qx, qy, qz, X.w, Y.w, Z.w);
+          const float m = __builtin_fminf(__builtin_fminf(d0, d1), __builtin_fminf(d2, d3));
+          if (m <= d[K - 1]) {  // rare once the list has warmed up (<=: an equal distance with a lower index still enters)
+            list_insert_lex<K>(d, ix, d0, static_cast<int32_t>(__float_as_uint(P.x)));
+            list_insert_lex<K>(d, ix, d1, static_cast<int32_t>(__float_as_uint(P.y)));
+            list_insert_lex<K>(d, ix, d2, static_cast<int32_t>(__float_as_uint(P.z)));
+            list_insert_lex<K>(d, ix, d3, static_cast<int32_t>(__float_as_uint(P.w)));
+          }
         }
-      }
       }
     }
     __syncthreads();
   };
-  if (tid == 0) n_cand = 0;
-  scan_tile(own, false);
-  // the workgroup's query sphere and its largest K-th distance
-  float v[8] = {qx, qy, qz, -qx, -qy, -qz, d[K - 1], 0.f};  // maxima of these: -min(x) etc.
-#pragma unroll
-  for (int k = 0; k < 7; ++k) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v[k] = __builtin_fmaxf(v[k], __shfl_xor(v[k], off, 64));
-    if (lane == 0) red[k][wave] = v[k];
-  }
+  for (uint32_t w = tid; w < kPrunedMaxTiles / 32; w += kBlockThreads) need[w] = 0u;
+  scan_tile(own);  // fills every lane's K-list with near neighbours: d[K - 1] bounds what any other point has to beat
+  // every other tile some lane can still reach with its own K-th distance: super-tile spheres, then tile spheres.  No
+  // bound is taken over a group of queries, so a Morton jump inside the run costs twice the tiles, not all of them.
+  mark_reachable_tiles(qx, qy, qz, d[K - 1], super_table, table, 0, n_tiles, need);
   __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 7; ++k) {
-    v[k] = red[k][0];
-#pragma unroll
-    for (int w = 1; w < kBlockThreads / 64; ++w) v[k] = __builtin_fmaxf(v[k], red[k][w]);
-  }
-  const float cqx = 0.5f * v[0] - 0.5f * v[3], cqy = 0.5f * v[1] - 0.5f * v[4], cqz = 0.5f * v[2] - 0.5f * v[5];
-  const float dk_max = v[6];  // +inf while any list is not full (or NaN-free by construction: d is never NaN)
-  float rq2 = dist2(qx, qy, qz, cqx, cqy, cqz);
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) rq2 = __builtin_fmaxf(rq2, __shfl_xor(rq2, off, 64));
-  __syncthreads();  // red[] is reused
-  if (lane == 0) red[7][wave] = rq2;
-  __syncthreads();
-  rq2 = red[7][0];
-#pragma unroll
-  for (int w = 1; w < kBlockThreads / 64; ++w) rq2 = __builtin_fmaxf(rq2, red[7][w]);
-  const float rq = __builtin_sqrtf(rq2) * 1.000003815f;
-  bool too_many = false;
-  for (uint32_t t = tid; t < n_tiles; t += kBlockThreads) {
-    if (t != own && needed(cqx, cqy, cqz, rq, table[t], dk_max)) {
-      const uint32_t slot = atomicAdd(&n_cand, 1u);
-      if (slot < kMaxCand) cand[slot] = t;
+  for (uint32_t w = 0; w < (n_tiles + 31) / 32; ++w) {
+    uint32_t word = __builtin_amdgcn_readfirstlane(need[w]);
+    while (word) {
+      const uint32_t t = w * 32 + static_cast<uint32_t>(__builtin_ctz(word));
+      word &= word - 1;
+      if (t != own) scan_tile(t);
     }
-  }
-  __syncthreads();
-  const uint32_t nc = n_cand;
-  too_many = nc > kMaxCand;
-  const uint32_t visits = too_many ? n_tiles : nc;  // more candidates than the list holds: visit every tile
-  for (uint32_t k = 0; k < visits; ++k) {
-    const uint32_t t = too_many ? k : cand[k];
-    if (too_many && t == own) continue;
-    const bool mine = needed(qx, qy, qz, 0.0f, table[t], d[K - 1]);
-    scan_tile(t, __builtin_amdgcn_ballot_w64(mine) == 0);
   }
   if (pos < n) {
     const uint32_t orig = perm[pos];
@@ -424,22 +383,23 @@ void launch_knn_scan(void* stream, int k, DevicePlanes planes, uint32_t n, uint3
 }
 
 // the pruned scan on the sorted copy (sorted original coordinates, sorted position -> original index, per-tile spheres)
-void launch_knn_pruned(void* stream, int k, DevicePlanes sorted, const uint32_t* perm, const void* table, const void* sub_table, uint32_t n,
-                       uint32_t n_tiles, float* list_d, int32_t* list_i, uint32_t q_stride) {
+void launch_knn_pruned(void* stream, int k, DevicePlanes sorted, const uint32_t* perm, const void* table, const void* sub_table,
+                       const void* super_table, uint32_t n, uint32_t n_tiles, float* list_d, int32_t* list_i, uint32_t q_stride) {
   const uint32_t qblocks = (n + kBlockThreads - 1) / kBlockThreads;
   if (!qblocks) return;
   dim3 grid(qblocks);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float4* tb = static_cast<const float4*>(table);
   const float4* sb = static_cast<const float4*>(sub_table);
+  const float4* pb = static_cast<const float4*>(super_table);
   if (k <= 8)
-    hipLaunchKernelGGL(knn_pruned_kernel<8>, grid, dim3(kBlockThreads), 0, st, sorted.x, sorted.y, sorted.z, perm, tb, sb, n, n_tiles, list_d,
+    hipLaunchKernelGGL(knn_pruned_kernel<8>, grid, dim3(kBlockThreads), 0, st, sorted.x, sorted.y, sorted.z, perm, tb, sb, pb, n, n_tiles, list_d,
                        list_i, q_stride);
   else if (k <= 20)
-    hipLaunchKernelGGL(knn_pruned_kernel<20>, grid, dim3(kBlockThreads), 0, st, sorted.x, sorted.y, sorted.z, perm, tb, sb, n, n_tiles, list_d,
+    hipLaunchKernelGGL(knn_pruned_kernel<20>, grid, dim3(kBlockThreads), 0, st, sorted.x, sorted.y, sorted.z, perm, tb, sb, pb, n, n_tiles, list_d,
                        list_i, q_stride);
   else
-    hipLaunchKernelGGL(knn_pruned_kernel<32>, grid, dim3(kBlockThreads), 0, st, sorted.x, sorted.y, sorted.z, perm, tb, sb, n, n_tiles, list_d,
+    hipLaunchKernelGGL(knn_pruned_kernel<32>, grid, dim3(kBlockThreads), 0, st, sorted.x, sorted.y, sorted.z, perm, tb, sb, pb, n, n_tiles, list_d,
                        list_i, q_stride);
 }
 

@@ -256,6 +256,40 @@ __global__ __launch_bounds__(kBlockThreads) void xt_fill_kernel(float* __restric
   perm[i] = 0u;
 }
 
+// one thread per super-tile: a sphere around 16 consecutive tile spheres (centre = mean of their centres, radius = the
+// farthest reach of any of them, rounded up).  Tiles the builder never wrote (r^2 = 0 at the origin) only widen it.
+__global__ __launch_bounds__(kBlockThreads) void super_tile_kernel(const float4* __restrict__ table, uint32_t n_tiles,
+                                                                    float4* __restrict__ super_table) {
+  const uint32_t s = blockIdx.x * kBlockThreads + threadIdx.x;
+  const uint32_t t0 = s * kSuperTiles;
+  if (t0 >= n_tiles) return;
+  const uint32_t t1 = t0 + kSuperTiles < n_tiles ? t0 + kSuperTiles : n_tiles;
+  double cx = 0, cy = 0, cz = 0;
+  for (uint32_t t = t0; t < t1; ++t) {
+    cx += table[t].x;
+    cy += table[t].y;
+    cz += table[t].z;
+  }
+  const double inv = 1.0 / static_cast<double>(t1 - t0);
+  const float fx = static_cast<float>(cx * inv), fy = static_cast<float>(cy * inv), fz = static_cast<float>(cz * inv);
+  double reach = 0.0;
+  for (uint32_t t = t0; t < t1; ++t) {
+    const double ex = static_cast<double>(table[t].x) - fx, ey = static_cast<double>(table[t].y) - fy, ez = static_cast<double>(table[t].z) - fz;
+    const double r = __builtin_sqrt(ex * ex + ey * ey + ez * ez) + __builtin_sqrt(static_cast<double>(table[t].w));
+    reach = r > reach ? r : reach;
+  }
+  const double r2 = reach * reach * (1.0 + 1e-6);
+  super_table[s] = make_float4(fx, fy, fz, __uint_as_float(__float_as_uint(static_cast<float>(r2)) + 1u));
+}
+
+void launch_super_tiles(void* stream, const float* table, uint32_t n_tiles_total, float* super_table) {
+  const uint32_t n_super = (n_tiles_total + kSuperTiles - 1) / kSuperTiles;
+  if (!n_super) return;
+  hipLaunchKernelGGL(super_tile_kernel, dim3((n_super + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0,
+                     static_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(table), n_tiles_total,
+                     reinterpret_cast<float4*>(super_table));
+}
+
 int xtarget_sort_temp_bytes(uint32_t n, size_t* bytes) {
   uint32_t* k = nullptr;
   size_t tmp = 0;

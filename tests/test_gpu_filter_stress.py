@@ -1,4 +1,4 @@
-"""Randomised A/B of the matrix-core filter path against the all-exact scan (both on the GPU, bit-for-bit): clouds of
+"""Randomised A/B of the matrix-core filter path (and of the optional pruned scan) against the all-exact scan (both on the GPU, bit-for-bit): clouds of
 random size, scale (1e-4 .. 1e4), offset from the origin, anisotropy and clustering, under random rigid poses.  The
 exact engine is itself pinned to the oracle by test_gpu_parity.py; this battery is about the filter's error band
 (icp_fused_kernels.hip) on geometry the named tests do not cover.  MI355_ICP_STRESS_CASES raises the case count."""
@@ -48,7 +48,7 @@ def random_cloud(rng, n):
 
 def test_matrix_core_filter_equals_the_exact_scan_on_random_geometry():
     rng = np.random.default_rng(20261004)
-    with engine_with_mode("xbf16") as fast, engine_with_mode("exact") as exact:
+    with engine_with_mode("xbf16") as fast, engine_with_mode("exact") as exact, engine_with_mode("pruned") as pruned:
         for case in range(CASES):
             ns, nt = int(rng.integers(100, 30000)), int(rng.integers(100, 60000))
             tgt = random_cloud(rng, nt)
@@ -59,10 +59,12 @@ def test_matrix_core_filter_equals_the_exact_scan_on_random_geometry():
                 src = random_cloud(rng, ns)
                 pose = st.rigid_transform(rng.uniform(0, 180), rng.standard_normal(3), rng.standard_normal(3))
             out = []
-            for eng in (fast, exact):
+            for eng in (fast, exact, pruned):
                 eng.set_targets([tgt])
                 eng.set_sources([src])
                 out.append(eng.correspond(pose[None]))
             assert np.array_equal(out[0][0], out[1][0]), f"case {case}: indices differ ({ns} x {nt})"
             assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32)), f"case {case}: distances differ"
             np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-11, atol=0)
+            assert np.array_equal(out[2][0], out[1][0]), f"case {case}: pruned-scan indices differ ({ns} x {nt})"
+            assert np.array_equal(out[2][1].view(np.uint32), out[1][1].view(np.uint32)), f"case {case}: pruned-scan distances differ"

@@ -20,6 +20,7 @@ MI355_ICP_SCAN_MODE=fused step 900 pytest_gpu_fused.txt python -m pytest tests -
 MI355_ICP_SCAN_MODE=xfilter step 900 pytest_gpu_xfilter.txt python -m pytest tests -m gpu -x -q
 MI355_ICP_SCAN_MODE=xbf16 step 900 pytest_gpu_xbf16.txt python -m pytest tests -m gpu -x -q
 MI355_ICP_SCAN_MODE=exact step 900 pytest_gpu_exact.txt python -m pytest tests -m gpu -x -q
+MI355_ICP_SCAN_MODE=pruned step 900 pytest_gpu_pruned.txt python -m pytest tests -m gpu -x -q
 step 300 smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
 step 400 bench.txt python bench.py --steps "${STEPS:-3}" --warmup 1
-tail -3 gpurun_out/pytest_gpu.txt; tail -2 gpurun_out/pytest_gpu_fused.txt; tail -2 gpurun_out/pytest_gpu_xfilter.txt; tail -2 gpurun_out/pytest_gpu_xbf16.txt; tail -2 gpurun_out/pytest_gpu_exact.txt; tail -2 gpurun_out/smoke.txt; tail -1 gpurun_out/bench.txt
+tail -3 gpurun_out/pytest_gpu.txt; tail -2 gpurun_out/pytest_gpu_fused.txt; tail -2 gpurun_out/pytest_gpu_xfilter.txt; tail -2 gpurun_out/pytest_gpu_xbf16.txt; tail -2 gpurun_out/pytest_gpu_exact.txt; tail -2 gpurun_out/pytest_gpu_pruned.txt; tail -2 gpurun_out/smoke.txt; tail -1 gpurun_out/bench.txt

@@ -26,7 +26,7 @@ for d in ("sq1", "sq2"):
             k = r["Kernel_Name"].split("(")[0][:60]
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
         for k, cs in acc.items():
-            if "scan" not in k: continue
+            if "scan" not in k and "pruned" not in k: continue
             print(d, k)
             for c, v in sorted(cs.items()):
                 print(f"   {c:28s} {v / n[(k, c)]:16.1f} per launch ({n[(k, c)]} launches)")
