@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--n-source", type=int, default=1 << 20, help="source points PER GPU")
     ap.add_argument("--n-target", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-iters", type=int, default=3)
+    ap.add_argument("--cpu-baseline-iters", type=int, default=20, help="ICP iterations of the CPU baseline sample (about 3 s on 16 threads)")
     ap.add_argument("--collective", choices=["native", "torch"], default="native",
                     help="N > 1: RCCL all-reduce issued inside the engine (native) or by torch.distributed")
     ap.add_argument("--force-dist", action="store_true", help="exercise the distributed code path even at N = 1")
