@@ -714,7 +714,8 @@ __global__ __launch_bounds__(kTile) void overflow_exact_kernel(
 // contract formula over ALL targets - from a fraction of the distance evaluations:
 //   * sources and targets both have a Morton-sorted copy (xtarget_kernels.hip) with a bounding sphere per 1024-point
 //     tile and per 64-point run; a workgroup takes 256 consecutive SORTED source points - a rigid pose keeps them
-//     spatially coherent - transforms them with the contract transform and bounds them by a sphere (cq, rq);
+//     spatially coherent - transforms them with the contract transform, cuts the run at its largest gap and bounds each
+//     of the two parts by a sphere (cq, rq);
 //   * every tile holds a point within (|cq - c| + rq + r) of every query: the smallest such bound picks the first tile,
 //     which is scanned exhaustively; afterwards each lane's best distance is exact and an upper bound of its minimum;
 //   * a tile (or 64-point run) whose nearest possible point is farther than a lane's best can hold neither its minimum
@@ -722,9 +723,7 @@ __global__ __launch_bounds__(kTile) void overflow_exact_kernel(
 //     through LDS with dk refreshed after every visit (the walk stops at the first tile out of reach), and each wave
 //     scans only the runs one of its lanes can still reach.
 // All bound arithmetic rounds towards "needed" (relative margins of 2^-18 against float32 errors of a few 2^-24; NaN and
-// overflow compare false = needed).  Known weakness: a workgroup whose run straddles a Morton jump has a huge sphere and
-// visits most tiles (58 of 4096 workgroups at 1M<->1M); the k-NN kernel's per-lane tile search avoids that but measured
-// slower here, where the seed tiles are poorer than a scene point's own tile.
+// overflow compare false = needed).
 // (v_sqrt_f32 directly: its 1 ulp is far inside the margins, and the correctly rounded sqrtf expands to fused
 // multiply-adds, which `make check-isa` bans from this file wholesale)
 __device__ __forceinline__ bool sphere_needed(float ox, float oy, float oz, float orad, float4 c, float dk) {
@@ -756,9 +755,9 @@ __global__ __launch_bounds__(kBlockThreads) void nn_pruned_kernel(
   __shared__ float4 lds_sphere[kTile / 64 + 1];  // ... the bounding spheres of its 16 runs and its own
   __shared__ unsigned long long cand[kMaxCand], sorted[kMaxCand];  // (lower-bound bits << 32 | tile)
   __shared__ uint32_t n_cand;
-  __shared__ uint32_t red_a[kBlockThreads / 64];
+  __shared__ uint32_t red_a[2 * (kBlockThreads / 64)];
   __shared__ float red[7][kBlockThreads / 64];
-  __shared__ unsigned long long first_key[kBlockThreads / 64];
+  __shared__ unsigned long long first_key[kBlockThreads / 64], seed_key[2][kBlockThreads / 64];
   const JobDesc& J = jobs[blockIdx.y];
   if (blockIdx.x * kBlockThreads >= J.src_n) return;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -810,80 +809,144 @@ __global__ __launch_bounds__(kBlockThreads) void nn_pruned_kernel(
     }
     __syncthreads();
   };
-  // dk: the largest best distance over the workgroup's lanes (best is never NaN nor negative: unsigned order of the
-  // bits is float order), wave-uniform DPP reductions + one LDS hop
-  auto block_dk = [&]() {
-    const uint32_t wk = ~wave_min_u32(~__float_as_uint(best));
-    if (lane == 0) red_a[wave] = wk;
-    __syncthreads();
-    uint32_t r = red_a[0];
-#pragma unroll
-    for (int w = 1; w < kBlockThreads / 64; ++w) r = red_a[w] > r ? red_a[w] : r;
-    __syncthreads();
-    return r;
-  };
-  // the workgroup's query sphere
-  float v[6] = {qx, qy, qz, -qx, -qy, -qz};
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v[k] = __builtin_fmaxf(v[k], __shfl_xor(v[k], off, 64));
-    if (lane == 0) red[k][wave] = v[k];
-  }
-  if (tid == 0) n_cand = 0;
+  // The run of 256 sorted points is cut in two at its largest gap between consecutive points: a Morton jump, if the run
+  // straddles one, is that gap, so each part stays spatially compact (one sphere over a run with a jump in it reaches
+  // every tile of the cloud: 58 of 4096 workgroups at 1M<->1M, and they set the kernel's duration).  Without a jump the
+  // cut is merely somewhere, and two smaller spheres bound better than one.
+  float* ex = reinterpret_cast<float*>(&lds[0][0]);  // the tile buffer is free until the first scan
+  ex[tid] = qx;
+  ex[kBlockThreads + tid] = qy;
+  ex[2 * kBlockThreads + tid] = qz;
   __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    v[k] = red[k][0];
-#pragma unroll
-    for (int w = 1; w < kBlockThreads / 64; ++w) v[k] = __builtin_fmaxf(v[k], red[k][w]);
-  }
-  const float cqx = 0.5f * v[0] - 0.5f * v[3], cqy = 0.5f * v[1] - 0.5f * v[4], cqz = 0.5f * v[2] - 0.5f * v[5];
-  float rq2 = dist2(qx, qy, qz, cqx, cqy, cqz);
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) rq2 = __builtin_fmaxf(rq2, __shfl_xor(rq2, off, 64));
-  if (lane == 0) red[6][wave] = rq2;
-  __syncthreads();
-  rq2 = red[6][0];
-#pragma unroll
-  for (int w = 1; w < kBlockThreads / 64; ++w) rq2 = __builtin_fmaxf(rq2, red[6][w]);
-  const float rq = __builtin_amdgcn_sqrtf(rq2) * 1.000003815f;
-  // first tile: the one whose farthest possible point is nearest (any tile would do for correctness)
-  unsigned long long fk = ~0ull;
-  for (uint32_t t = tid; t < n_tiles; t += kBlockThreads) {
-    const float4 c = ttable[tile_base + t];
-    const float u = __builtin_amdgcn_sqrtf(dist2(cqx, cqy, cqz, c.x, c.y, c.z)) + rq + __builtin_amdgcn_sqrtf(c.w);
-    const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(u)) << 32) | t;  // u >= 0 or NaN (sorts last)
-    fk = key < fk ? key : fk;
+  unsigned long long gk = 0ull;  // (gap bits << 32 | position), the largest wins; position 0 has no predecessor
+  if (tid > 0) {
+    const float g = dist2(qx, qy, qz, ex[tid - 1], ex[kBlockThreads + tid - 1], ex[2 * kBlockThreads + tid - 1]);
+    gk = (static_cast<unsigned long long>(g >= 0.0f ? __float_as_uint(g) : 0u) << 32) | tid;
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
-    const unsigned long long o = __shfl_xor(fk, off, 64);
-    fk = o < fk ? o : fk;
+    const unsigned long long o = __shfl_xor(gk, off, 64);
+    gk = o > gk ? o : gk;
   }
-  if (lane == 0) first_key[wave] = fk;
+  if (lane == 0) first_key[wave] = gk;
+  if (tid == 0) n_cand = 0;
   __syncthreads();
-  fk = first_key[0];
+  gk = first_key[0];
 #pragma unroll
-  for (int w = 1; w < kBlockThreads / 64; ++w) fk = first_key[w] < fk ? first_key[w] : fk;
-  const uint32_t first = static_cast<uint32_t>(fk);
-  scan_tile(first);
-  uint32_t dk_bits = block_dk();
-  // every other tile whose lower bound does not exceed dk, nearest first
+  for (int w = 1; w < kBlockThreads / 64; ++w) gk = first_key[w] > gk ? first_key[w] : gk;
+  const uint32_t cut = static_cast<uint32_t>(gk) ? static_cast<uint32_t>(gk) : kBlockThreads;  // no gap at all: one part
+  const int part = tid >= cut ? 1 : 0;
+  // bounding sphere of each part (centre of its box, largest distance of a member from it, rounded up)
+  float cq[2][3], rq[2];
+  bool has[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const bool in = part == g;
+    const float ninf = -__builtin_inff();
+    float v[6] = {in ? qx : ninf, in ? qy : ninf, in ? qz : ninf, in ? -qx : ninf, in ? -qy : ninf, in ? -qz : ninf};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v[k] = __builtin_fmaxf(v[k], __shfl_xor(v[k], off, 64));
+      if (lane == 0) red[k][wave] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      v[k] = red[k][0];
+#pragma unroll
+      for (int w = 1; w < kBlockThreads / 64; ++w) v[k] = __builtin_fmaxf(v[k], red[k][w]);
+    }
+    has[g] = v[0] > ninf;  // part 1 is empty when there is no cut (uniform)
+    cq[g][0] = has[g] ? 0.5f * v[0] - 0.5f * v[3] : 0.0f;
+    cq[g][1] = has[g] ? 0.5f * v[1] - 0.5f * v[4] : 0.0f;
+    cq[g][2] = has[g] ? 0.5f * v[2] - 0.5f * v[5] : 0.0f;
+    float r2 = in ? dist2(qx, qy, qz, cq[g][0], cq[g][1], cq[g][2]) : 0.0f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) r2 = __builtin_fmaxf(r2, __shfl_xor(r2, off, 64));
+    if (lane == 0) red[6][wave] = r2;
+    __syncthreads();
+    r2 = red[6][0];
+#pragma unroll
+    for (int w = 1; w < kBlockThreads / 64; ++w) r2 = __builtin_fmaxf(r2, red[6][w]);
+    rq[g] = __builtin_amdgcn_sqrtf(r2) * 1.000003815f;
+    __syncthreads();  // red[] is reused by the next part
+  }
+  // dk of each part: the largest best distance over its lanes (best is never NaN nor negative: unsigned order of the bits is
+  // float order)
+  uint32_t dk[2];
+  auto refresh_dk = [&]() {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const uint32_t mine = part == g ? __float_as_uint(best) : 0u;
+      const uint32_t wk = ~wave_min_u32(~mine);
+      if (lane == 0) red_a[g * (kBlockThreads / 64) + wave] = wk;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      uint32_t r = red_a[g * (kBlockThreads / 64)];
+#pragma unroll
+      for (int w = 1; w < kBlockThreads / 64; ++w) r = red_a[g * (kBlockThreads / 64) + w] > r ? red_a[g * (kBlockThreads / 64) + w] : r;
+      dk[g] = r;
+    }
+    __syncthreads();
+  };
+  // first tiles: per part, the tile whose farthest possible point is nearest (any tile would do for correctness)
+  unsigned long long fk[2] = {~0ull, ~0ull};
   for (uint32_t t = tid; t < n_tiles; t += kBlockThreads) {
-    if (t == first) continue;
-    const float lb = sphere_pair_lower_bound(cqx, cqy, cqz, rq, ttable[tile_base + t]);
-    const uint32_t lbb = lb >= 0.0f ? __float_as_uint(lb) : 0u;  // NaN: nothing known, treat as 0
-    if (lbb <= dk_bits) {
+    const float4 c = ttable[tile_base + t];
+    const float rt = __builtin_amdgcn_sqrtf(c.w);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float u = __builtin_amdgcn_sqrtf(dist2(cq[g][0], cq[g][1], cq[g][2], c.x, c.y, c.z)) + rq[g] + rt;
+      const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(u)) << 32) | t;  // u >= 0 or NaN (sorts last)
+      fk[g] = key < fk[g] ? key : fk[g];
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned long long o = __shfl_xor(fk[g], off, 64);
+      fk[g] = o < fk[g] ? o : fk[g];
+    }
+    if (lane == 0) seed_key[g][wave] = fk[g];
+  }
+  __syncthreads();
+  uint32_t first[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    unsigned long long k = seed_key[g][0];
+#pragma unroll
+    for (int w = 1; w < kBlockThreads / 64; ++w) k = seed_key[g][w] < k ? seed_key[g][w] : k;
+    first[g] = static_cast<uint32_t>(k);
+  }
+  if (!has[1]) first[1] = first[0];
+  scan_tile(first[0]);
+  if (first[1] != first[0]) scan_tile(first[1]);
+  refresh_dk();
+  // every other tile within reach of a part, nearest first
+  for (uint32_t t = tid; t < n_tiles; t += kBlockThreads) {
+    if (t == first[0] || t == first[1]) continue;
+    const float4 c = ttable[tile_base + t];
+    uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float lb = sphere_pair_lower_bound(cq[g][0], cq[g][1], cq[g][2], rq[g], c);
+      const uint32_t lbb = lb >= 0.0f ? __float_as_uint(lb) : 0u;  // NaN: nothing known, treat as 0
+      if (has[g] && lbb <= dk[g] && lbb < key) key = lbb;
+    }
+    if (key != 0xFFFFFFFFu) {
       const uint32_t slot = atomicAdd(&n_cand, 1u);
-      if (slot < kMaxCand) cand[slot] = (static_cast<unsigned long long>(lbb) << 32) | t;
+      if (slot < kMaxCand) cand[slot] = (static_cast<unsigned long long>(key) << 32) | t;
     }
   }
   __syncthreads();
   const uint32_t nc = n_cand;
   if (nc > kMaxCand) {  // more candidates than the list holds: visit every tile
     for (uint32_t t = 0; t < n_tiles; ++t)
-      if (t != first) scan_tile(t);
+      if (t != first[0] && t != first[1]) scan_tile(t);
   } else {
     for (uint32_t i = tid; i < nc; i += kBlockThreads) {  // rank sort (keys are distinct: the tile id is part of them)
       const unsigned long long key = cand[i];
@@ -894,9 +957,10 @@ __global__ __launch_bounds__(kBlockThreads) void nn_pruned_kernel(
     __syncthreads();
     for (uint32_t k = 0; k < nc; ++k) {
       const unsigned long long key = sorted[k];
-      if (static_cast<uint32_t>(key >> 32) > dk_bits) break;  // this tile and all later ones are out of reach (uniform)
+      const uint32_t reach = dk[0] > dk[1] ? dk[0] : dk[1];
+      if (static_cast<uint32_t>(key >> 32) > reach) break;  // this tile and all later ones are out of reach (uniform)
       scan_tile(static_cast<uint32_t>(key));
-      dk_bits = block_dk();
+      refresh_dk();
     }
   }
   if (pos < J.src_n) {
