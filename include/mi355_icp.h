@@ -75,6 +75,11 @@ typedef struct mi355_icp_params {
 } mi355_icp_params;
 
 #define MI355_ICP_FLAG_PROFILE 1  /* bracket every kernel launch with HIP events (see mi355_icp_get_profile) */
+#define MI355_ICP_FLAG_PRUNED_SCAN 2 /* answer the nearest-neighbour queries with the exact PRUNED scan instead of the
+                                        brute-force one: identical indices, distances and poses from a fraction of the
+                                        distance evaluations (Morton-sorted copies of both clouds, bounding spheres per
+                                        tile and run).  Off by default: the reference path this engine replaces is
+                                        specified - and benchmarked - as brute force.  Worth it from ~100k points. */
 
 /* Kernel timing collected when MI355_ICP_FLAG_PROFILE is set; cumulative since
  * the last mi355_icp_reset_profile(). */

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("MI355_ICP_LIB") or os.path.join(_HERE, "lib", "libmi3
 NSUMS = 17
 UNIQUE_ID_BYTES = 128
 FLAG_PROFILE = 1
+FLAG_PRUNED_SCAN = 2
 
 OK = 0
 ERR_INVALID_ARGUMENT = 1

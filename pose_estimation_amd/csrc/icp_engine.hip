@@ -181,6 +181,7 @@ struct mi355_icp_ctx {
   uint32_t target_blocks_mfma = 4096; // ... for the matrix-core filter: its workgroups span 512 points and publish two key
                                      // rows per split, so fewer, longer ones cost less key traffic (100k<->100k: resolve
                                      // 82 -> 35 us at equal scan time; profiles/r01o_target_blocks.txt)
+  bool call_pruned = false;          // this call asked for the pruned scan (MI355_ICP_FLAG_PRUNED_SCAN)
   int xbf16_shape = 0;               // 0: <4 sets, 256 threads> workgroups, 1: <2 sets, 512 threads> (MI355_ICP_XBF16_SHAPE)
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
 };
@@ -370,7 +371,7 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   // ... and the split-bf16 matrix-core form of it (xkind 3: one issue slot per pair, 2.3x the VALU filter end to end at
   // 100k<->100k, 1M<->1M and 64 x 50k<->50k: profiles/r01n_baseline_configs.jsonl) is the default wherever it applies
   plan.xkind = c->scan_fused < 0 ? 3 : (c->scan_fused >= 2 ? c->scan_fused - 2 : 0);
-  if (c->scan_fused == 6) {  // the optional pruned scan: no keys, no filters, no splits
+  if (c->scan_fused == 6 || c->call_pruned) {  // the optional pruned scan: no keys, no filters, no splits
     plan.pruned = true;
     plan.fused = plan.xfilter = false;
     plan.xkind = 0;
@@ -1073,6 +1074,7 @@ int mi355_icp_align(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const i
   if (params->max_iterations < 1) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align: max_iterations must be >= 1");
   HIP_TRY(c, hipSetDevice(c->device));
   Plan plan;
+  c->call_pruned = (params->flags & MI355_ICP_FLAG_PRUNED_SCAN) != 0;
   int st = make_plan(c, n_jobs, source_ids, target_ids, params->max_correspondence_distance, plan);
   if (st != MI355_ICP_OK) return st;
   if ((st = ensure_buffers(c, plan, static_cast<size_t>(n_jobs))) != MI355_ICP_OK) return st;
@@ -1129,6 +1131,7 @@ int mi355_icp_correspond(mi355_icp_ctx* c, int n_jobs, const int* source_ids, co
                          float max_correspondence_distance, int32_t* out_index, float* out_dist2, double* out_sums) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   c->err.clear();
+  c->call_pruned = false;
   if (n_jobs < 1 || !poses) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "correspond: bad arguments");
   HIP_TRY(c, hipSetDevice(c->device));
   Plan plan;
@@ -1169,6 +1172,7 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
   int st = check_reference_inputs(c, n_jobs, source_ids, target_ids);
   if (st != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+  c->call_pruned = (rp->flags & MI355_ICP_FLAG_PRUNED_SCAN) != 0;
   const bool profile = c->profile_always || (rp->flags & MI355_ICP_FLAG_PROFILE) != 0;
 
   struct JobState { double pose[16]; double residual = 0.0; int passes = 0; int status = MI355_ICP_OK; };
@@ -1284,6 +1288,7 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
                              uint8_t* out_selected, float* out_threshold, double* out_sums) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   c->err.clear();
+  c->call_pruned = false;
   if (!pose_start || !pose_cur || level < 0 || level > 23) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: bad arguments");
   HIP_TRY(c, hipSetDevice(c->device));
   int st = check_reference_inputs(c, 1, &source_id, &target_id);

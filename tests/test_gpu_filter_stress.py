@@ -68,3 +68,19 @@ def test_matrix_core_filter_equals_the_exact_scan_on_random_geometry():
             np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-11, atol=0)
             assert np.array_equal(out[2][0], out[1][0]), f"case {case}: pruned-scan indices differ ({ns} x {nt})"
             assert np.array_equal(out[2][1].view(np.uint32), out[1][1].view(np.uint32)), f"case {case}: pruned-scan distances differ"
+
+
+def test_pruned_scan_flag_gives_the_same_alignment(engine):
+    """MI355_ICP_FLAG_PRUNED_SCAN per call (no environment involved): point-to-point and reference mode."""
+    import pose_estimation_amd as pa
+    from pose_estimation_amd import _lib
+    src, tgt, gt = st.make_pair(st.synth_cloud_np, 30000, 50000)
+    tgt6 = st.synth_cloud_np(st.TARGET_SEED, 50000, normals=True)
+    engine.set_targets([tgt6])
+    engine.set_sources([src])
+    a = engine.align(np.eye(4)[None], pa.default_params(max_iterations=12))
+    b = engine.align(np.eye(4)[None], pa.default_params(max_iterations=12, flags=_lib.FLAG_PRUNED_SCAN))
+    assert np.array_equal(a.poses, b.poses) and np.array_equal(a.iterations, b.iterations)
+    ra = engine.align_reference(np.eye(4)[None], 60, 0.005, 2.5, 5)
+    rb = engine.align_reference(np.eye(4)[None], 60, 0.005, 2.5, 5, flags=_lib.FLAG_PRUNED_SCAN)
+    assert np.array_equal(ra.poses, rb.poses) and np.array_equal(ra.passes, rb.passes)
