@@ -221,6 +221,13 @@ class ICP {
     return 0;
   }
 
+  // Answer the nearest-neighbour queries with the exact pruned scan (MI355_ICP_FLAG_PRUNED_SCAN): same poses, less time
+  // from ~100k points.  Not upstream API; off by default (the replaced path is specified as brute force).
+  void setPrunedScan(bool on) {
+    params_.flags = on ? (params_.flags | MI355_ICP_FLAG_PRUNED_SCAN) : (params_.flags & ~MI355_ICP_FLAG_PRUNED_SCAN);
+    ref_params_.flags = on ? (ref_params_.flags | MI355_ICP_FLAG_PRUNED_SCAN) : (ref_params_.flags & ~MI355_ICP_FLAG_PRUNED_SCAN);
+  }
+
   Engine& engine() { return *engine_; }
   const mi355_icp_params& params() const { return params_; }
   const Engine::Result& last_result() const { return last_; }

@@ -113,7 +113,7 @@ class ICP:
 
     def __init__(self, iterations: int = 250, tolerence: float = 0.05, rejectionScale: float = 2.5,
                  numLevels: int = 6, sampleType: int = 0, numMaxCorr: int = 1, device_id: int = 0,
-                 engine: Optional[IcpEngine] = None, mode: str = "point_to_point"):
+                 engine: Optional[IcpEngine] = None, mode: str = "point_to_point", pruned_scan: bool = False):
         if mode not in ("point_to_point", "reference"):
             raise ValueError("mode must be 'point_to_point' or 'reference'")
         self.mode = mode
@@ -124,6 +124,10 @@ class ICP:
         self.sampleType = int(sampleType)
         self.numMaxCorr = int(numMaxCorr)
         self.params = params_from_reference(self.iterations, self.tolerence, self.rejectionScale, self.numLevels)
+        # not upstream API: answer the NN queries with the exact pruned scan (same poses; off by default, see the header)
+        self.pruned_scan = bool(pruned_scan)
+        if self.pruned_scan:
+            self.params.flags |= _lib.FLAG_PRUNED_SCAN
         self._engine = engine
         self._device_id = device_id
 
@@ -148,7 +152,8 @@ class ICP:
         init = np.stack([p.pose for p in plist])
         if self.mode == "reference":
             res = self.engine.align_reference(init, self.iterations, self.tolerence, self.rejectionScale, self.numLevels,
-                                              source_ids=[source_id] * len(plist), target_ids=[target_id] * len(plist))
+                                              source_ids=[source_id] * len(plist), target_ids=[target_id] * len(plist),
+                                              flags=_lib.FLAG_PRUNED_SCAN if self.pruned_scan else 0)
         else:
             res = self.engine.align(init, self.params, source_ids=[source_id] * len(plist),
                                     target_ids=[target_id] * len(plist))

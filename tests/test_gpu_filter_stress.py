@@ -84,3 +84,12 @@ def test_pruned_scan_flag_gives_the_same_alignment(engine):
     ra = engine.align_reference(np.eye(4)[None], 60, 0.005, 2.5, 5)
     rb = engine.align_reference(np.eye(4)[None], 60, 0.005, 2.5, 5, flags=_lib.FLAG_PRUNED_SCAN)
     assert np.array_equal(ra.poses, rb.poses) and np.array_equal(ra.passes, rb.passes)
+
+
+def test_icp_mirror_with_pruned_scan(engine):
+    import pose_estimation_amd as pa
+    src, tgt, gt = st.make_pair(st.synth_cloud_np, 20000, 30000)
+    poses_a, poses_b = [pa.Pose3D()], [pa.Pose3D()]
+    pa.ICP(40, 0.005, 2.5, 8, engine=engine).registerModelToScene(src, tgt, poses_a)
+    pa.ICP(40, 0.005, 2.5, 8, engine=engine, pruned_scan=True).registerModelToScene(src, tgt, poses_b)
+    assert np.array_equal(poses_a[0].pose, poses_b[0].pose) and poses_a[0].residual == poses_b[0].residual
