@@ -38,25 +38,26 @@ __device__ __forceinline__ uint32_t bf16_bits(float x) {
 __device__ __forceinline__ float bf16_value(uint32_t bits) { return __uint_as_float(bits << 16); }
 
 // ---- sphere bounds of the pruned scans (nn_pruned_kernel, knn_pruned_kernel) ----
-// Lower bound of the contract squared distance from the point o to any point of the sphere c = (centre, r^2), with every
+// Lower bound of the contract squared distance from any point of the sphere (o, orad) to any point of the sphere c =
+// (centre, r^2), with every
 // rounding pushed DOWN: relative margins of 2^-18 against float32 errors of a few 2^-24 (v_sqrt_f32 directly: its 1 ulp
 // is far inside the margins, and the correctly rounded sqrtf expands to fused multiply-adds, which `make check-isa` bans
 // from icp_kernels.hip).  0 when o may be inside the sphere; NaN when nothing can be said (overflow).
-__device__ __forceinline__ float sphere_lower_bound(float ox, float oy, float oz, float4 c) {
+__device__ __forceinline__ float sphere_lower_bound(float ox, float oy, float oz, float orad, float4 c) {
   const float dx = ox - c.x, dy = oy - c.y, dz = oz - c.z;
   float a = dx * dx;
   const float b = dy * dy, e = dz * dz;
   a = a + b;
   a = a + e;
-  const float D = __builtin_amdgcn_sqrtf(a) * 0.999996185f;                                  // (1 - 2^-18)
-  const float gap = D - __builtin_amdgcn_sqrtf(c.w) * 1.000003815f - 1.17549435e-38f;        // (1 + 2^-18), FLT_MIN
+  const float D = __builtin_amdgcn_sqrtf(a) * 0.999996185f;                                            // (1 - 2^-18)
+  const float gap = D - (orad + __builtin_amdgcn_sqrtf(c.w)) * 1.000003815f - 1.17549435e-38f;         // (1 + 2^-18), FLT_MIN
   float lb = gap * gap;
   lb = lb * 0.999996185f;
   return gap > 0.0f ? lb : (gap <= 0.0f ? 0.0f : gap);
 }
-// can the sphere hold a point at squared distance <= dk from o?  (NaN bounds answer yes)
-__device__ __forceinline__ bool sphere_reachable(float ox, float oy, float oz, float4 c, float dk) {
-  return !(sphere_lower_bound(ox, oy, oz, c) > dk);
+// can the sphere hold a point at squared distance <= dk from some point of the sphere (o, orad)?  (NaN bounds answer yes)
+__device__ __forceinline__ bool sphere_reachable(float ox, float oy, float oz, float orad, float4 c, float dk) {
+  return !(sphere_lower_bound(ox, oy, oz, orad, c) > dk);
 }
 constexpr int kSuperTiles = 16;          // tiles per super-tile sphere (the first level of the pruned scans' tile search)
 constexpr uint32_t kPrunedMaxTiles = 16384;  // bitmap of needed tiles held in LDS: 16M points per cloud
@@ -69,11 +70,11 @@ __device__ __forceinline__ void mark_reachable_tiles(float qx, float qy, float q
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t s0 = tile_base / kSuperTiles, s1 = (tile_base + n_tiles - 1) / kSuperTiles;
   for (uint32_t sidx = s0; sidx <= s1; ++sidx) {
-    if (__builtin_amdgcn_ballot_w64(sphere_reachable(qx, qy, qz, super_table[sidx], dk)) == 0) continue;
+    if (__builtin_amdgcn_ballot_w64(sphere_reachable(qx, qy, qz, 0.0f, super_table[sidx], dk)) == 0) continue;
     const uint32_t t0 = sidx * kSuperTiles > tile_base ? sidx * kSuperTiles : tile_base;
     const uint32_t t1 = (sidx + 1) * kSuperTiles < tile_base + n_tiles ? (sidx + 1) * kSuperTiles : tile_base + n_tiles;
     for (uint32_t t = t0; t < t1; ++t)
-      if (__builtin_amdgcn_ballot_w64(sphere_reachable(qx, qy, qz, tile_table[t], dk)) != 0 && lane == 0)
+      if (__builtin_amdgcn_ballot_w64(sphere_reachable(qx, qy, qz, 0.0f, tile_table[t], dk)) != 0 && lane == 0)
         atomicOr(&need[(t - tile_base) >> 5], 1u << ((t - tile_base) & 31u));
   }
 }

@@ -722,28 +722,7 @@ __global__ __launch_bounds__(kTile) void overflow_exact_kernel(
 //     nor a tie with it, so: tiles are listed once against the workgroup's largest best (dk), visited nearest first
 //     through LDS with dk refreshed after every visit (the walk stops at the first tile out of reach), and each wave
 //     scans only the runs one of its lanes can still reach.
-// All bound arithmetic rounds towards "needed" (relative margins of 2^-18 against float32 errors of a few 2^-24; NaN and
-// overflow compare false = needed).
-// (v_sqrt_f32 directly: its 1 ulp is far inside the margins, and the correctly rounded sqrtf expands to fused
-// multiply-adds, which `make check-isa` bans from this file wholesale)
-__device__ __forceinline__ bool sphere_needed(float ox, float oy, float oz, float orad, float4 c, float dk) {
-  const float D = __builtin_amdgcn_sqrtf(dist2(ox, oy, oz, c.x, c.y, c.z)) * 0.999996185f;                  // (1 - 2^-18)
-  const float gap = D - (orad + __builtin_amdgcn_sqrtf(c.w)) * 1.000003815f - 1.17549435e-38f;             // (1 + 2^-18), FLT_MIN
-  float lb = gap * gap;
-  lb = lb * 0.999996185f;
-  return !(gap > 0.0f && lb > dk);
-}
-
-// lower bound (rounded down, see above) of the squared distance from any point of the sphere (o, orad) to any point of the
-// sphere c = (centre, r^2); 0 when the spheres may touch; NaN when nothing can be said (overflow) - callers treat NaN as 0
-__device__ __forceinline__ float sphere_pair_lower_bound(float ox, float oy, float oz, float orad, float4 c) {
-  const float D = __builtin_amdgcn_sqrtf(dist2(ox, oy, oz, c.x, c.y, c.z)) * 0.999996185f;
-  const float gap = D - (orad + __builtin_amdgcn_sqrtf(c.w)) * 1.000003815f - 1.17549435e-38f;
-  float lb = gap * gap;
-  lb = lb * 0.999996185f;
-  return gap > 0.0f ? lb : (gap <= 0.0f ? 0.0f : gap);  // gap NaN -> NaN
-}
-
+// All bound arithmetic rounds towards "reachable" (sphere_lower_bound, icp_internal.h).
 __global__ __launch_bounds__(kBlockThreads) void nn_pruned_kernel(
     const JobDesc* __restrict__ jobs, const float* __restrict__ ssx, const float* __restrict__ ssy,
     const float* __restrict__ ssz, const uint32_t* __restrict__ sperm, const float* __restrict__ tsx,
@@ -787,9 +766,9 @@ __global__ __launch_bounds__(kBlockThreads) void nn_pruned_kernel(
     if (tid < kTile / 64) lds_sphere[tid] = tsub[(tile_base + tile) * (kTile / 64) + tid];
     if (tid == kTile / 64) lds_sphere[tid] = ttable[tile_base + tile];
     __syncthreads();
-    if (__builtin_amdgcn_ballot_w64(sphere_needed(qx, qy, qz, 0.0f, lds_sphere[kTile / 64], best)) != 0) {
+    if (__builtin_amdgcn_ballot_w64(sphere_reachable(qx, qy, qz, 0.0f, lds_sphere[kTile / 64], best)) != 0) {
       for (uint32_t sub = 0; sub < kTile / 64; ++sub) {
-        const bool reach = sphere_needed(qx, qy, qz, 0.0f, lds_sphere[sub], best);
+        const bool reach = sphere_reachable(qx, qy, qz, 0.0f, lds_sphere[sub], best);
         if (__builtin_amdgcn_ballot_w64(reach) == 0) continue;
 #pragma unroll 4
         for (uint32_t g = sub * 16; g < sub * 16 + 16; ++g) {
@@ -933,7 +912,7 @@ __global__ __launch_bounds__(kBlockThreads) void nn_pruned_kernel(
     uint32_t key = 0xFFFFFFFFu;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      const float lb = sphere_pair_lower_bound(cq[g][0], cq[g][1], cq[g][2], rq[g], c);
+      const float lb = sphere_lower_bound(cq[g][0], cq[g][1], cq[g][2], rq[g], c);
       const uint32_t lbb = lb >= 0.0f ? __float_as_uint(lb) : 0u;  // NaN: nothing known, treat as 0
       if (has[g] && lbb <= dk[g] && lbb < key) key = lbb;
     }

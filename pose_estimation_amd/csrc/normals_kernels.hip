@@ -201,9 +201,9 @@ __global__ __launch_bounds__(kBlockThreads) void knn_pruned_kernel(const float* 
     if (tid < kTile / 64) lds_sphere[tid] = sub_table[tile * (kTile / 64) + tid];
     if (tid == kTile / 64) lds_sphere[tid] = table[tile];
     __syncthreads();
-    if (__builtin_amdgcn_ballot_w64(sphere_reachable(qx, qy, qz, lds_sphere[kTile / 64], d[K - 1])) != 0) {
+    if (__builtin_amdgcn_ballot_w64(sphere_reachable(qx, qy, qz, 0.0f, lds_sphere[kTile / 64], d[K - 1])) != 0) {
       for (uint32_t sub = 0; sub < kTile / 64; ++sub) {
-        if (__builtin_amdgcn_ballot_w64(sphere_reachable(qx, qy, qz, lds_sphere[sub], d[K - 1])) == 0) continue;
+        if (__builtin_amdgcn_ballot_w64(sphere_reachable(qx, qy, qz, 0.0f, lds_sphere[sub], d[K - 1])) == 0) continue;
 #pragma unroll 2
         for (uint32_t g = sub * 16; g < sub * 16 + 16; ++g) {
           const float4 X = lds[0][g], Y = lds[1][g], Z = lds[2][g], P = lds[3][g];
