@@ -4,12 +4,13 @@
 // driving the refine half through the C++ mirror.  PPF matching is not part of this path, so candidate
 // poses are synthesised around the known alignment the way PPF votes would deliver them.
 //
-//   estimate_pose_harness <n_model> <n_scene> [n_candidates] [reference|pipeline]
+//   estimate_pose_harness <n_model> <n_scene> [n_candidates] [reference|pipeline] [pruned]
 //     prints the 7-float pose and per-candidate results; "reference" selects Mode::Reference (scene with normals);
 //     "pipeline" starts from a raw camera-like frame (NaN dropouts + a table plane) and runs the whole
 //     create_surface_match_pc -> computeNormalsPC3d -> ICP chain on the device: NaN removal, plane band, k = 20
 //     normals, commit, reference-mode refine (pose_estimation.cpp:211-279, opencv_surface_match.cpp:57-94)
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -48,6 +49,7 @@ int main(int argc, char** argv) {
   const int n_cand = argc > 3 ? std::atoi(argv[3]) : 7;
   const bool pipeline = argc > 4 && std::string(argv[4]) == "pipeline";
   const bool reference_mode = pipeline || (argc > 4 && std::string(argv[4]) == "reference");
+  const bool pruned = argc > 5 && std::string(argv[5]) == "pruned";  // MI355_ICP_FLAG_PRUNED_SCAN for the ICP
   EstimatePoseRequest req;
   req.object = "bumpy_sphere";
   EstimatePoseResponse resp;
@@ -62,6 +64,7 @@ int main(int argc, char** argv) {
 
     using mi355::ppf_match_3d::ICP;
     ICP icp(250, 0.005f, 2.5f, 8, 0, reference_mode ? ICP::Mode::Reference : ICP::Mode::PointToPoint);  // the reference's arguments
+    icp.setPrunedScan(pruned);
     std::vector<mi355::ppf_match_3d::Pose3DPtr> results;
     const size_t votes[] = {300, 900, 500, 450, 100, 420, 50, 10};
     for (int k = 0; k < n_cand; ++k) {
@@ -86,6 +89,10 @@ int main(int argc, char** argv) {
         }
       }
       mi355::Engine& eng = icp.engine();
+      // the request is run twice: the second pass shows the steady state of a service (buffers sized, code loaded)
+      for (int rep = 0; rep < 2; ++rep) {
+      for (int k = 0; k < n_cand; ++k) results[k]->updatePose(rotation_about(0.2, 1, -0.4, 1.0 + k, 0.01, -0.02, 0.015));
+      const auto t0 = std::chrono::steady_clock::now();
       eng.scene_load(mi355::CloudView{raw.data(), raw.size() / 3, 12});
       mi355_scene_filter fin{};
       fin.kind = MI355_SCENE_FILTER_FINITE;
@@ -93,13 +100,23 @@ int main(int argc, char** argv) {
       band.kind = MI355_SCENE_FILTER_PLANE_BAND_REMOVE;  // plane 0x + 0y + 1z + 1.3 = 0, band 0.005 (pose_estimation.cpp:320)
       band.p[0] = 0.f; band.p[1] = 0.f; band.p[2] = 1.f; band.p[3] = 1.3f; band.p[4] = 0.005f;
       const size_t kept = eng.scene_filter({fin, band});
-      std::printf("pipeline: %zu raw points -> %zu kept\n", raw.size() / 3, kept);
+      const auto t1 = std::chrono::steady_clock::now();
       eng.scene_normals(20, true, {0.f, 0.f, 0.f});  // computeNormalsPC3d(scene, out, 20, true, viewpoint 0)
+      const auto t2 = std::chrono::steady_clock::now();
       eng.scene_commit_target();
       eng.set_sources({mi355::CloudView{model.data(), n_model, 12}});
+      const auto t3 = std::chrono::steady_clock::now();
       std::vector<mi355::ppf_match_3d::Pose3DPtr> subset(results.begin(), results.begin() + static_cast<std::ptrdiff_t>(results.size() > 6 ? 6 : results.size()));
       icp.registerUploaded(subset, 0, 0);
+      const auto t4 = std::chrono::steady_clock::now();
       best = mi355::ppf_match_3d::select_best_pose(subset, results.size());
+      const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+      };
+      std::printf("pipeline pass %d: %zu raw points -> %zu kept | upload+filters %.3f ms, normals %.3f ms, commit+model upload %.3f ms, "
+                  "ICP of %zu candidates %.3f ms, total %.3f ms\n",
+                  rep, raw.size() / 3, kept, ms(t0, t1), ms(t1, t2), ms(t2, t3), subset.size(), ms(t3, t4), ms(t0, t4));
+      }
       pose.assign(7, 0.f);
       mi355_icp_pose_to_pose7(results[best]->pose.data(), pose.data(), 1);
     } else {
