@@ -83,8 +83,8 @@ def test_cpp_harness_full_pipeline_on_device(engine):
     out = subprocess.run([exe, "4000", "6000", "3", "pipeline"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.splitlines()
-    kept = [l for l in lines if l.startswith("pipeline:")][0].split()
-    assert int(kept[1]) == 9000 and int(kept[5]) == 6000 - 300       # 3000 plane points and 300 NaN pixels removed
+    kept = [l for l in lines if l.startswith("pipeline pass 1:")][0].split()   # "pipeline pass 1: 9000 raw points -> 5700 kept | ..."
+    assert int(kept[3]) == 9000 and int(kept[7]) == 6000 - 300       # 3000 plane points and 300 NaN pixels removed
     poses = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]).reshape(4, 4) for l in lines if l.startswith("pose ")}
     gt = np.linalg.inv(st.perturbation(-1))
     for k in range(3):
