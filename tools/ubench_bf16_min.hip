@@ -29,7 +29,19 @@ __device__ __forceinline__ uint32_t min16(const f32x16& acc, uint32_t seed) {
   return b[0] < seed ? b[0] : seed;
 }
 
-template <int MODE>  // 0 M, 1 V2, 2 V3, 3 B2, 4 B3
+// 14 registers + seed through 7 v_min3_u32; the other two go to a per-lane LDS slot with ds_min_u32 (LDS pipe, no VALU slot)
+__device__ __forceinline__ uint32_t min14_lds2(const f32x16& acc, uint32_t seed, uint32_t* slot) {
+  uint32_t b[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) b[k] = __float_as_uint(acc[k]);
+  __hip_atomic_fetch_min(slot, b[14], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_min(slot, b[15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const uint32_t t0 = m3(b[0], b[1], b[2]), t1 = m3(b[3], b[4], b[5]), t2 = m3(b[6], b[7], b[8]), t3 = m3(b[9], b[10], b[11]);
+  const uint32_t t4 = m3(b[12], b[13], seed), t5 = m3(t0, t1, t2);
+  return m3(t3, t4, t5);
+}
+
+template <int MODE>  // 0 M, 1 V2, 2 V3, 3 B2, 4 B3, 5 B3 with two values per MFMA through ds_min_u32
 __global__ __launch_bounds__(256, 2) void k(float* out, int iters, const u32x4* in) {
   f32x16 acc[4];
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -39,21 +51,24 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters, const u32x4* 
     for (int i = 0; i < 16; ++i) acc[m][i] = threadIdx.x + i + m;
   u32x4 fa = in[threadIdx.x], fb = in[threadIdx.x + 256];
   uint32_t cm[4] = {0x7F800000u, 0x7F800000u, 0x7F800000u, 0x7F800000u};
+  __shared__ uint32_t slots[4][256];
+  for (int m = 0; m < 4; ++m) slots[m][threadIdx.x] = 0x7F800000u;
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      if (MODE == 3 || MODE == 4) asm volatile("" : "+v"(fa), "+v"(acc[(m + 2) & 3]), "+v"(cm[(m + 3) & 3]));
-      if (MODE == 0 || MODE == 3 || MODE == 4)
+      if (MODE == 3 || MODE == 4 || MODE == 5) asm volatile("" : "+v"(fa), "+v"(acc[(m + 2) & 3]), "+v"(cm[(m + 3) & 3]));
+      if (MODE == 0 || MODE == 3 || MODE == 4 || MODE == 5)
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), zero, 0, 0, 0);
       if (MODE == 1 || MODE == 3) cm[m] = min16<true>(acc[(m + 2) & 3], cm[m]);
       if (MODE == 2 || MODE == 4) cm[m] = min16<false>(acc[(m + 2) & 3], cm[m]);
+      if (MODE == 5) cm[m] = min14_lds2(acc[(m + 2) & 3], cm[m], &slots[m][threadIdx.x]);
       if (MODE == 1 || MODE == 2) asm volatile("" : "+v"(acc[(m + 2) & 3]));  // keep the minima in the loop
     }
   }
   float s = 0;
 #pragma unroll
-  for (int m = 0; m < 4; ++m) s += acc[m][0] + acc[m][7] + __uint_as_float(cm[m]);
+  for (int m = 0; m < 4; ++m) s += acc[m][0] + acc[m][7] + __uint_as_float(cm[m]) + (MODE == 5 ? __uint_as_float(slots[m][threadIdx.x]) : 0.f);
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -80,11 +95,12 @@ int main() {
   for (int wps : {1, 2, 3}) {
     const int grid = 256 * wps;
     const float m = run<0>(out, in, grid, iters), v2 = run<1>(out, in, grid, iters), v3 = run<2>(out, in, grid, iters);
-    const float b2 = run<3>(out, in, grid, iters), b3 = run<4>(out, in, grid, iters);
+    const float b2 = run<3>(out, in, grid, iters), b3 = run<4>(out, in, grid, iters), b5 = run<5>(out, in, grid, iters);
     const double steps = 4.0 * iters * wps;  // steps per SIMD
     auto cyc = [&](float ms) { return ms * 1e-3 * 2.4e9 / steps; };
     printf("waves/SIMD=%d  cycles per step per SIMD at 2.4 GHz:  (MFMA only %.1f) | pairwise tree (hipcc: min/min3 mix) %.1f | 8 v_min3_u32 %.1f | MFMA + mix %.1f | MFMA + 8 v_min3_u32 %.1f\n",
            wps, cyc(m), cyc(v2), cyc(v3), cyc(b2), cyc(b3));
+    printf("              MFMA + 7 v_min3_u32 + 2 ds_min_u32 (two of the 16 results through the LDS pipe): %.1f\n", cyc(b5));
   }
   return 0;
 }
