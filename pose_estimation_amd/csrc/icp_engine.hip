@@ -128,6 +128,7 @@ struct mi355_icp_ctx {
   double* ref_partials = nullptr;      size_t ref_partials_cap = 0;
   double* ref_sums_dev = nullptr;      size_t ref_jobs_cap = 0;
   float* thr_dev = nullptr;
+  uint32_t* select_work = nullptr;  // per job: 2048-bin histogram + selection state of the multi-workgroup rank select
   RefJobDesc* rjobs_dev = nullptr;
   RefJobDesc* rjobs_host = nullptr;    // pinned
   double* ref_sums_host = nullptr;     // pinned
@@ -818,6 +819,9 @@ int ensure_ref_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs, size_t
     const size_t want = std::max<size_t>(n_jobs, 8) * 2;
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->ref_sums_dev), want * kRefSums * sizeof(double)));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->thr_dev), want * sizeof(float)));
+    if (c->select_work) { HIP_TRY(c, hipFree(c->select_work)); c->select_work = nullptr; }
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->select_work), want * (2048 + 4) * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->select_work, 0, want * (2048 + 4) * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->rjobs_dev), want * sizeof(RefJobDesc)));
     HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->rjobs_host), want * sizeof(RefJobDesc), hipHostMallocDefault));
     HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->ref_sums_host), want * kRefSums * sizeof(double), hipHostMallocDefault));
@@ -874,7 +878,9 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
     if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
   }
   if (rejection_scale > 0.0f) {
-    launch_rejection_select(c->stream, c->jobs_dev, n_active, c->out_dist2, rejection_scale, c->thr_dev);
+    uint32_t max_n = 0;
+    for (int k = 0; k < n_active; ++k) max_n = std::max(max_n, c->jobs_host[k].src_n);
+    launch_rejection_select(c->stream, c->jobs_dev, n_active, max_n, c->out_dist2, rejection_scale, c->thr_dev, c->select_work);
   } else {
     for (int k = 0; k < n_active; ++k) c->thr_host[k] = std::numeric_limits<float>::infinity();
     HIP_TRY(c, hipMemcpyAsync(c->thr_dev, c->thr_host, static_cast<size_t>(n_active) * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -1035,6 +1041,7 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   (void)hipFree(c->ref_partials);
   (void)hipFree(c->ref_sums_dev);
   (void)hipFree(c->thr_dev);
+  (void)hipFree(c->select_work);
   (void)hipFree(c->rjobs_dev);
   if (c->rjobs_host) (void)hipHostFree(c->rjobs_host);
   if (c->ref_sums_host) (void)hipHostFree(c->ref_sums_host);

@@ -187,8 +187,8 @@ void launch_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, cons
 
 void launch_subsample(void* stream, const float* in, size_t in_stride, uint32_t in_off, float* out, size_t out_stride,
                       uint32_t out_off, uint32_t n_level, uint32_t n_padded, uint32_t step, float pad);
-void launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, const float* dist2, float scale,
-                             float* thr);
+void launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_n, const float* dist2, float scale,
+                             float* thr, uint32_t* work);
 void launch_picky_scatter(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
                           uint32_t max_src_blocks, const int32_t* index, const float* dist2, const float* thr,
                           unsigned long long* owner);

@@ -9,11 +9,13 @@
 //   subsample_kernel          level planes:  out[i] = in[i * step], padded
 //   rejection_select_kernel   per job, ONE workgroup: exact rank select (3-pass 11/11/10-bit radix on the
 //                             float bits, LDS histograms) of d2, then of |d2 - med|  ->  threshold
+//   select_hist/pick_kernel   the same selection across many workgroups, for jobs of >= 64k points
 //   picky_scatter_kernel      accepted pairs: atomicMin(owner[target], d2 bits << 32 | source index)
 //   ref_accumulate_kernel     winners: 21 + 6 normal-equation sums, sum |p-q|^2, count (29 doubles)
 //   ref_final_reduce_kernel   fixed-order reduction of the per-workgroup partials
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 
 #include "icp_internal.h"
@@ -151,6 +153,107 @@ __global__ __launch_bounds__(kSelThreads) void rejection_select_kernel(const Job
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same selection across MANY workgroups, for large jobs (one workgroup walks a million values six times in 1.4 ms).
+// Per radix pass two launches: select_hist_kernel - every workgroup histograms a strided share of the job's values that
+// still match the chosen prefix into LDS and adds it to the job's global histogram - and select_pick_kernel - one
+// workgroup per job finds the digit that holds rank k, extends the prefix, clears the histogram; after pass 3 it has
+// the median (stage 0) and the following three passes select the median of |d2 - med| (stage 1), after which it writes
+// the threshold.  Counts are integers: the selected element, hence the threshold, is the one-workgroup kernel's bit for bit.
+struct SelectState {
+  uint32_t prefix, mask, k;
+  float med;
+};
+constexpr uint32_t kSelectWork = 2048u + 4u;  // uint32 of scratch per job: its histogram, then its SelectState
+__device__ __forceinline__ uint32_t* select_hist_of(uint32_t* work, uint32_t job) { return work + static_cast<size_t>(job) * kSelectWork; }
+__device__ __forceinline__ SelectState* select_state_of(uint32_t* work, uint32_t job) {
+  return reinterpret_cast<SelectState*>(work + static_cast<size_t>(job) * kSelectWork + 2048u);
+}
+
+__device__ __forceinline__ float select_value(const float* __restrict__ d, uint32_t i, int stage, float med) {
+  const float v = d[i];
+  return stage == 0 ? v : static_cast<float>(__builtin_fabs(static_cast<double>(v) - static_cast<double>(med)));
+}
+
+// grid = (chunks, n_jobs), block = kSelThreads.  pass = 0..5 (3 per stage)
+__global__ __launch_bounds__(kSelThreads) void select_hist_kernel(const JobDesc* __restrict__ jobs, const float* __restrict__ dist2,
+                                                                   uint32_t* __restrict__ work, int pass) {
+  __shared__ uint32_t hist[2048];
+  const JobDesc& J = jobs[blockIdx.y];
+  const uint32_t n = J.src_n;
+  if (blockIdx.x * kSelThreads >= n) return;
+  const int stage = pass / 3, sub = pass % 3;
+  const int shift = sub == 0 ? 21 : (sub == 1 ? 10 : 0);
+  const uint32_t nb = sub == 2 ? 1024u : 2048u;
+  const SelectState st = *select_state_of(work, blockIdx.y);
+  uint32_t* ghist = select_hist_of(work, blockIdx.y);
+  const uint32_t prefix = sub == 0 ? 0u : st.prefix, mask = sub == 0 ? 0u : st.mask;
+  for (uint32_t b = threadIdx.x; b < 2048; b += kSelThreads) hist[b] = 0;
+  __syncthreads();
+  const float* __restrict__ d = dist2 + J.out_off;
+  for (uint32_t i = blockIdx.x * kSelThreads + threadIdx.x; i < n; i += gridDim.x * kSelThreads) {
+    const uint32_t bits = __float_as_uint(select_value(d, i, stage, st.med));
+    if ((bits & mask) == prefix) atomicAdd(&hist[(bits >> shift) & (nb - 1)], 1u);
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nb; b += kSelThreads)
+    if (hist[b]) atomicAdd(&ghist[b], hist[b]);
+}
+
+// grid = n_jobs, block = kSelThreads
+__global__ __launch_bounds__(kSelThreads) void select_pick_kernel(const JobDesc* __restrict__ jobs, uint32_t* __restrict__ work,
+                                                                   int pass, float scale, float* __restrict__ thr_out) {
+  __shared__ uint32_t bcast[2];
+  __shared__ uint32_t wave_tot[kSelThreads / 64];
+  const JobDesc& J = jobs[blockIdx.x];
+  const uint32_t n = J.src_n;
+  if (n == 0) {
+    if (threadIdx.x == 0 && pass == 5) thr_out[blockIdx.x] = __builtin_inff();
+    return;
+  }
+  const int sub = pass % 3;
+  const int shift = sub == 0 ? 21 : (sub == 1 ? 10 : 0);
+  const uint32_t nb = sub == 2 ? 1024u : 2048u;
+  SelectState st = *select_state_of(work, blockIdx.x);
+  const uint32_t k = sub == 0 ? (n - 1) / 2 : st.k;
+  uint32_t* h = select_hist_of(work, blockIdx.x);
+  const uint32_t c0 = h[2 * threadIdx.x], c1 = h[2 * threadIdx.x + 1];
+  const uint32_t mine = c0 + c1;
+  uint32_t incl = mine;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off, 64);
+    if (lane >= static_cast<uint32_t>(off)) incl += up;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t w = 0; w < wave; ++w) base += wave_tot[w];
+  const uint32_t excl = base + incl - mine;
+  if (mine && k >= excl && k < excl + mine) {  // exactly one thread
+    const bool second = k >= excl + c0;
+    bcast[0] = 2 * threadIdx.x + (second ? 1u : 0u);
+    bcast[1] = k - excl - (second ? c0 : 0u);
+  }
+  h[2 * threadIdx.x] = 0;  // ready for the next pass
+  h[2 * threadIdx.x + 1] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st.prefix = (sub == 0 ? 0u : st.prefix) | (bcast[0] << shift);
+    st.mask = (sub == 0 ? 0u : st.mask) | ((nb - 1) << shift);
+    st.k = bcast[1];
+    if (pass == 2) st.med = __uint_as_float(st.prefix);
+    if (pass == 5) {
+      const float mad = __uint_as_float(st.prefix);
+      const float s = 1.48257968f * mad;
+      const float t = scale * s;
+      thr_out[blockIdx.x] = t + st.med;
+    }
+    *select_state_of(work, blockIdx.x) = st;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // grid = (max src_blocks, n_jobs).  owner[] was set to ~0 before the launch.
 __global__ __launch_bounds__(kBlockThreads) void picky_scatter_kernel(const JobDesc* __restrict__ jobs,
                                                                        const RefJobDesc* __restrict__ rjobs,
@@ -258,10 +361,23 @@ void launch_subsample(void* stream, const float* in, size_t in_stride, uint32_t 
                      step, pad);
 }
 
-void launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, const float* dist2, float scale,
-                             float* thr) {
-  hipLaunchKernelGGL(rejection_select_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kSelThreads), 0,
-                     static_cast<hipStream_t>(stream), jobs_dev, dist2, scale, thr);
+// max_n: largest job of the launch.  work: n_jobs * (2048 + 4) uint32 of scratch, zeroed once at allocation (the pick
+// kernel leaves the histograms clear); small launches keep the one-workgroup kernel (a dozen launches cost more).
+void launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_n, const float* dist2, float scale,
+                             float* thr, uint32_t* work) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (max_n < 65536u || !work) {
+    hipLaunchKernelGGL(rejection_select_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kSelThreads), 0, st, jobs_dev, dist2, scale,
+                       thr);
+    return;
+  }
+  const uint32_t chunks = std::min<uint32_t>(256u, (max_n + 8u * kSelThreads - 1) / (8u * kSelThreads));  // >= 8 values per thread
+  for (int pass = 0; pass < 6; ++pass) {
+    hipLaunchKernelGGL(select_hist_kernel, dim3(chunks, static_cast<uint32_t>(n_jobs)), dim3(kSelThreads), 0, st, jobs_dev, dist2, work,
+                       pass);
+    hipLaunchKernelGGL(select_pick_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kSelThreads), 0, st, jobs_dev, work, pass, scale,
+                       thr);
+  }
 }
 
 void launch_picky_scatter(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
