@@ -1,0 +1,82 @@
+"""N > 1 on the GPU box with the single GPU it has: two processes share the device, each owns a contiguous source slab
+(mi355_icp_slab_range), every iteration's 17 sums per job come from the HIP engine (mi355_icp_correspond through
+pose_estimation_amd.distributed.engine_pass) and are all-reduced over gloo; every rank runs the product's host controller
+on the reduced sums.  The RCCL flavour of the same loop (mi355_icp_comm_attach) needs one GPU per rank and is exercised
+by bench.py --gpus N; here the point is that the slab-sharded HIP path lands on the single-process answer."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIZES = ((30001, 25000), (17777, 21000))   # two jobs of different clouds; sizes that do not divide evenly
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import pose_estimation_amd as pa
+    from pose_estimation_amd import distributed as pd
+    import synth_twin as st
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        targets, slabs = [], []
+        for k, (ns, nt) in enumerate(SIZES):
+            targets.append(pa.synth_cloud(st.TARGET_SEED + 16 * k, nt))
+            b, c = pa.slab_range(ns, rank, world)
+            slabs.append(pa.synth_cloud(st.SOURCE_SEED + 16 * k, c, first_index=b, noise_seed=st.NOISE_SEED + 16 * k,
+                                        sigma=st.SIGMA, transform=st.perturbation(k)))
+        with pa.IcpEngine(0) as eng:
+            eng.set_targets(targets)
+            eng.set_sources(slabs)
+            params = pa.default_params(max_iterations=12, relative_mse_epsilon=2e-3)
+            res = pd.align_external_collective(pd.engine_pass(eng, [0, 1], [0, 1]), pd.torch_allreduce(),
+                                               np.stack([np.eye(4), np.eye(4)]), params)
+        q.put((rank, res.poses, res.residual, res.iterations, res.status, res.converged))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_slab_sharded_hip_passes_match_the_single_process_engine(engine):
+    import torch.multiprocessing as mp
+    import pose_estimation_amd as pa
+    import synth_twin as st
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, poses0, res0, it0, st0, cv0), (r1, poses1, res1, it1, st1, cv1) = got
+    assert np.array_equal(poses0, poses1) and np.array_equal(it0, it1) and np.array_equal(cv0, cv1)  # same reduced bits
+    params = pa.default_params(max_iterations=12, relative_mse_epsilon=2e-3)
+    tgts = [pa.synth_cloud(st.TARGET_SEED + 16 * k, nt) for k, (ns, nt) in enumerate(SIZES)]
+    srcs = [pa.synth_cloud(st.SOURCE_SEED + 16 * k, ns, noise_seed=st.NOISE_SEED + 16 * k, sigma=st.SIGMA, transform=st.perturbation(k))
+            for k, (ns, nt) in enumerate(SIZES)]
+    engine.set_targets(tgts)
+    engine.set_sources(srcs)
+    one = engine.align(np.stack([np.eye(4), np.eye(4)]), params, source_ids=[0, 1], target_ids=[0, 1])
+    for k in range(2):
+        assert st0[k] == 0 and it0[k] == one.iterations[k] and cv0[k] == one.converged[k]
+        assert np.linalg.norm(poses0[k] - one.poses[k]) <= 1e-9   # only the summation order (two slabs) differs
+        assert abs(res0[k] - one.residual[k]) <= 1e-12
