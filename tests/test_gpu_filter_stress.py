@@ -93,3 +93,25 @@ def test_icp_mirror_with_pruned_scan(engine):
     pa.ICP(40, 0.005, 2.5, 8, engine=engine).registerModelToScene(src, tgt, poses_a)
     pa.ICP(40, 0.005, 2.5, 8, engine=engine, pruned_scan=True).registerModelToScene(src, tgt, poses_b)
     assert np.array_equal(poses_a[0].pose, poses_b[0].pose) and poses_a[0].residual == poses_b[0].residual
+
+
+def test_reference_mode_is_the_same_through_every_scan_path():
+    """align_reference (pyramid, rejection, picky, point-to-plane) on random surfaces under random initial poses: passes,
+    residuals and poses identical whichever scan answers the nearest-neighbour queries."""
+    rng = np.random.default_rng(77)
+    cases = max(4, CASES // 6)
+    with engine_with_mode("exact") as exact, engine_with_mode("xbf16") as fast, engine_with_mode("pruned") as pruned:
+        for case in range(cases):
+            ns, nt = int(rng.integers(3000, 40000)), int(rng.integers(5000, 80000))
+            tgt6 = st.synth_cloud_np(st.TARGET_SEED + case, nt, normals=True)
+            T = st.rigid_transform(rng.uniform(0.5, 4.0), rng.standard_normal(3), rng.standard_normal(3) * 0.02)
+            src = st.synth_cloud_np(st.SOURCE_SEED + case, ns, noise_seed=st.NOISE_SEED + case, sigma=st.SIGMA, transform=T)
+            init = np.stack([np.eye(4), st.rigid_transform(1.0, (0.2, 1, -0.4), (0.01, -0.02, 0.015))])
+            out = []
+            for eng in (exact, fast, pruned):
+                eng.set_targets([tgt6])
+                eng.set_sources([src])
+                out.append(eng.align_reference(init, 60, 0.005, 2.5, 6, source_ids=[0, 0], target_ids=[0, 0]))
+            for other in out[1:]:
+                assert np.array_equal(other.passes, out[0].passes), case
+                assert np.array_equal(other.poses, out[0].poses) and np.array_equal(other.residual, out[0].residual), case
