@@ -535,7 +535,11 @@ __global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xmfma_kernel(const J
 // VALU work per pair: the minimum over the 16 accumulator registers (1 issue slot) + ~0.14 slots of bookkeeping.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifdef MI355_PIN_OFF
+#define MI355_PIN(frag, acc, cm) ((void)0)
+#else
 #define MI355_PIN(frag, acc, cm) asm volatile("" : "+v"(frag), "+v"(acc), "+v"(cm))
+#endif
 __device__ __forceinline__ u32x4 load_frag(const uint4* p) { return *reinterpret_cast<const u32x4*>(p); }
 
 __device__ __forceinline__ void split_bf16(float v, uint32_t& packed, float& value) {
