@@ -100,3 +100,14 @@ def test_cpp_harness_builds_against_the_abi_and_fails_loudly_without_gpu():
     if not _gpu_visible():
         r = subprocess.run([exe, "100", "100"], capture_output=True, text=True, timeout=60)
         assert r.returncode == 1 and "no CPU fallback" in r.stderr
+
+
+def test_flag_and_status_constants_match_the_header():
+    """The ctypes side repeats a few #defines of include/mi355_icp.h by hand: keep them honest."""
+    import re
+    from pose_estimation_amd import _lib
+    text = open(os.path.join(ROOT, "include", "mi355_icp.h")).read()
+    defines = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(MI355_ICP_\w+)\s+(-?\d+)\b", text)}
+    assert defines["MI355_ICP_FLAG_PROFILE"] == _lib.FLAG_PROFILE
+    assert defines["MI355_ICP_FLAG_PRUNED_SCAN"] == _lib.FLAG_PRUNED_SCAN
+    assert defines["MI355_ICP_NSUMS"] == _lib.NSUMS
