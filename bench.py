@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — correspondence-pairs/s and ICP iterations/s of the MI355X alignment engine.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by torch.distributed.run,
-one rank per GPU).  A *step* is one ICP iteration: source transform + exact brute-force NN scan +
+Contract: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the driver launches it under
+torch.distributed.run, one rank per GPU; run plainly (no WORLD_SIZE in the environment) with --gpus N > 1 it spawns the
+N ranks ITSELF - fresh child processes, started before this process has touched torch or HIP - and relays rank 0's JSON
+line.  `n_gpus` in that line is what the communicator reports (ncclCommCount), and a run whose rank count differs from
+--gpus exits non-zero instead of printing a mislabelled line.  A *step* is one ICP iteration: source transform + exact brute-force NN scan +
 covariance accumulation + (N > 1: one RCCL all-reduce of 17 doubles) + host Kabsch/convergence, all
 through `mi355_icp_align`.  Clouds are uploaded before the timed region (inputs resident in HBM).
 
@@ -59,6 +62,10 @@ def parse():
     ap.add_argument("--n-target", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-iters", type=int, default=20, help="ICP iterations of the CPU baseline sample (about 3 s on 16 threads)")
+    ap.add_argument("--cpu-baseline-iters-1thread", type=int, default=3, help="... of its 1-thread leg (about 5 s)")
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the short all-exact-scan leg (roofline_exact)")
+    ap.add_argument("--exact-leg-steps", type=int, default=3)
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--collective", choices=["native", "torch"], default="native",
                     help="N > 1: RCCL all-reduce issued inside the engine (native) or by torch.distributed")
     ap.add_argument("--force-dist", action="store_true", help="exercise the distributed code path even at N = 1")
@@ -68,36 +75,104 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(src, tgt, iters):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(src, tgt, iters, iters_1thread):
     """CPU restatement of point-to-point ICP (KD-tree), timed on this host: oracle/icp_oracle.c.
-    Never labelled PCL/OpenCV: neither exists here."""
+    Never labelled PCL/OpenCV: neither exists here.  Headline = ICP iterations/s on all the cores this
+    job owns; the 1-thread figure and the CPU model are printed beside it.  The tree answers a
+    query in O(log Nt): Ns*Nt "pairs" per iteration is only the brute-force-EQUIVALENT count, kept under that name."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as ora
     # the GPU box gives a 1-GPU job a 16-core share of its host (more threads than that would be borrowed)
     threads = max(1, min(ora.max_threads(), len(os.sched_getaffinity(0)), 16))
-    p = ora.params(max_iterations=iters)
-    t0 = time.perf_counter()
-    r = ora.icp(src, tgt, np.eye(4), p, use_kdtree=True, nthreads=threads)
-    dt = time.perf_counter() - t0
-    pairs = float(src.shape[0]) * float(tgt.shape[0]) * r["iterations"]
+
+    def timed(n_iter, nth):
+        p = ora.params(max_iterations=n_iter)
+        t0 = time.perf_counter()
+        r = ora.icp(src, tgt, np.eye(4), p, use_kdtree=True, nthreads=nth)
+        return r, time.perf_counter() - t0
+
+    r, dt = timed(iters, threads)
+    r1, dt1 = timed(iters_1thread, 1)
     return {
-        "value": pairs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-        "iters_per_s": r["iterations"] / dt,
-        "sample": f"{r['iterations']} ICP iterations of the same {src.shape[0]}x{tgt.shape[0]} workload incl. KD-tree build, "
-                  f"exact KD-tree NN (pairs counted as Ns*Nt per iteration, i.e. brute-force-equivalent), {dt:.2f} s",
+        "value": r["iterations"] / dt, "unit": f"ICP iterations/s ({src.shape[0]}x{tgt.shape[0]}, exact KD-tree NN)",
+        "cores": threads, "kind": "port", "cpu_model": cpu_model(), "host_cores_visible": len(os.sched_getaffinity(0)),
+        "iters_per_s": r["iterations"] / dt, "iters_per_s_1thread": r1["iterations"] / dt1,
+        "brute_force_equivalent_pairs_per_s": float(src.shape[0]) * float(tgt.shape[0]) * r["iterations"] / dt,
+        "sample": f"{r['iterations']} ICP iterations of the same {src.shape[0]}x{tgt.shape[0]} workload on {threads} threads in "
+                  f"{dt:.2f} s + {r1['iterations']} iterations on 1 thread in {dt1:.2f} s, KD-tree build included in both; "
+                  "O(Ns log Nt) exact tree search, NOT a brute-force scan - compare iterations/s, not pairs/s",
         "pose": r["pose"],
     }
 
 
+def launch_ranks(n, argv, extra_env=None):
+    """Plain `python bench.py --gpus N` (N > 1, no WORLD_SIZE): start N fresh rank processes - one per device,
+    RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set - and relay rank 0's stdout.  Called before this process imports torch or
+    touches HIP: children are ordinary child processes, never a re-exec of a GPU-initialised one.  Returns the exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py launcher: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def launcher_selftest():
+    """Rank body of `--launcher-selftest`: rendezvous over gloo (no GPU), prove every rank is there, rank 0 prints one
+    JSON line.  tests/test_bench_launcher_cpu.py drives it through launch_ranks with 2 ranks."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = torch.zeros(world, dtype=torch.int64)
+    seen[rank] = 1 + int(os.environ["LOCAL_RANK"])
+    dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_ranks": dist.get_world_size(), "local_ranks_plus_1": seen.tolist()}))
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # nothing GPU-related has been imported yet: spawn the ranks and relay rank 0's line
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
+    if a.launcher_selftest:
+        return launcher_selftest()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist_mode = world > 1 or a.force_dist
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: refusing to print a mislabelled line")
     torch = dist = None
     if dist_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -105,6 +180,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch  # loads the HIP runtime first so the engine binds to the same one
         import torch.distributed as dist
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: --gpus {a.gpus} needs device {local_rank}, but only {torch.cuda.device_count()} are visible")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -173,6 +250,15 @@ def main():
     assert int(res.iterations[0]) == a.steps and int(res.status[0]) == 0, (res.iterations, res.status)
 
     prof = eng.profile()
+    # the rank count the line reports is the communicator's own (ncclCommCount), not an environment variable
+    if collective == "rccl-native":
+        n_ranks = eng.comm_info()[1]
+    elif dist_mode:
+        n_ranks = dist.get_world_size()
+    else:
+        n_ranks = 1
+    if n_ranks != a.gpus:
+        raise SystemExit(f"the communicator spans {n_ranks} ranks but --gpus is {a.gpus}: refusing to print a mislabelled line")
     traffic, traffic_note = None, None
     try:  # PMC counters cannot be read from inside this process; use the committed rocprofv3 pass of this same command
         tj = json.load(open(os.path.join(ROOT, "profiles", "scan_traffic.json")))
@@ -189,7 +275,7 @@ def main():
         kernel, bound, peak, exec_flop, slots_per_pair, note = SCAN_MODELS.get(mode, SCAN_MODELS["xfilter"])
         out = {
             "metric": "correspondence_pairs_per_sec", "value": pairs_step * a.steps / elapsed, "unit": "pairs/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "n_gpus": n_ranks, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "icp_iters_per_sec": a.steps / elapsed,
             "correspondences_per_sec": float(ns_total) * a.steps / elapsed,
@@ -225,8 +311,36 @@ def main():
             "upload_s": upload_s, "device": eng.device_info()["name"],
             "final_pose_error_vs_truth": float(np.linalg.norm(res.poses[0] - np.linalg.inv(T))),
         }
+        if world == 1 and not a.no_exact_leg and mode != "exact":
+            # north_star's literal kernel (LDS-tiled all-exact scan, no matrix cores) in the same driver-timed run: a
+            # second engine with the planner forced to it, a few steps, priced against the FP32 vector peak
+            os.environ["MI355_ICP_SCAN_MODE"] = "exact"
+            try:
+                ex = pa.IcpEngine(local_rank)
+            finally:
+                os.environ.pop("MI355_ICP_SCAN_MODE")
+            ex.set_targets([tgt])
+            ex.set_sources([src])
+            ex.align(np.eye(4)[None], pa.default_params(max_iterations=1))
+            ex.reset_profile()
+            ex.set_profiling(True)
+            t1 = time.perf_counter()
+            rex = ex.align(np.eye(4)[None], pa.default_params(max_iterations=a.exact_leg_steps))
+            ex_elapsed = time.perf_counter() - t1
+            pe = ex.profile()
+            ex.close()
+            ex_ms = pe.nn_scan_ms / max(pe.nn_scan_launches, 1)
+            k2, b2, peak2, flop2, _slots2, note2 = SCAN_MODELS["exact"]
+            out["roofline_exact"] = {
+                "bound": b2, "kernel": k2, "achieved": flop2 * pairs_launch / (ex_ms * 1e-3) / 1e12, "peak": peak2, "unit": "TFLOP/s",
+                "frac": flop2 * pairs_launch / (ex_ms * 1e-3) / 1e12 / peak2, "avg_launch_ms": ex_ms, "launches": int(pe.nn_scan_launches),
+                "steps": a.exact_leg_steps, "ms_per_step": 1e3 * ex_elapsed / a.exact_leg_steps, "pairs_per_s": pairs_step * a.exact_leg_steps / ex_elapsed,
+                "flop_per_pair": flop2, "pose_vs_default_path_frobenius": float(np.linalg.norm(rex.poses[0] - eng.align(np.eye(4)[None], pa.default_params(max_iterations=a.exact_leg_steps)).poses[0])),
+                "note": note2 + " This is north_star's literal form (target tiles through LDS, no MFMA); the default path above "
+                                "returns the same bits faster.",
+            }
         if world == 1 and not a.no_cpu_baseline:
-            cb = cpu_baseline(src, tgt, a.cpu_baseline_iters)
+            cb = cpu_baseline(src, tgt, a.cpu_baseline_iters, a.cpu_baseline_iters_1thread)
             cpu_pose = cb.pop("pose")
             if a.cpu_baseline_iters == a.steps:
                 out["pose_vs_cpu_frobenius"] = float(np.linalg.norm(res.poses[0] - cpu_pose))

@@ -100,6 +100,9 @@ typedef struct mi355_icp_profile {
   uint64_t scene_filter_launches;
   uint64_t scene_points_in;  /* points read / written by those launches */
   uint64_t scene_points_out;
+  uint64_t overflow_host_passes; /* passes whose overflow points went through the host path (gather -> all-exact tiled
+                                    scan -> scatter) instead of the device-side pass: more than 1024 of them in one job,
+                                    a large target, or a communicator attached */
 } mi355_icp_profile;
 
 /* ---- lifetime ------------------------------------------------------------ */
@@ -121,10 +124,10 @@ void mi355_icp_default_params(mi355_icp_params* p);
 
 /* Maps the reference's constructor arguments ICP(iterations, tolerance,
  * rejectionScale, numLevels) (opencv_surface_match.cpp:85) onto params.
- * iterations -> max_iterations, tolerance -> relative_mse_epsilon.
- * rejectionScale and numLevels belong to the point-to-plane/pyramid mode
- *  and are accepted but not used by this point-to-point
- * engine; returns MI355_ICP_OK.  [host] */
+ * iterations -> max_iterations, tolerance -> relative_mse_epsilon, for the POINT-TO-POINT loop
+ * (mi355_icp_align), which has no use for rejectionScale and numLevels: they are validated and dropped
+ * here.  All four arguments are live in reference mode - mi355_icp_reference_params /
+ * mi355_icp_align_reference below - which is what the reference's call really runs.  [host] */
 int mi355_icp_params_from_reference(int iterations, float tolerance, float rejection_scale, int num_levels,
                                     mi355_icp_params* p);
 
@@ -185,7 +188,11 @@ int mi355_icp_align(mi355_icp_ctx* ctx, int n_jobs, const int* source_ids, const
  *   out_index   concatenated over jobs, source-cloud order: int32 target index  (may be NULL)
  *   out_dist2   same shape: float32 squared distance                         (may be NULL)
  *   out_sums    MI355_ICP_NSUMS * n_jobs doubles, LOCAL to this rank (never all-reduced)
- * max_correspondence_distance as in params (<= 0 keeps all). */
+ * max_correspondence_distance as in params (<= 0 keeps all).
+ * A source point whose distance to EVERY target is +inf or NaN (coordinates or a pose that overflow float32)
+ * gets the oracle's answer for "nothing below +inf": index 0, d2 = +inf; the call still returns MI355_ICP_OK and
+ * mi355_icp_last_error() says that it happened.  (In mi355_icp_align such a pair makes the job's sums non-finite
+ * and the job ends with MI355_ICP_ERR_NUMERIC, its pose left at the last valid value.) */
 int mi355_icp_correspond(mi355_icp_ctx* ctx, int n_jobs, const int* source_ids, const int* target_ids,
                          const double* poses, float max_correspondence_distance, int32_t* out_index,
                          float* out_dist2, double* out_sums);
@@ -212,7 +219,7 @@ typedef struct mi355_icp_reference_params {
 /* Batched like mi355_icp_align.  out_residual[k] is the smallest fval = sqrt(sum |p-q|^2)/n_level of the
  * finest level that ran (cloud units; upstream reports it in its pre-normalised units), out_passes[k] the
  * number of correspondence passes over all levels.  A job whose level ends early (< 6 pairs, degenerate
- * solve) keeps what it has, as upstream does.  Single-GPU only (not with a communicator attached).
+ * solve) keeps what it has, as upstream does.
  * Replaces: ICP::registerModelToScene(model, scene, poses) with the reference's parameters. */
 int mi355_icp_align_reference(mi355_icp_ctx* ctx, int n_jobs, const int* source_ids, const int* target_ids,
                               const double* init_poses, const mi355_icp_reference_params* params, double* out_poses,
@@ -316,12 +323,30 @@ int mi355_icp_pose_to_pose7(const double pose[16], float out7[7], int reference_
  * other ranks by any means (bench.py uses torch.distributed).  [host+RCCL] */
 int mi355_icp_comm_unique_id(unsigned char out_id[MI355_ICP_UNIQUE_ID_BYTES]);
 
-/* Joins this context to an RCCL communicator of `n_ranks` ranks.  Afterwards
- * mi355_icp_align all-reduces the MI355_ICP_NSUMS * n_jobs doubles once per
- * iteration (ncclAllReduce, sum, float64) on the engine's stream. */
+/* Joins this context to an RCCL communicator of `n_ranks` ranks.  Afterwards mi355_icp_align and
+ * mi355_icp_align_reference run slab-sharded: every rank makes the same call on its own slab of each source cloud
+ * and receives identical results.  Per correspondence pass the MI355_ICP_NSUMS (or MI355_ICP_NREFSUMS) doubles of
+ * every job are exchanged ONCE: the per-rank rows are all-gathered (ncclAllGather on the engine's stream) and added
+ * in rank order on every rank, so the sums - hence poses and convergence decisions - are bit-identical on all ranks
+ * and do not depend on the collective algorithm RCCL picks.  Reference mode adds integer
+ * collectives, exact in any order: six ncclAllReduce(sum, uint32) of a 2048-bin histogram per pass for the MAD
+ * threshold and one ncclAllReduce(min, uint64) of the picky owner table. */
 int mi355_icp_comm_attach(mi355_icp_ctx* ctx, const unsigned char id[MI355_ICP_UNIQUE_ID_BYTES], int rank,
                           int n_ranks);
+
+/* The same exchange over a transport the CALLER supplies: `allgather(user, send, recv, bytes_per_rank)` must place
+ * rank r's `bytes_per_rank` bytes at recv + r * bytes_per_rank on every rank (host memory) and return 0.  The engine
+ * stages through pinned host buffers and performs every reduction itself, in rank order.  Used where RCCL cannot
+ * run (ranks sharing one GPU, gloo in the tests); slower than the native path by one host synchronisation per
+ * exchange. */
+typedef int (*mi355_icp_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+int mi355_icp_comm_attach_external(mi355_icp_ctx* ctx, int rank, int n_ranks, mi355_icp_allgather_fn allgather,
+                                   void* user);
 int mi355_icp_comm_detach(mi355_icp_ctx* ctx);
+
+/* What is attached: *kind = 0 none, 1 RCCL (rank and size as the communicator itself reports them:
+ * ncclCommUserRank / ncclCommCount), 2 external.  Any output may be NULL. */
+int mi355_icp_comm_info(const mi355_icp_ctx* ctx, int* rank, int* n_ranks, int* kind);
 
 /* ---- measurement ---------------------------------------------------------- */
 

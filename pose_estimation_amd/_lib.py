@@ -78,6 +78,7 @@ class Profile(C.Structure):
         ("scene_filter_launches", C.c_uint64),
         ("scene_points_in", C.c_uint64),
         ("scene_points_out", C.c_uint64),
+        ("overflow_host_passes", C.c_uint64),
     ]
 
 
@@ -92,6 +93,9 @@ SCENE_FILTER_SPHERE_REMOVE_INSIDE = 2
 SCENE_FILTER_PLANE_BAND_REMOVE = 3
 SCENE_MAX_FILTERS = 8
 
+
+# mi355_icp_allgather_fn: int (*)(void* user, const void* send, void* recv, size_t bytes_per_rank)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
 # every symbol include/mi355_icp.h declares: name -> (restype, argtypes)
 _P = C.POINTER
@@ -126,7 +130,9 @@ SIGNATURES = {
     "mi355_icp_pose_to_pose7": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "mi355_icp_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mi355_icp_comm_attach": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
+    "mi355_icp_comm_attach_external": (C.c_int, [_ctx, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),
     "mi355_icp_comm_detach": (C.c_int, [_ctx]),
+    "mi355_icp_comm_info": (C.c_int, [_ctx, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     "mi355_icp_set_profiling": (C.c_int, [_ctx, C.c_int]),
     "mi355_icp_get_profile": (C.c_int, [_ctx, _P(Profile)]),
     "mi355_icp_reset_profile": (C.c_int, [_ctx]),

@@ -152,8 +152,7 @@ struct mi355_icp_ctx {
   uint32_t* scene_counters = nullptr;       // device: ticket, kept total, error bits
   uint32_t* scene_counters_host = nullptr;  // pinned
 
-  void* comm = nullptr;
-  int comm_rank = 0, comm_size = 1;
+  CommState comm;  // slab-sharded runs: the cross-rank exchange (comm.hip); not attached = single GPU
 
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   mi355_icp_profile prof{};
@@ -323,10 +322,11 @@ int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs) {
     if (c->sums_host) { HIP_TRY(c, hipHostFree(c->sums_host)); c->sums_host = nullptr; }
     c->jobs_cap = 0;
     const size_t want = std::max<size_t>(n_jobs, 8) * 2;
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sums_dev), want * MI355_ICP_NSUMS * sizeof(double)));
+    // + one double per job: the overflow-excess flag that rides along with the sums in a slab-sharded pass
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sums_dev), want * (MI355_ICP_NSUMS + 1) * sizeof(double)));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->jobs_dev), want * sizeof(JobDesc)));
     HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->jobs_host), want * sizeof(JobDesc), hipHostMallocDefault));
-    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->sums_host), want * MI355_ICP_NSUMS * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->sums_host), want * (MI355_ICP_NSUMS + 1) * sizeof(double), hipHostMallocDefault));
     c->jobs_cap = want;
   }
   return MI355_ICP_OK;
@@ -510,6 +510,7 @@ int run_overflow_fallback(mi355_icp_ctx* c, const Plan& plan, int n_active, cons
     c->overflow_points_total += J.src_n;
     c->prof.overflow_points += J.src_n;
   }
+  c->prof.overflow_host_passes += 1;
   HIP_TRY(c, hipGetLastError());
   return MI355_ICP_OK;
 }
@@ -662,16 +663,17 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
 }
 
 // After the final synchronisation of a pass that deferred its overflow handling: were all counts within what the device
-// pass covers?  (If not, the caller repeats the pass with the host path.)  Books the points either way.
-bool overflow_settled(mi355_icp_ctx* c, int n_active) {
+// pass covers?  (If not, the caller repeats the pass with the host path.)
+bool overflow_within_cap(const mi355_icp_ctx* c, int n_active) {
   bool ok = true;
   for (int k = 0; k < n_active; ++k) ok = ok && c->overflow_count_host[k] <= kOverflowCap;
-  if (ok)
-    for (int k = 0; k < n_active; ++k) {
-      c->overflow_points_total += c->overflow_count_host[k];
-      c->prof.overflow_points += c->overflow_count_host[k];
-    }
   return ok;
+}
+void book_overflow(mi355_icp_ctx* c, int n_active) {
+  for (int k = 0; k < n_active; ++k) {
+    c->overflow_points_total += c->overflow_count_host[k];
+    c->prof.overflow_points += c->overflow_count_host[k];
+  }
 }
 
 // The device-side pass streams the whole target cloud once per overflow point (12 B per target and point, out of L2 /
@@ -688,9 +690,10 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
 // Enqueues one correspondence pass for the first n_active descriptors of jobs_host and leaves
 // their sums in sums_host (synchronises the stream).  `local_only` skips the collective.
 int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only) {
-  // with a communicator attached the collective sits between the kernels and the synchronisation, so a rank cannot
-  // repeat its pass afterwards: read the overflow counts first, as before
-  const bool defer = plan.fused && !(c->comm && !local_only) && defer_pays(c, n_active);
+  // Slab-sharded: the exchange sits between the kernels and the synchronisation, so a rank cannot decide on its own to
+  // repeat a pass.  The per-job "my device-side overflow pass was too small" flags therefore travel WITH the sums;
+  // every rank sees their total and all of them repeat the pass through the host path together.
+  const bool defer = plan.fused && defer_pays(c, n_active);
   bool retry = false;
   int st = run_pass_once(c, plan, n_active, profile, local_only, defer, &retry);
   if (st == MI355_ICP_OK && retry) st = run_pass_once(c, plan, n_active, profile, local_only, false, &retry);
@@ -735,16 +738,27 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
   launch_final_reduce(c->stream, c->jobs_dev, n_active, c->partials, c->sums_dev);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
   HIP_TRY(c, hipGetLastError());
-  if (c->comm && !local_only) {
+  const bool exchange = c->comm.attached() && !local_only;
+  const size_t n_sums = static_cast<size_t>(n_active) * MI355_ICP_NSUMS;
+  if (exchange) {
     const char* why = nullptr;
-    if (rccl_allreduce_f64_sum(c->comm, c->sums_dev, static_cast<size_t>(n_active) * MI355_ICP_NSUMS, c->stream, &why) != MI355_ICP_OK)
-      return fail(c, MI355_ICP_ERR_COMM, std::string("ncclAllReduce: ") + (why ? why : "?"));
+    double* flags = c->sums_dev + n_sums;
+    if (defer) launch_overflow_excess(c->stream, c->overflow_count, kOverflowCap, n_active, flags);
+    else HIP_TRY(c, hipMemsetAsync(flags, 0, static_cast<size_t>(n_active) * sizeof(double), c->stream));
+    const int cst = comm_sum_f64_rank_order(c->comm, c->sums_dev, n_sums + static_cast<size_t>(n_active), c->stream, &why);
+    if (cst != MI355_ICP_OK) return fail(c, cst == MI355_ICP_ERR_HIP ? MI355_ICP_ERR_HIP : MI355_ICP_ERR_COMM, std::string("cross-rank exchange: ") + (why ? why : "?"));
   }
-  HIP_TRY(c, hipMemcpyAsync(c->sums_host, c->sums_dev, static_cast<size_t>(n_active) * MI355_ICP_NSUMS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->sums_host, c->sums_dev, (n_sums + (exchange ? static_cast<size_t>(n_active) : 0)) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (defer && !overflow_settled(c, n_active)) {
-    *retry = true;
-    return MI355_ICP_OK;
+  if (defer) {
+    bool settled = overflow_within_cap(c, n_active);
+    if (exchange)  // the decision must be the same on every rank: was any flag raised anywhere?
+      for (int k = 0; k < n_active; ++k) settled = settled && c->sums_host[n_sums + static_cast<size_t>(k)] == 0.0;
+    if (!settled) {
+      *retry = true;
+      return MI355_ICP_OK;
+    }
+    book_overflow(c, n_active);
   }
   c->prof.iterations += 1;
   c->prof.pairs_evaluated += pairs;
@@ -783,11 +797,17 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
     }
     lv.stride = static_cast<size_t>(std::max<uint64_t>(total, pad_multiple));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&lv.planes), 3 * lv.stride * sizeof(float)));
-    if (total == 0) HIP_TRY(c, hipMemsetAsync(lv.planes, 0, 3 * lv.stride * sizeof(float), c->stream));
-    for (size_t k = 0; k < set.clouds.size(); ++k)
+    hipError_t e = hipSuccess;
+    if (total == 0) e = hipMemsetAsync(lv.planes, 0, 3 * lv.stride * sizeof(float), c->stream);
+    for (size_t k = 0; k < set.clouds.size() && e == hipSuccess; ++k)
       launch_subsample(c->stream, set.planes, set.stride, set.clouds[k].off, lv.planes, lv.stride, lv.clouds[k].off,
                        lv.clouds[k].n, lv.clouds[k].padded, step, pad_value);
-    HIP_TRY(c, hipGetLastError());
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {  // the level is not adopted: give its planes back
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipFree(lv.planes);
+      return fail(c, MI355_ICP_ERR_HIP, std::string("building pyramid level: ") + hipGetErrorString(e));
+    }
     set.levels.push_back(lv);
   }
   return MI355_ICP_OK;
@@ -897,9 +917,12 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
   HIP_TRY(c, hipMemcpyAsync(c->ref_sums_host, c->ref_sums_dev, static_cast<size_t>(n_active) * kRefSums * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->thr_host, c->thr_dev, static_cast<size_t>(n_active) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (defer && !overflow_settled(c, n_active)) {
-    *retry = true;
-    return MI355_ICP_OK;
+  if (defer) {
+    if (!overflow_within_cap(c, n_active)) {
+      *retry = true;
+      return MI355_ICP_OK;
+    }
+    book_overflow(c, n_active);
   }
   c->prof.iterations += 1;
   c->prof.pairs_evaluated += pairs;
@@ -995,7 +1018,7 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  if (c->comm) rccl_comm_destroy(c->comm);
+  comm_release(c->comm);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1174,7 +1197,7 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
   c->err.clear();
   if (n_jobs < 1 || !init_poses || !rp) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: bad arguments");
   if (rp->iterations < 1 || rp->num_levels < 1 || rp->num_levels > 24) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: iterations >= 1 and 1 <= num_levels <= 24 required");
-  if (c->comm) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: not available on a slab-sharded context (the MAD threshold needs a global selection)");
+  if (c->comm.attached()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: not available on a slab-sharded context (the MAD threshold needs a global selection)");
   HIP_TRY(c, hipSetDevice(c->device));
   int st = check_reference_inputs(c, n_jobs, source_ids, target_ids);
   if (st != MI355_ICP_OK) return st;
@@ -1556,27 +1579,48 @@ int mi355_icp_comm_unique_id(unsigned char out_id[MI355_ICP_UNIQUE_ID_BYTES]) {
 int mi355_icp_comm_attach(mi355_icp_ctx* c, const unsigned char id[MI355_ICP_UNIQUE_ID_BYTES], int rank, int n_ranks) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "comm_attach: bad rank / size");
-  if (c->comm) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "comm_attach: a communicator is already attached");
+  if (c->comm.attached()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "comm_attach: a communicator is already attached");
   HIP_TRY(c, hipSetDevice(c->device));
   const char* why = nullptr;
   void* comm = nullptr;
   if (rccl_comm_init(&comm, id, rank, n_ranks, &why) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_COMM, std::string("ncclCommInitRank: ") + (why ? why : "?"));
-  c->comm = comm;
-  c->comm_rank = rank;
-  c->comm_size = n_ranks;
+  c->comm.rccl = comm;
+  c->comm.rank = rank;
+  c->comm.size = n_ranks;
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_comm_attach_external(mi355_icp_ctx* c, int rank, int n_ranks, mi355_icp_allgather_fn allgather, void* user) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  if (!allgather || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "comm_attach_external: bad rank / size / callback");
+  if (c->comm.attached()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "comm_attach_external: a communicator is already attached");
+  c->comm.ext = allgather;
+  c->comm.ext_user = user;
+  c->comm.rank = rank;
+  c->comm.size = n_ranks;
   return MI355_ICP_OK;
 }
 
 int mi355_icp_comm_detach(mi355_icp_ctx* c) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
-  if (c->comm) {
+  if (c->comm.attached()) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    rccl_comm_destroy(c->comm);
-    c->comm = nullptr;
-    c->comm_rank = 0;
-    c->comm_size = 1;
+    comm_release(c->comm);
   }
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_comm_info(const mi355_icp_ctx* c, int* rank, int* n_ranks, int* kind) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  int r = c->comm.rank, n = c->comm.size;
+  if (c->comm.rccl) {  // what the communicator itself reports, not what the caller claimed at attach
+    const char* why = nullptr;
+    if (rccl_comm_query(c->comm.rccl, &r, &n, &why) != MI355_ICP_OK) return MI355_ICP_ERR_COMM;
+  }
+  if (rank) *rank = r;
+  if (n_ranks) *n_ranks = n;
+  if (kind) *kind = c->comm.rccl ? 1 : (c->comm.ext ? 2 : 0);
   return MI355_ICP_OK;
 }
 

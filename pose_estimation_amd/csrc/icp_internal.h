@@ -224,7 +224,38 @@ struct RcclApi;
 const RcclApi* rccl_api(const char** why_not);
 int rccl_unique_id(unsigned char* out128, const char** err);
 int rccl_comm_init(void** comm, const unsigned char* id128, int rank, int n_ranks, const char** err);
-int rccl_allreduce_f64_sum(void* comm, double* dev_buf, size_t count, void* stream, const char** err);
+int rccl_comm_query(void* comm, int* rank, int* n_ranks, const char** err);   // ncclCommUserRank / ncclCommCount
+int rccl_allgather_bytes(void* comm, const void* dev_send, void* dev_recv, size_t bytes_per_rank, void* stream, const char** err);
+int rccl_allreduce_u32_sum(void* comm, uint32_t* dev_buf, size_t count, void* stream, const char** err);
+int rccl_allreduce_u64_min(void* comm, unsigned long long* dev_buf, size_t count, void* stream, const char** err);
 void rccl_comm_destroy(void* comm);
+
+// ---- the cross-rank exchange step of a slab-sharded run (comm.hip) ----
+// One process per GPU; every rank holds a slab of each source cloud and the whole target.  Two transports:
+//   native   - an RCCL communicator (mi355_icp_comm_attach): collectives are enqueued on the engine's stream, no host sync;
+//   external - a host callback that all-gathers bytes (mi355_icp_comm_attach_external): the caller's transport
+//              (torch.distributed over gloo in the tests); the engine stages through pinned host memory.
+// Floating-point sums are NEVER reduced by the transport: the per-rank rows are all-gathered and added in rank order
+// (SURVEY.md 8e), so every rank holds identical bits and the result does not depend on RCCL's algorithm choice.
+// Integer reductions (histogram counts, picky owner keys) are exact in any order and use ncclAllReduce natively.
+struct CommState {
+  void* rccl = nullptr;
+  mi355_icp_allgather_fn ext = nullptr;
+  void* ext_user = nullptr;
+  int rank = 0, size = 1;
+  unsigned char* gather_dev = nullptr; size_t gather_dev_cap = 0;   // native: size x bytes_per_rank
+  unsigned char* stage_send = nullptr; unsigned char* stage_recv = nullptr; size_t stage_send_cap = 0, stage_recv_cap = 0;  // external: pinned
+  bool attached() const { return rccl != nullptr || ext != nullptr; }
+};
+// dev_buf[0..count) <- sum over ranks r = 0, 1, ... (in that order) of rank r's dev_buf.  Returns an mi355_icp_status.
+int comm_sum_f64_rank_order(CommState& cs, double* dev_buf, size_t count, void* stream, const char** err);
+int comm_sum_u32(CommState& cs, uint32_t* dev_buf, size_t count, void* stream, const char** err);
+int comm_min_u64(CommState& cs, unsigned long long* dev_buf, size_t count, void* stream, const char** err);
+// host-side all-gather of a few bytes per rank (cloud sizes at the start of a sharded reference-mode call)
+int comm_allgather_host(CommState& cs, const void* send, void* recv, size_t bytes_per_rank, void* stream, const char** err);
+void comm_release(CommState& cs);  // frees the staging buffers and destroys a native communicator
+// out[k] = counts[k] > cap ? 1.0 : 0.0 (rides along with the sums so that every rank learns whether ANY rank's
+// device-side overflow pass was too small, and all of them repeat the pass through the host path together)
+void launch_overflow_excess(void* stream, const uint32_t* counts, uint32_t cap, int n, double* out);
 
 }  // namespace mi355

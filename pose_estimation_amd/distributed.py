@@ -3,9 +3,13 @@
 Two ways to run the per-iteration all-reduce of the MI355_ICP_NSUMS x n_jobs doubles:
 
 * native (preferred, used by bench.py): ``IcpEngine.comm_attach`` joins the engine to an RCCL
-  communicator and ``IcpEngine.align`` issues one ``ncclAllReduce`` per iteration on its own
-  stream — no Python in the loop.  ``attach_native_comm`` below does the rendezvous through an
-  existing torch.distributed process group (it only ships the 128-byte RCCL unique id).
+  communicator and ``IcpEngine.align`` exchanges the sums once per iteration on its own stream
+  (``ncclAllGather`` + a rank-ordered sum on every rank) — no Python in the loop.
+  ``attach_native_comm`` below does the rendezvous through an existing torch.distributed process
+  group (it only ships the 128-byte RCCL unique id).
+* native loop, caller's transport: ``attach_external_comm`` hands the engine an all-gather that runs
+  over any torch.distributed group (gloo in the tests, where two ranks share one GPU and RCCL cannot
+  run); the engine's own loop and its rank-ordered reductions are what executes.
 * external (this module's ``align_external_collective``): the caller supplies the reduction
   (e.g. ``torch.distributed.all_reduce`` on RCCL or, in the CPU tests, gloo) and the loop runs here,
   calling the SAME host controller (``mi355_icp_host_update``) the native loop uses, so both make
@@ -99,3 +103,19 @@ def attach_native_comm(engine: IcpEngine, group=None) -> None:
     box = [IcpEngine.comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0, group=group)
     engine.comm_attach(box[0], rank, world)
+
+
+def attach_external_comm(engine: IcpEngine, group=None) -> None:
+    """Joins `engine` to the ranks of a torch.distributed group through a HOST all-gather (any backend; gloo in the
+    tests): the engine's own slab-sharded loops run, staging each exchange through host memory."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+    def allgather(send) -> bytes:
+        mine = torch.frombuffer(bytearray(send), dtype=torch.uint8)
+        out = torch.empty(world * mine.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(out, mine, group=group)
+        return out.numpy().tobytes()
+
+    engine.comm_attach_external(rank, world, allgather)

@@ -322,8 +322,30 @@ class IcpEngine:
         buf = (C.c_ubyte * _lib.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
         self._check(lib.mi355_icp_comm_attach(self._h, buf, rank, n_ranks))
 
+    def comm_attach_external(self, rank: int, n_ranks: int, allgather):
+        """Slab-sharded run over a transport the caller supplies: ``allgather(send: bytes-like of n bytes) -> bytes-like
+        of n_ranks * n bytes`` (rank r's block at offset r * n).  The engine reduces everything itself, in rank order."""
+        def thunk(_user, send, recv, nbytes):
+            try:
+                out = allgather((C.c_ubyte * nbytes).from_address(send))
+                C.memmove(recv, bytes(out), nbytes * n_ranks)
+                return 0
+            except Exception:  # must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._ext_cb = _lib.ALLGATHER_FN(thunk)  # keep the trampoline alive while attached
+        self._check(lib.mi355_icp_comm_attach_external(self._h, rank, n_ranks, self._ext_cb, None))
+
     def comm_detach(self):
         self._check(lib.mi355_icp_comm_detach(self._h))
+        self._ext_cb = None
+
+    def comm_info(self) -> tuple[int, int, int]:
+        """(rank, n_ranks, kind) with kind 0 = none, 1 = RCCL (as the communicator reports), 2 = external."""
+        r, n, k = C.c_int(), C.c_int(), C.c_int()
+        self._check(lib.mi355_icp_comm_info(self._h, C.byref(r), C.byref(n), C.byref(k)))
+        return r.value, n.value, k.value
 
     # -- measurement
     def set_profiling(self, enabled: bool):

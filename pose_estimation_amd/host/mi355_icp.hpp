@@ -166,15 +166,16 @@ struct Pose3D {
 using Pose3DPtr = std::shared_ptr<Pose3D>;
 
 // Mirror of cv::ppf_match_3d::ICP: same constructor arguments as the reference call site.
-// Mode::PointToPoint (default) is the engine of BASELINE.json (exact NN + Kabsch; numLevels and rejectionScale are
-// recorded only).  Mode::Reference runs upstream's structure with all four arguments live (pyramid, MAD rejection,
-// picky, point-to-plane on the scene normals: mi355_icp_align_reference) and needs the scene as N x 6 rows.
+// Mode::Reference (default: it is what the reference's call runs) keeps all four arguments live (pyramid, MAD
+// rejection, picky, point-to-plane on the scene normals: mi355_icp_align_reference) and needs the scene as N x 6 rows,
+// which is what the reference hands over (opencv_surface_match.cpp:57-59).  Mode::PointToPoint must be asked for by
+// name: the engine of BASELINE.json (exact NN + Kabsch; numLevels and rejectionScale are recorded only).
 class ICP {
  public:
   enum class Mode { PointToPoint, Reference };
 
   ICP(int iterations, float tolerence = 0.05f, float rejectionScale = 2.5f, int numLevels = 6, int device_id = 0,
-      Mode mode = Mode::PointToPoint)
+      Mode mode = Mode::Reference)
       : engine_(std::make_shared<Engine>(device_id)), mode_(mode) {
     const int st = mi355_icp_params_from_reference(iterations, tolerence, rejectionScale, numLevels, &params_);
     if (st != MI355_ICP_OK) throw Error(st, "mi355_icp_params_from_reference");

@@ -11,11 +11,13 @@ and then reads ``pose``, ``residual``, ``numVotes``, ``t`` and ``q`` off each Po
 in-place update behaviour, so code (and tests) written against the reference read the same;
 the arithmetic runs on the GPU through IcpEngine (C-ABI, include/mi355_icp.h).
 
-Two modes.  ``mode="point_to_point"`` (default) is the engine BASELINE.json specifies: exact NN,
-Kabsch, ``iterations``/``tolerence`` only.  ``mode="reference"`` runs what upstream's class really
-does with all four constructor arguments live — resolution pyramid (``numLevels``), median+MAD
-rejection (``rejectionScale``), picky dedupe and point-to-plane least squares on the scene normals
-(numeric definition in oracle/icp_oracle.c) — and needs the scene as N x 6.
+Two modes.  ``mode="reference"`` (the default: it is what the reference's call runs) keeps all four
+constructor arguments live — resolution pyramid (``numLevels``), median+MAD rejection
+(``rejectionScale``), picky dedupe and point-to-plane least squares on the scene normals (SURVEY.md
+8f rank 1; numeric definition in oracle/icp_oracle.c) — and needs the scene as N x 6, which is what
+the reference hands over (opencv_surface_match.cpp:57-59).  ``mode="point_to_point"`` must be asked
+for by name: the engine BASELINE.json specifies (exact NN, Kabsch), which uses ``iterations`` and
+``tolerence`` only.
 """
 from __future__ import annotations
 
@@ -113,7 +115,7 @@ class ICP:
 
     def __init__(self, iterations: int = 250, tolerence: float = 0.05, rejectionScale: float = 2.5,
                  numLevels: int = 6, sampleType: int = 0, numMaxCorr: int = 1, device_id: int = 0,
-                 engine: Optional[IcpEngine] = None, mode: str = "point_to_point", pruned_scan: bool = False):
+                 engine: Optional[IcpEngine] = None, mode: str = "reference", pruned_scan: bool = False):
         if mode not in ("point_to_point", "reference"):
             raise ValueError("mode must be 'point_to_point' or 'reference'")
         self.mode = mode

@@ -85,7 +85,7 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
     with pytest.raises(pa.IcpError) as e:
         pa.IcpEngine(0)
     assert e.value.status == _lib.ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
-    icp = pa.ICP(250, 0.005, 2.5, 8)
+    icp = pa.ICP(250, 0.005, 2.5, 8, mode="point_to_point")
     pts = np.zeros((10, 3), dtype=np.float32)
     with pytest.raises(pa.IcpError):
         icp.registerModelToScene(pts, pts, [pa.Pose3D()])

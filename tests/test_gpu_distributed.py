@@ -23,7 +23,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, native_loop=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -44,15 +44,24 @@ def _worker(rank, world, port, q):
             eng.set_targets(targets)
             eng.set_sources(slabs)
             params = pa.default_params(max_iterations=12, relative_mse_epsilon=2e-3)
-            res = pd.align_external_collective(pd.engine_pass(eng, [0, 1], [0, 1]), pd.torch_allreduce(),
-                                               np.stack([np.eye(4), np.eye(4)]), params)
+            if native_loop:
+                # the engine's OWN slab-sharded loop (mi355_icp_align with a communicator attached: rank-ordered
+                # exchange inside run_pass), over a host all-gather on gloo because two ranks share this GPU
+                pd.attach_external_comm(eng)
+                assert eng.comm_info() == (rank, world, 2)
+                res = eng.align(np.stack([np.eye(4), np.eye(4)]), params, source_ids=[0, 1], target_ids=[0, 1])
+                eng.comm_detach()
+            else:
+                res = pd.align_external_collective(pd.engine_pass(eng, [0, 1], [0, 1]), pd.torch_allreduce(),
+                                                   np.stack([np.eye(4), np.eye(4)]), params)
         q.put((rank, res.poses, res.residual, res.iterations, res.status, res.converged))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_slab_sharded_hip_passes_match_the_single_process_engine(engine):
+@pytest.mark.parametrize("native_loop", [False, True], ids=["python-loop", "engine-loop"])
+def test_two_rank_slab_sharded_hip_passes_match_the_single_process_engine(engine, native_loop):
     import torch.multiprocessing as mp
     import pose_estimation_amd as pa
     import synth_twin as st
@@ -60,7 +69,7 @@ def test_two_rank_slab_sharded_hip_passes_match_the_single_process_engine(engine
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, native_loop)) for r in range(2)]
     for p in procs:
         p.start()
     got = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])

@@ -90,8 +90,8 @@ def test_icp_mirror_with_pruned_scan(engine):
     import pose_estimation_amd as pa
     src, tgt, gt = st.make_pair(st.synth_cloud_np, 20000, 30000)
     poses_a, poses_b = [pa.Pose3D()], [pa.Pose3D()]
-    pa.ICP(40, 0.005, 2.5, 8, engine=engine).registerModelToScene(src, tgt, poses_a)
-    pa.ICP(40, 0.005, 2.5, 8, engine=engine, pruned_scan=True).registerModelToScene(src, tgt, poses_b)
+    pa.ICP(40, 0.005, 2.5, 8, engine=engine, mode="point_to_point").registerModelToScene(src, tgt, poses_a)
+    pa.ICP(40, 0.005, 2.5, 8, engine=engine, mode="point_to_point", pruned_scan=True).registerModelToScene(src, tgt, poses_b)
     assert np.array_equal(poses_a[0].pose, poses_b[0].pose) and poses_a[0].residual == poses_b[0].residual
 
 

@@ -10,20 +10,14 @@ import pytest
 
 import oracle_lib as ora
 import synth_twin as st
+from gpu_util import engine_with_mode, overflow_host_passes, overflow_points
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module", params=["fused", "xfilter", "xmfma", "xhybrid", "xbf16"])
 def fused(request):
-    import pose_estimation_amd as pa
-    old = os.environ.get("MI355_ICP_SCAN_MODE")
-    os.environ["MI355_ICP_SCAN_MODE"] = request.param
-    eng = pa.IcpEngine(0)
-    if old is None:
-        os.environ.pop("MI355_ICP_SCAN_MODE")
-    else:
-        os.environ["MI355_ICP_SCAN_MODE"] = old
+    eng = engine_with_mode(request.param)
     yield eng
     eng.close()
 
@@ -48,22 +42,34 @@ def test_fused_matches_oracle_ragged(fused, ns, nt):
 
 def test_near_ties_spread_over_many_chunks_take_the_exact_fallback(fused):
     """Targets on a sphere around the queries, radii jittered by a few float32 ulps: thousands of candidates inside the
-    filter's band, in hundreds of different chunks."""
+    filter's band, in hundreds of different chunks.  The counter asserted on is the engine's own
+    (mi355_icp_profile.overflow_points): points the resolve could not settle and the all-exact scan answered."""
     rng = np.random.default_rng(0)
     u = rng.standard_normal((20000, 3))
     u /= np.linalg.norm(u, axis=1, keepdims=True)
     tgt = (u * (1.0 + rng.integers(-3, 4, (20000, 1)) * 6e-8)).astype(np.float32)
     src = (rng.standard_normal((500, 3)) * 1e-4).astype(np.float32)       # all near the centre
-    before = fused_stats(fused)
+    before, host_before = overflow_points(fused), overflow_host_passes(fused)
     same_as_oracle(fused, src, tgt, np.eye(4), kd=False)
-    assert fused_stats(fused) > before                                     # the overflow path really ran
+    assert overflow_host_passes(fused) == host_before, "a small overflow list must be answered on the device"
+    assert 100 <= overflow_points(fused) - before <= 500, "the tie cloud did not reach the overflow path"   # device-side pass (<= kOverflowCap)
+    # more overflow points than the device-side pass takes per job (kOverflowCap = 1024): the pass is repeated through
+    # the host path (gather -> all-exact tiled scan -> scatter)
+    src = (rng.standard_normal((3000, 3)) * 1e-4).astype(np.float32)
+    before = overflow_points(fused)
+    same_as_oracle(fused, src, tgt, np.eye(4), kd=False)
+    assert overflow_points(fused) - before > 1024 and overflow_host_passes(fused) == host_before + 1, "the host overflow path did not run"
 
 
-def fused_stats(eng):
-    # every overflow pass re-scans with the exact kernel; the profile's pair counter does not see it, so probe
-    # behaviour through a side effect instead: last_error stays empty and results are exact; count passes here
-    fused_stats.calls = getattr(fused_stats, "calls", 0) + 1
-    return fused_stats.calls
+def test_benign_cloud_never_overflows(fused):
+    """Every query sits a hair away from one target and far (in units of that hair) from all others: the first granule
+    settles every point, so the overflow counter must not move."""
+    rng = np.random.default_rng(11)
+    tgt = rng.random((20000, 3)).astype(np.float32)
+    src = (tgt[rng.permutation(20000)[:4000]] + (rng.standard_normal((4000, 3)) * 1e-6).astype(np.float32)).astype(np.float32)
+    before = overflow_points(fused)
+    same_as_oracle(fused, src, tgt, np.eye(4), kd=False)
+    assert overflow_points(fused) == before
 
 
 def test_two_chunk_near_ties_and_exact_duplicates(fused):
@@ -133,27 +139,19 @@ def test_fused_align_golden_and_batched(fused):
         assert res.iterations[k] == o["iterations"] and np.linalg.norm(res.poses[k] - o["pose"]) <= 1e-5
 
 
-def test_fused_equals_exact_engine_at_1m(fused, engine):
-    """Above the planner's threshold both engines run different kernels; their answers must be identical bits."""
+def test_fused_equals_exact_engine_and_oracle_at_1m(fused):
+    """Above the planner's threshold the engines run different kernels; every one of the 2^20 (index, d2) answers must be
+    the oracle's (exact KD-tree over all 2^20 targets), and the all-exact HIP scan's, bit for bit."""
     import pose_estimation_amd as pa
     n = 1 << 20
     src, tgt, gt = st.make_pair(pa.synth_cloud, n, n)
-    old = os.environ.get("MI355_ICP_SCAN_MODE")
-    os.environ["MI355_ICP_SCAN_MODE"] = "exact"
-    try:
-        exact = pa.IcpEngine(0)
-    finally:
-        if old is None:
-            os.environ.pop("MI355_ICP_SCAN_MODE")
-        else:
-            os.environ["MI355_ICP_SCAN_MODE"] = old
-    try:
+    oi, od = ora.KdTree(tgt).query(ora.transform(np.eye(4), src), nthreads=ora.max_threads())
+    with engine_with_mode("exact") as exact:
         outs = []
         for eng in (fused, exact):
             eng.set_targets([tgt])
             eng.set_sources([src])
             outs.append(eng.correspond(np.eye(4)[None]))
-    finally:
-        exact.close()
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+    for idx, d2, sums in outs:
+        assert np.array_equal(idx, oi) and np.array_equal(d2.view(np.uint32), od.view(np.uint32))
     np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-12)

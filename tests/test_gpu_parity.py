@@ -10,6 +10,7 @@ import pytest
 
 import oracle_lib as ora
 import synth_twin as st
+from gpu_util import engine_with_mode
 
 pytestmark = pytest.mark.gpu
 
@@ -210,7 +211,7 @@ def test_icp_mirror_register_model_to_scene(engine):
     import pose_estimation_amd as pa
     from pose_estimation_amd.icp import refine_candidates
     model, scene, gt = st.make_pair(st.synth_cloud_np, 3000, 3500)
-    icp = pa.ICP(250, 0.005, 2.5, 8, engine=engine)
+    icp = pa.ICP(250, 0.005, 2.5, 8, engine=engine, mode="point_to_point")
     results = []
     for k, (ang, votes) in enumerate([(4.0, 300), (1.0, 900), (7.0, 500), (2.0, 450), (9.0, 100), (3.0, 420), (5.0, 50)]):
         p = pa.Pose3D(numVotes=votes)
@@ -238,16 +239,26 @@ def test_icp_mirror_register_model_to_scene(engine):
     assert np.array_equal(pose7, ora.pose_to_pose7(results[best].pose, True))
 
 
-def test_full_size_1m_properties(engine):
-    """BASELINE config 3 (1M <-> 1M) is too big for the oracle to scan in seconds, so check
-    size-independent properties: (a) d2 of every returned pair recomputes bit-exact on the host,
-    (b) on a 1500-point sample the oracle's brute-force scan of all 1M targets returns the same
-    (index, d2), (c) sums are additive over source slabs, (d) the pass is idempotent."""
+def test_full_size_1m_every_pair_against_the_oracle(engine):
+    """BASELINE config[2] (1M <-> 1M) at full size, under the default planner (the matrix-core filter at this size) and
+    under MI355_ICP_SCAN_MODE=exact (north_star's literal LDS-tiled kernel): ALL 2^20 (index, d2) answers equal the
+    oracle's exact KD-tree over all 2^20 targets bit for bit.  Plus size-independent properties: (a) d2 of every pair
+    recomputes bit-exact on the host, (c) sums are additive over source slabs, (d) the pass is idempotent."""
     import pose_estimation_amd as pa
     n = 1 << 20
     src, tgt, gt = st.make_pair(pa.synth_cloud, n, n)
-    engine.set_targets([tgt])
-    engine.set_sources([src])
+    tree = ora.KdTree(tgt)
+    for pose in (np.eye(4), gt):
+        moved = ora.transform(pose, src)
+        oi, od = tree.query(moved, nthreads=ora.max_threads())
+        with engine_with_mode("exact") as exact:
+            for eng in (engine, exact):
+                eng.set_targets([tgt])
+                eng.set_sources([src])
+                idx, d2, sums = eng.correspond(pose[None])
+                assert np.array_equal(idx, oi), "nearest-neighbour indices differ from the oracle"
+                assert np.array_equal(d2.view(np.uint32), od.view(np.uint32)), "float32 distances differ from the oracle"
+                np.testing.assert_allclose(sums[0], ora.accumulate(src, tgt, oi, od), rtol=1e-11, atol=1e-9)
     pose = np.eye(4)
     idx, d2, sums = engine.correspond(pose[None])
     moved = ora.transform(pose, src)
@@ -256,11 +267,6 @@ def test_full_size_1m_properties(engine):
     a = a + diff[:, 1] * diff[:, 1]
     a = a + diff[:, 2] * diff[:, 2]
     assert np.array_equal(a.view(np.uint32), d2.view(np.uint32))                      # (a)
-    sel = np.random.default_rng(3).choice(n, 1500, replace=False)
-    oi, od = ora.nn_brute(moved[sel], tgt, nthreads=ora.max_threads())
-    assert np.array_equal(oi, idx[sel]) and np.array_equal(od.view(np.uint32), d2[sel].view(np.uint32))  # (b)
-    osums = ora.accumulate(src, tgt, idx, d2)
-    np.testing.assert_allclose(sums[0], osums, rtol=1e-11, atol=1e-9)
     idx2, d22, sums2 = engine.correspond(pose[None])
     assert np.array_equal(idx, idx2) and np.array_equal(sums, sums2)                  # (d) bitwise reproducible
     b0, c0 = pa.slab_range(n, 0, 2)
@@ -268,6 +274,82 @@ def test_full_size_1m_properties(engine):
     engine.set_sources([src[b0:b0 + c0], src[b1:b1 + c1]])
     _, _, s2 = engine.correspond(np.stack([pose, pose]), source_ids=[0, 1], target_ids=[0, 0], want_pairs=False)
     np.testing.assert_allclose(s2[0] + s2[1], sums[0], rtol=1e-12, atol=1e-9)        # (c)
+
+
+def test_config3_batched_bin_picking_64_objects_at_full_size(engine):
+    """BASELINE config[3] at full size: 64 objects x (50k <-> 50k) in ONE batched call - every (index, d2) of the first
+    pass against the oracle's KD-tree, then a 20-iteration align of all 64 jobs, each against the oracle's ICP
+    (reference batch dimension: the <= 6 candidates of opencv_surface_match.cpp:89-94, here 64 models and scenes)."""
+    import pose_estimation_amd as pa
+    n, n_obj = 50_000, 64
+    pairs = [st.make_pair(pa.synth_cloud, n, n, object_index=k) for k in range(n_obj)]
+    engine.set_targets([p[1] for p in pairs])
+    engine.set_sources([p[0] for p in pairs])
+    ids = list(range(n_obj))
+    eye = np.stack([np.eye(4)] * n_obj)
+    idx, d2, sums = engine.correspond(eye, source_ids=ids, target_ids=ids)
+    nth = ora.max_threads()
+    for k in range(n_obj):
+        oi, od, os_ = ora.correspond(np.eye(4), pairs[k][0], pairs[k][1], nthreads=nth)
+        assert np.array_equal(idx[k * n:(k + 1) * n], oi), f"object {k}: indices"
+        assert np.array_equal(d2[k * n:(k + 1) * n].view(np.uint32), od.view(np.uint32)), f"object {k}: distances"
+        np.testing.assert_allclose(sums[k], os_, rtol=1e-11, atol=1e-10)
+    params = pa.default_params(max_iterations=20)
+    res = engine.align(eye, params, source_ids=ids, target_ids=ids)
+    worst = 0.0
+    for k in range(n_obj):
+        o = ora.icp(pairs[k][0], pairs[k][1], np.eye(4), ora.params_from(params), nthreads=nth)
+        assert res.status[k] == 0 and res.iterations[k] == o["iterations"] == 20, k
+        worst = max(worst, float(np.linalg.norm(res.poses[k] - o["pose"])))
+        assert abs(res.residual[k] - o["residual"]) <= 1e-9, k
+    assert worst <= POSE_TOL, worst
+
+
+def test_config4_8m_vs_1m_eight_slabs_on_one_gpu(engine):
+    """BASELINE config[4] (8M <-> 1M, source slab-sharded over 8 GPUs) rendered on ONE GPU: the 8 slabs of
+    mi355_icp_slab_range(8 * 2^20, r, 8) are 8 jobs against the one replicated 2^20-point target; every one of the 8M
+    (index, d2) answers equals the oracle's KD-tree, the 8 x 17 sums added IN RANK ORDER (what the engine's fixed-order
+    cross-rank reduction computes, csrc/icp_engine.hip) equal the oracle's accumulation over all 8M pairs, and a
+    5-iteration ICP driven by those rank-ordered sums lands on the oracle's 8M-point ICP."""
+    import pose_estimation_amd as pa
+    from pose_estimation_amd import distributed as pd
+    n, world = 1 << 20, 8
+    T = st.perturbation(-1)
+    tgt = pa.synth_cloud(st.TARGET_SEED, n)
+    slabs = []
+    for r in range(world):
+        b, c = pa.slab_range(world * n, r, world)
+        assert (b, c) == (r * n, n)
+        slabs.append(pa.synth_cloud(st.SOURCE_SEED, c, first_index=b, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T))
+    src = np.concatenate(slabs)
+    engine.set_targets([tgt])
+    engine.set_sources(slabs)
+    ids, zeros = list(range(world)), [0] * world
+    idx, d2, sums = engine.correspond(np.stack([np.eye(4)] * world), source_ids=ids, target_ids=zeros)
+    nth = ora.max_threads()
+    oi, od = ora.KdTree(tgt).query(ora.transform(np.eye(4), src), nthreads=nth)
+    assert np.array_equal(idx, oi) and np.array_equal(d2.view(np.uint32), od.view(np.uint32))
+    total = np.zeros(17)
+    for r in range(world):
+        total = total + sums[r]                                  # rank order
+    osum = ora.accumulate(src, tgt, oi, od)
+    assert total[0] == osum[0] == world * n
+    np.testing.assert_allclose(total, osum, rtol=1e-12, atol=0)
+
+    def rank_ordered_pass(poses, job_ids):
+        assert list(job_ids) == [0]
+        _, _, s = engine.correspond(np.repeat(poses, world, axis=0), source_ids=ids, target_ids=zeros, want_pairs=False)
+        out = np.zeros(17)
+        for r in range(world):
+            out = out + s[r]
+        return out[None]
+
+    params = pa.default_params(max_iterations=5)
+    res = pd.align_external_collective(rank_ordered_pass, lambda a: a, np.eye(4)[None], params)
+    o = ora.icp(src, tgt, np.eye(4), ora.params_from(params), nthreads=nth)
+    assert res.status[0] == 0 and res.iterations[0] == o["iterations"] == 5
+    assert np.linalg.norm(res.poses[0] - o["pose"]) <= POSE_TOL
+    assert abs(res.residual[0] - o["residual"]) <= 1e-9
 
 
 def test_cpp_host_mirror_harness_matches_python_engine(engine):
@@ -292,7 +374,7 @@ def test_cpp_host_mirror_harness_matches_python_engine(engine):
         elif f[0] == "pose7":
             pose7 = np.array([float(v) for v in f[1:]], dtype=np.float32)
     model, scene, gt = st.make_pair(pa.synth_cloud, 2500, 3000)
-    icp = pa.ICP(250, 0.005, 2.5, 8, engine=engine)
+    icp = pa.ICP(250, 0.005, 2.5, 8, engine=engine, mode="point_to_point")
     votes = [300, 900, 500, 450, 100, 420, 50, 10]
     cands = []
     for k in range(7):
@@ -310,6 +392,58 @@ def test_cpp_host_mirror_harness_matches_python_engine(engine):
     np.testing.assert_allclose(pose7, pa.pose_to_pose7(poses[best], True), atol=1e-6)
 
 
+def test_rank_ordered_sums_for_1_2_4_8_slabs(engine):
+    """the cross-rank reduction adds the per-rank rows in rank order, so one workload cut into 1, 2, 4 or 8
+    slabs gives sums within 1e-12 relative of each other (only the association order inside a slab differs) and the
+    same bits run to run.  Rendered on one GPU: slab r is job r, rows added 0, 1, 2, ... like comm.hip does."""
+    import pose_estimation_amd as pa
+    ns, nt = 300_007, 120_000
+    src, tgt, gt = st.make_pair(pa.synth_cloud, ns, nt)
+    engine.set_targets([tgt])
+    totals = {}
+    for world in (1, 2, 4, 8):
+        slabs = [src[b:b + c] for b, c in (pa.slab_range(ns, r, world) for r in range(world))]
+        engine.set_sources(slabs)
+        runs = []
+        for _ in range(2):
+            _, _, s = engine.correspond(np.stack([gt] * world), source_ids=list(range(world)), target_ids=[0] * world, want_pairs=False)
+            tot = np.zeros(17)
+            for r in range(world):
+                tot = tot + s[r]
+            runs.append(tot)
+        assert np.array_equal(runs[0], runs[1]), f"{world} slabs: sums differ run to run"
+        totals[world] = runs[0]
+    for world in (2, 4, 8):
+        assert totals[world][0] == totals[1][0] == ns
+        np.testing.assert_allclose(totals[world], totals[1], rtol=1e-12, atol=0)
+
+
+def test_external_transport_single_rank_goes_through_the_exchange(engine):
+    """mi355_icp_comm_attach_external with one rank: the engine's exchange path (stage to host, caller's all-gather,
+    rank-ordered sum, back) must leave the results bit-identical to the run without a communicator."""
+    import pose_estimation_amd as pa
+    src, tgt, gt = st.make_pair(st.synth_cloud_np, 4000, 3000)
+    engine.set_targets([tgt])
+    engine.set_sources([src])
+    p = pa.default_params(max_iterations=6)
+    ref = engine.align(np.eye(4)[None], p)
+    calls = []
+
+    def allgather(send):
+        calls.append(len(send))
+        return bytes(send)
+
+    engine.comm_attach_external(0, 1, allgather)
+    try:
+        assert engine.comm_info() == (0, 1, 2)
+        got = engine.align(np.eye(4)[None], p)
+    finally:
+        engine.comm_detach()
+    assert engine.comm_info()[2] == 0
+    assert np.array_equal(got.poses, ref.poses) and np.array_equal(got.residual, ref.residual)
+    assert calls == [8 * 18] * 6      # per iteration: 17 sums + the overflow-excess flag of the one job
+
+
 def test_rccl_single_rank_communicator(engine):
     """N5 plumbing on one GPU: dlopen RCCL, unique id, ncclCommInitRank(size 1), one ncclAllReduce per
     iteration inside mi355_icp_align; results must equal the run without a communicator bit for bit."""
@@ -323,6 +457,7 @@ def test_rccl_single_rank_communicator(engine):
     assert len(uid) == 128
     engine.comm_attach(uid, 0, 1)
     try:
+        assert engine.comm_info() == (0, 1, 1)      # rank and size as ncclCommUserRank / ncclCommCount report them
         got = engine.align(np.eye(4)[None], p)
         with pytest.raises(pa.IcpError):
             engine.comm_attach(uid, 0, 1)   # already attached
