@@ -76,6 +76,7 @@ struct Plan {
   bool xfilter = false;        // expansion-filter scan on the sorted/centred target copy (largest launches); implies fused
   int xkind = 0;               // 0 VALU kernel, 1 f32 MFMA kernel, 2 both side by side, 3 split-bf16 MFMA kernel
   bool pruned = false;         // OPTIONAL exact pruned scan (MI355_ICP_SCAN_MODE=pruned), never chosen by the planner
+  bool sorted_src = false;     // the matrix-core scan and its resolve walk the SOURCE cloud in Morton order too (below)
   uint32_t key_rows() const { return (xkind == 3 ? 2u : 1u) * max_split; }  // key rows per rank (wave halves publish separately)
   uint32_t key_ranks() const { return xfilter && xkind != 3 ? 4u : 3u; }       // the VALU expansion kernels also publish U
 };
@@ -184,6 +185,7 @@ struct mi355_icp_ctx {
   bool call_pruned = false;          // this call asked for the pruned scan (MI355_ICP_FLAG_PRUNED_SCAN)
   int xbf16_shape = 0;               // 0: <4 sets, 256 threads> workgroups, 1: <2 sets, 512 threads> (MI355_ICP_XBF16_SHAPE)
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
+  bool sort_sources = true;          // matrix-core scan: walk the sources in Morton order (MI355_ICP_SORT_SOURCES=0 turns it off: A/B)
 };
 
 namespace {
@@ -380,6 +382,13 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   if (plan.xfilter) plan.scan_ppl = c->scan_ppl ? c->scan_ppl : 4;
   if (plan.xfilter && plan.xkind && plan.scan_ppl != 2) plan.scan_ppl = 4;  // the MFMA kernel spans 128 * {4, 8} points
   if (plan.xfilter && plan.xkind == 3) plan.scan_ppl = 2;                     // split-bf16 kernel: 512 points per workgroup
+  // The matrix-core scan keeps, per lane, the three best granules of its point and takes a wave-uniform branch whenever
+  // ANY of the wave's 32 points improves one.  In upload order those 32 points are anywhere on the model, each improving
+  // at its own places of the (Morton-ordered) target walk: the branch is taken in most chunks.  Walking the sources in
+  // Morton order as well puts neighbours into one wave - they improve in the same few chunks: 31.6 -> 28.8 ms at 1M<->1M
+  // (profiles/r02c_sorted_source_what_if.txt).  Same pairs, same arithmetic, same results; only which lane holds which
+  // point changes, and the resolve writes each answer back at the point's original index.
+  plan.sorted_src = plan.xfilter && plan.xkind == 3 && c->sort_sources;
   const uint32_t scan_src = static_cast<uint32_t>(kBlockThreads * plan.scan_ppl);
   uint64_t total_src_blocks = 0;
   for (int k = 0; k < n_jobs; ++k)
@@ -601,12 +610,23 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
   const bool xf = plan.xfilter && Xp && Xp->valid;
   const XCopy none;
   const XCopy& X = xf ? *Xp : none;
+  // matrix-core scan: the Morton-ordered copy of these source planes (the scan and the resolve agree on positions; the
+  // resolve writes results - and lists overflow points - at original indices, so everything downstream is unchanged)
+  DevicePlanes Sscan = S;
+  const uint32_t* src_perm = nullptr;
+  if (xf && plan.sorted_src) {
+    size_t sstride = 0;
+    const XCopy* xs = find_xcopy(c->sources, S.x, &sstride);
+    if (!xs || !xs->valid) return fail(c, MI355_ICP_ERR_INTERNAL, "matrix-core scan: sorted copy of the sources missing");
+    Sscan = DevicePlanes{xs->planes + 4 * sstride, xs->planes + 5 * sstride, xs->planes + 6 * sstride};
+    src_perm = xs->perm;
+  }
   if (xf) {
     const float* xp = X.planes;
     const size_t st = xstride;
     const int ppl = plan.scan_ppl == 2 ? 2 : 4;  // the MFMA kernel spans 128 * {4, 8} points per workgroup
     if (bx && plan.xkind == 3) {
-      launch_nn_scan_xbf16(c->stream, c->jobs_dev, n_active, bx, S, X.bf, X.table, c->keys3, plan.out_total, rank_stride, c->xbf16_shape);
+      launch_nn_scan_xbf16(c->stream, c->jobs_dev, n_active, bx, Sscan, X.bf, X.table, c->keys3, plan.out_total, rank_stride, c->xbf16_shape);
     } else if (bx && plan.xkind == 0) {
       launch_nn_scan_xfilter(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, xp, xp + st, xp + 2 * st, xp + 3 * st,
                              X.table, c->keys3, plan.out_total, rank_stride);
@@ -640,7 +660,8 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
     const float* xp = X.planes;
     const size_t st = xstride;
     const bool xb = plan.xkind == 3;
-    launch_resolve_xfilter(c->stream, xb ? kXbRun : kFusedChunk, xb ? 2u : 1u, c->jobs_dev, n_active, sbx, S, DevicePlanes{xp + 4 * st, xp + 5 * st, xp + 6 * st}, X.perm,
+    launch_resolve_xfilter(c->stream, xb ? kXbRun : kFusedChunk, xb ? 2u : 1u, c->jobs_dev, n_active, sbx, xb ? Sscan : S, xb ? src_perm : nullptr,
+                           DevicePlanes{xp + 4 * st, xp + 5 * st, xp + 6 * st}, X.perm,
                            c->keys3, plan.out_total, rank_stride, c->out_index, c->out_dist2, c->overflow_list, c->overflow_count,
                            c->error_flag);
   } else if (sbx) {
@@ -995,6 +1016,10 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   c->target_blocks = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks);
   c->target_blocks_mfma = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks_mfma);  // the same override serves A/B runs of either
   c->min_tiles_per_split = env_u32("MI355_ICP_MIN_TILES_PER_SPLIT", c->min_tiles_per_split);
+  {
+    const char* ss = std::getenv("MI355_ICP_SORT_SOURCES");
+    if (ss && std::string(ss) == "0") c->sort_sources = false;
+  }
   auto bail = [&](const char* what, hipError_t err) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(err);
     mi355_icp_destroy(c);
@@ -1109,7 +1134,7 @@ int mi355_icp_align(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const i
   if (st != MI355_ICP_OK) return st;
   if ((st = ensure_buffers(c, plan, static_cast<size_t>(n_jobs))) != MI355_ICP_OK) return st;
   if ((plan.xfilter || plan.pruned) && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;
-  if (plan.pruned && (st = ensure_xtarget(c, c->sources)) != MI355_ICP_OK) return st;
+  if ((plan.pruned || plan.sorted_src) && (st = ensure_xtarget(c, c->sources)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
 
   struct JobState { double pose[16]; double prev_mse = 0.0; double residual = 0.0; int iters = 0; int status = MI355_ICP_OK; int converged = 0; };
@@ -1169,7 +1194,7 @@ int mi355_icp_correspond(mi355_icp_ctx* c, int n_jobs, const int* source_ids, co
   if (st != MI355_ICP_OK) return st;
   if ((st = ensure_buffers(c, plan, static_cast<size_t>(n_jobs))) != MI355_ICP_OK) return st;
   if ((plan.xfilter || plan.pruned) && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;
-  if (plan.pruned && (st = ensure_xtarget(c, c->sources)) != MI355_ICP_OK) return st;
+  if ((plan.pruned || plan.sorted_src) && (st = ensure_xtarget(c, c->sources)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
   for (int k = 0; k < n_jobs; ++k) {
     JobDesc J = plan.jobs[static_cast<size_t>(k)];
@@ -1242,7 +1267,7 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
     }
     if ((st = ensure_ref_buffers(c, plan, static_cast<size_t>(np), owner_total)) != MI355_ICP_OK) return st;
     if ((plan.xfilter || plan.pruned) && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
-    if (plan.pruned && (st = ensure_level_xcopy(c, c->sources, level)) != MI355_ICP_OK) return st;
+    if ((plan.pruned || plan.sorted_src) && (st = ensure_level_xcopy(c, c->sources, level)) != MI355_ICP_OK) return st;
 
     const double tolp = static_cast<double>(rp->tolerance) * static_cast<double>(level + 1) * static_cast<double>(level + 1);
     const int maxit = static_cast<int>(std::floor(static_cast<double>(rp->iterations) / static_cast<double>(level + 1) + 0.5));
@@ -1332,7 +1357,7 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
   const size_t owner_total = level_clouds(c->targets, level)[target_id].padded;
   if ((st = ensure_ref_buffers(c, plan, 1, owner_total)) != MI355_ICP_OK) return st;
   if ((plan.xfilter || plan.pruned) && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
-  if (plan.pruned && (st = ensure_level_xcopy(c, c->sources, level)) != MI355_ICP_OK) return st;
+  if ((plan.pruned || plan.sorted_src) && (st = ensure_level_xcopy(c, c->sources, level)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
   JobDesc J = plan.jobs[0];
   RefJobDesc R{};

@@ -575,6 +575,12 @@ __device__ __forceinline__ uint32_t min16(const f32x16& acc, uint32_t seed) {
 
 // kSets: 32-source column sets per wave; kThreads: workgroup size.  A workgroup covers kThreads / 2 * kSets source points:
 // <4, 256> (4 waves, 2 workgroups per CU = 2 waves per SIMD at <= 256 registers) or <2, 512> (4 waves per SIMD at <= 128).
+// The next tile travels global -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave-instruction, no registers, no
+// ds_write).  Round 1 staged it through a register array, which hipcc - out of registers at 224 - promoted to LDS
+// ("promote alloca"): every chunk paid global_load -> s_waitcnt vmcnt -> ds_write to a scratch slot -> ds_read ->
+// ds_write to the tile, 8 LDS instructions next to the 8 fragment reads that do the work, at a 32-byte lane stride that
+// conflicts two ways (SQ_LDS_BANK_CONFLICT = 73 % of SQ_ACTIVE_INST_LDS in profiles/r01o_pmc_summary.txt; 33.6 -> 32.0 ms
+// at 1M<->1M without it: profiles/r02b_scan_ab_lds_dma.txt).
 template <int kSets, int kThreads>
 __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDesc* __restrict__ jobs,
                                                                        const float* __restrict__ sx,
@@ -584,14 +590,16 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
                                                                        const float4* __restrict__ tile_table,
                                                                        unsigned long long* __restrict__ keys4,
                                                                        uint32_t key_stride, uint32_t rank_stride) {
-  __shared__ uint4 lds[2][kXbTileVecs];  // [buffer][k half][row slot]: 2 x 32 KiB
+  // [buffer][k half][row slot]: 2 x 32 KiB, + 96 slots the fragment prefetch of a tile's last two steps runs into
+  // (blocks 32-34 do not exist: whatever is read there feeds MFMAs whose results are dropped)
+  constexpr uint32_t kLdsPad = 96;
+  __shared__ uint4 lds[2 * kXbTileVecs + kLdsPad];
   const JobDesc& J = jobs[blockIdx.y];
   const uint32_t n_split = J.n_split;
   const uint32_t sb = blockIdx.x / n_split;
   const uint32_t sp = blockIdx.x - sb * n_split;
   if (sb >= J.scan_blocks) return;
   constexpr uint32_t kScanSrcPerBlock = (kThreads / 64) * 32 * kSets;
-  constexpr int kPf = 2 * kBlockThreads / kThreads;  // uint4 per thread and chunk of the next tile (a quarter of it: 512)
   const uint32_t tile0 = sp * J.split_q + (sp < J.split_r ? sp : J.split_r);
   const uint32_t tile1 = tile0 + J.split_q + (sp < J.split_r ? 1u : 0u);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -599,55 +607,59 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
   float pose[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
-  float qx[kSets], qy[kSets], qz[kSets];
+  float q2x[kSets], q2y[kSets], q2z[kSets];  // -2 q (exact scaling): -2 fl(q - c) = fl(-2q + 2c) bit for bit
   float l1[kSets], l2[kSets], l3[kSets];
   uint32_t c1[kSets], c2[kSets], c3[kSets];
-  bool unsafe = false;
+  bool unsafe[kSets];  // per point: its bound is not finite somewhere along the walk -> everything is a candidate for it
   const uint32_t src_local = (wave * kSets) * 32 + (lane & 31u);
 #pragma unroll
   for (int m = 0; m < kSets; ++m) {
     const uint32_t i = J.src_off + sb * kScanSrcPerBlock + src_local + m * 32;  // padded planes: always in bounds
-    transform_point(pose, sx[i], sy[i], sz[i], qx[m], qy[m], qz[m]);
+    float qx, qy, qz;
+    transform_point(pose, sx[i], sy[i], sz[i], qx, qy, qz);
+    q2x[m] = -2.0f * qx;
+    q2y[m] = -2.0f * qy;
+    q2z[m] = -2.0f * qz;
     l1[m] = l2[m] = l3[m] = __builtin_inff();
     c1[m] = c2[m] = c3[m] = tile0 * (2 * kXbChunksPerTile);
+    unsafe[m] = false;
   }
   const uint32_t tile_base = J.tgt_off / kTile;  // tgt_off is a multiple of kTile
   const uint4* __restrict__ image = bf_image + static_cast<size_t>(tile_base) * kXbTileVecs;
 #pragma unroll
   for (int k = 0; k < kXbTileVecs / kThreads; ++k)
-    lds[0][k * kThreads + tid] = image[static_cast<size_t>(tile0) * kXbTileVecs + k * kThreads + tid];
+    lds[k * kThreads + tid] = image[static_cast<size_t>(tile0) * kXbTileVecs + k * kThreads + tid];
   __syncthreads();
   uint32_t cur = 0;
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t tile = tile0; tile < tile1; ++tile) {
     const bool more = tile + 1 < tile1;
     const float4 tc = tile_table[tile_base + tile];  // centre xyz, r^2 (wave-uniform)
+    const float c2x = 2.0f * tc.x, c2y = 2.0f * tc.y, c2z = 2.0f * tc.z;
     uint4 bq[kSets];
     float adj[kSets], ee[kSets];
 #pragma unroll
     for (int m = 0; m < kSets; ++m) {
       uint32_t px, py, pz;
       float vx, vy, vz;
-      split_bf16(-2.0f * (qx[m] - tc.x), px, vx);
-      split_bf16(-2.0f * (qy[m] - tc.y), py, vy);
-      split_bf16(-2.0f * (qz[m] - tc.z), pz, vz);
-      const float cx = -0.5f * vx, cy = -0.5f * vy, cz = -0.5f * vz;  // the quantised qc'
-      const float qq = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, cx * cx));
+      split_bf16(q2x[m] + c2x, px, vx);  // q' = -2 fl(q - c) in two bf16 pieces; v = their sum
+      split_bf16(q2y[m] + c2y, py, vy);
+      split_bf16(q2z[m] + c2z, pz, vz);
+      const float qq = 0.25f * __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));  // |qc'|^2 of the quantised point (x 1/4: exact)
       ee[m] = __builtin_fmaf(7.62939453125e-06f, qq + tc.w, 7.5231638e-37f);  // 2^-17 (|qc'|^2 + r^2) + 2^-120
-      unsafe = unsafe || !(ee[m] < 1.0e37f);                                    // inf / NaN bound: exact scan instead
+      unsafe[m] = unsafe[m] || !(ee[m] < 1.0e37f);                              // inf / NaN bound: exact scan instead
       const uint32_t bias = (__float_as_uint(__builtin_fmaf(2.0f, ee[m], qq)) + 0xFFFFu) >> 16;  // bf16, rounded up
       adj[m] = qq - bf16_value(bias);  // s = MFMA + adj
       const uint32_t w0 = hi ? pz : px;
       bq[m] = make_uint4(w0, w0, hi ? 0x3F803F80u : py, hi ? (0x00003F80u | (bias << 16)) : py);
     }
-    const uint4* __restrict__ A = lds[cur] + (hi ? kTile : 0) + (lane & 31u);
-    const uint4* __restrict__ next = image + static_cast<size_t>(tile + 1) * kXbTileVecs;
+    const uint4* __restrict__ A = lds + cur * kXbTileVecs + (hi ? kTile : 0) + (lane & 31u);
     // Two accumulator sets in flight over the tile's 32 MFMA blocks, one MFMA then the 8 integer minima of an EARLIER
     // result, alternating in program order: a wave's next MFMA waits at the vector issue port until the matrix pipe
     // is free (32 cycles), and anything behind it - including the other resident wave's VALU work - waits with it, so
-    // MFMAs issued back to back serialise the two pipes (measured: 38 ms per 2^40 pairs that way, the figure in
-    // DESIGN.md with this schedule).  The loop is kept rolled (unrolled, hipcc hoists every MFMA of a chunk ahead of
-    // the minima and spills their 512 results) and the order is pinned with sched_group_barrier.
+    // MFMAs issued back to back serialise the two pipes.  The loop is kept rolled at one 256-target chunk per
+    // iteration (unrolled further, hipcc hoists every MFMA of a tile ahead of the minima and spills their results)
+    // and the order is pinned as data flow (MI355_PIN).
     f32x16 acc_a[kSets], acc_b[kSets];
     {
       const uint4 a = A[0];
@@ -658,20 +670,25 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
     uint32_t cmin[kSets];
 #pragma unroll
     for (int m = 0; m < kSets; ++m) cmin[m] = 0x7F800000u;
-    uint4 pf[kPf];
-    if (more) {  // a quarter of the next tile rides along with each chunk
+    // the whole next tile, asynchronously: the barrier that ended the previous tile says every wave is done reading the
+    // other buffer; the __syncthreads() at the end of this tile waits for these (vmcnt(0)) before anyone reads it
+    if (more) {
+      const uint4* __restrict__ next = image + static_cast<size_t>(tile + 1) * kXbTileVecs;
 #pragma unroll
-      for (int k = 0; k < kPf; ++k) pf[k] = next[k * kThreads + tid];
+      for (int k = 0; k < kXbTileVecs / kThreads; ++k)
+        __builtin_amdgcn_global_load_lds(next + k * kThreads + tid, &lds[(cur ^ 1) * kXbTileVecs + k * kThreads + wave * 64], 16, 0, 0);
     }
-    // operands of the NEXT step's MFMAs are read one step ahead, into two register sets used alternately (no copies)
+    // operands of the NEXT step's MFMAs are read one step ahead, into two register sets used alternately (no copies);
+    // Ap walks the tile two blocks per step, so the four reads of an iteration sit at immediate offsets from it
     u32x4 f0_b = load_frag(A + 32), f0_a = load_frag(A + 64), f1_b, f1_a;
+    const uint4* __restrict__ Ap = A;
     // MI355_PIN: an empty asm that "rewrites" the next MFMA's operand, the accumulator the next minima read and the
     // previous minimum - so step m (one MFMA + 8 minima) can start only when step m - 1's minima are done, which is
     // the alternation the comment above asks for, expressed as data flow the scheduler cannot undo.
-    auto step = [&](uint32_t pair, u32x4& use_b, u32x4& use_a, u32x4& next_b, u32x4& next_a) {
-      // blocks past the tile's last one do not exist: earlier blocks are read again and their results dropped
-      next_b = load_frag(A + ((2 * pair + 3) & (kTile / 32 - 1)) * 32);
-      next_a = load_frag(A + ((2 * pair + 4) & (kTile / 32 - 1)) * 32);
+    auto step = [&](u32x4& use_b, u32x4& use_a, u32x4& next_b, u32x4& next_a) {
+      next_b = load_frag(Ap + 96);   // blocks 2p + 3 and 2p + 4 of step p (past the tile's end on its last two steps: see kLdsPad)
+      next_a = load_frag(Ap + 128);
+      Ap += 64;
 #pragma unroll
       for (int m = 0; m < kSets; ++m) {
         MI355_PIN(use_b, acc_a[m], cmin[(m + kSets - 1) % kSets]);
@@ -686,40 +703,31 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
       }
     };
 #pragma unroll 1
-    for (uint32_t pair = 0; pair < kTile / 64; pair += 2) {
-      step(pair, f0_b, f0_a, f1_b, f1_a);
-      step(pair + 1, f1_b, f1_a, f0_b, f0_a);
-      if ((pair & 2u) != 0) {  // a 256-target chunk = 4 pairs of blocks
-        const uint32_t c = pair >> 2;
-        const uint32_t run = ((tile * kXbChunksPerTile + c) << 1) | (hi ? 1u : 0u);
+    for (uint32_t c = 0; c < kXbChunksPerTile; ++c) {  // a 256-target chunk = 8 blocks = 4 steps
+      step(f0_b, f0_a, f1_b, f1_a);
+      step(f1_b, f1_a, f0_b, f0_a);
+      step(f0_b, f0_a, f1_b, f1_a);
+      step(f1_b, f1_a, f0_b, f0_a);
+      const uint32_t run = ((tile * kXbChunksPerTile + c) << 1) | (hi ? 1u : 0u);
 #pragma unroll
-        for (int m = 0; m < kSets; ++m) {
-          const float s = __uint_as_float(cmin[m]) + adj[m];
-          const float lo = __builtin_fmaxf((s - ee[m]) * 0.99902f, 0.0f);
-          cmin[m] = 0x7F800000u;
-          // once the scan has passed a point's neighbourhood its three best granules rarely change: the sorted insert
-          // (12 selects) is skipped unless some lane of the wave needs it
-          if (__builtin_amdgcn_ballot_w64(lo < l3[m]) != 0) {
-            const float o1 = l1[m], o2 = l2[m], o3 = l3[m];
-            const uint32_t i1 = c1[m], i2 = c2[m], i3 = c3[m];
-            const bool d1 = lo < o1, d2 = lo < o2, d3 = lo < o3;
-            const float keep3 = d3 ? lo : o3, keep2 = d2 ? lo : o2;
-            const uint32_t keepi3 = d3 ? run : i3, keepi2 = d2 ? run : i2;
-            l3[m] = d2 ? o2 : keep3;
-            c3[m] = d2 ? i2 : keepi3;
-            l2[m] = d1 ? o1 : keep2;
-            c2[m] = d1 ? i1 : keepi2;
-            l1[m] = d1 ? lo : o1;
-            c1[m] = d1 ? run : i1;
-          }
-        }
-        if (more) {
-#pragma unroll
-          for (int k = 0; k < kPf; ++k) lds[cur ^ 1][(c * kPf + k) * kThreads + tid] = pf[k];
-          if (c + 1 < kXbChunksPerTile) {
-#pragma unroll
-            for (int k = 0; k < kPf; ++k) pf[k] = next[((c + 1) * kPf + k) * kThreads + tid];
-          }
+      for (int m = 0; m < kSets; ++m) {
+        const float s = __uint_as_float(cmin[m]) + adj[m];
+        const float lo = __builtin_fmaxf((s - ee[m]) * 0.99902f, 0.0f);
+        cmin[m] = 0x7F800000u;
+        // once the scan has passed a point's neighbourhood its three best granules rarely change: the sorted insert
+        // (12 selects) is skipped unless some lane of the wave needs it (rarely, with the sources in Morton order too)
+        if (__builtin_amdgcn_ballot_w64(lo < l3[m]) != 0) {
+          const float o1 = l1[m], o2 = l2[m], o3 = l3[m];
+          const uint32_t i1 = c1[m], i2 = c2[m], i3 = c3[m];
+          const bool d1 = lo < o1, d2 = lo < o2, d3 = lo < o3;
+          const float keep3 = d3 ? lo : o3, keep2 = d2 ? lo : o2;
+          const uint32_t keepi3 = d3 ? run : i3, keepi2 = d2 ? run : i2;
+          l3[m] = d2 ? o2 : keep3;
+          c3[m] = d2 ? i2 : keepi3;
+          l2[m] = d1 ? o1 : keep2;
+          c2[m] = d1 ? i1 : keepi2;
+          l1[m] = d1 ? lo : o1;
+          c1[m] = d1 ? run : i1;
         }
       }
     }
@@ -731,14 +739,15 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
 #pragma unroll
   for (int m = 0; m < kSets; ++m) {
     const size_t o = out + m * 32;
-    const float w1 = unsafe ? 0.0f : l1[m], w2 = unsafe ? 0.0f : l2[m], w3 = unsafe ? 0.0f : l3[m];
+    const float w1 = unsafe[m] ? 0.0f : l1[m], w2 = unsafe[m] ? 0.0f : l2[m], w3 = unsafe[m] ? 0.0f : l3[m];
     keys4[o] = (static_cast<unsigned long long>(__float_as_uint(w1)) << 32) | c1[m];
     keys4[rank_stride + o] = (static_cast<unsigned long long>(__float_as_uint(w2)) << 32) | c2[m];
     keys4[2 * static_cast<size_t>(rank_stride) + o] = (static_cast<unsigned long long>(__float_as_uint(w3)) << 32) | c3[m];
   }
 }
 
-// a workgroup spans 512 source points either way (the planner's 2 points per lane); shape 1 = <2 sets, 512 threads>
+// a workgroup spans 512 source points either way (the planner's 2 points per lane); shape 0 = <4 sets, 256 threads> (default),
+// 1 = <2 sets, 512 threads> (1.4 % slower: profiles/r02b_scan_ab_lds_dma.txt)
 void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
                           const void* bf_image, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
                           uint32_t rank_stride, int shape) {

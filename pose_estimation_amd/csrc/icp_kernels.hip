@@ -523,7 +523,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 template <int kRun>  // targets per remembered granule: kFusedChunk (VALU filter) or kXbRun (matrix-core filter)
 __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
     const JobDesc* __restrict__ jobs, uint32_t split_mul, const float* __restrict__ sx, const float* __restrict__ sy,
-    const float* __restrict__ sz, const float* __restrict__ sox, const float* __restrict__ soy,
+    const float* __restrict__ sz, const uint32_t* __restrict__ src_perm, const float* __restrict__ sox, const float* __restrict__ soy,
     const float* __restrict__ soz, const uint32_t* __restrict__ perm, const unsigned long long* __restrict__ keys4,
     uint32_t key_stride, uint32_t rank_stride, int32_t* __restrict__ out_index, float* __restrict__ out_dist2,
     uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ overflow_count) {
@@ -630,15 +630,17 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
       }
     }
     if (!valid) return;
+    // `local` is a position in the (possibly Morton-ordered) source planes the scan walked; answers go to the point's own slot
+    const uint32_t orig = src_perm ? src_perm[J.src_off + local] : local;
     if (L3 <= __uint_as_float(res_d) || res_j == 0xFFFFFFFFu) {  // a third candidate granule (or more), or nothing finite found
       const uint32_t pos = atomicAdd(&overflow_count[blockIdx.y], 1u);
-      overflow_list[J.out_off + pos] = local;
-      out_index[J.out_off + local] = 0;  // valid placeholder, see resolve_fused_kernel
-      out_dist2[J.out_off + local] = __builtin_inff();
+      overflow_list[J.out_off + pos] = orig;
+      out_index[J.out_off + orig] = 0;  // valid placeholder, see resolve_fused_kernel
+      out_dist2[J.out_off + orig] = __builtin_inff();
       return;
     }
-    out_index[J.out_off + local] = static_cast<int32_t>(res_j);
-    out_dist2[J.out_off + local] = __uint_as_float(res_d);
+    out_index[J.out_off + orig] = static_cast<int32_t>(res_j);
+    out_dist2[J.out_off + orig] = __uint_as_float(res_d);
   }
 }
 
@@ -1110,18 +1112,18 @@ void launch_resolve_fused(void* stream, const JobDesc* jobs_dev, int n_jobs, uin
 }
 
 void launch_resolve_xfilter(void* stream, int run_len, uint32_t split_mul, const JobDesc* jobs_dev, int n_jobs,
-                            uint32_t max_src_blocks, DevicePlanes src, DevicePlanes sorted_original, const uint32_t* perm,
+                            uint32_t max_src_blocks, DevicePlanes src, const uint32_t* src_perm, DevicePlanes sorted_original, const uint32_t* perm,
                             const unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride, int32_t* out_index,
                             float* out_dist2, uint32_t* overflow_list, uint32_t* overflow_count, uint32_t* error_flag) {
   dim3 grid(max_src_blocks * kResolvePointsPerLane, static_cast<uint32_t>(n_jobs));  // one workgroup per 256 points
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (run_len == kXbRun)
-    hipLaunchKernelGGL(resolve_xfilter_kernel<kXbRun>, grid, dim3(kBlockThreads), 0, st, jobs_dev, split_mul, src.x, src.y, src.z,
+    hipLaunchKernelGGL(resolve_xfilter_kernel<kXbRun>, grid, dim3(kBlockThreads), 0, st, jobs_dev, split_mul, src.x, src.y, src.z, src_perm,
                        sorted_original.x, sorted_original.y, sorted_original.z, perm, keys4, key_stride, rank_stride, out_index,
                        out_dist2, overflow_list, overflow_count);
   else
     hipLaunchKernelGGL(resolve_xfilter_kernel<kFusedChunk>, grid, dim3(kBlockThreads), 0, st, jobs_dev, split_mul, src.x, src.y,
-                       src.z, sorted_original.x, sorted_original.y, sorted_original.z, perm, keys4, key_stride, rank_stride,
+                       src.z, src_perm, sorted_original.x, sorted_original.y, sorted_original.z, perm, keys4, key_stride, rank_stride,
                        out_index, out_dist2, overflow_list, overflow_count);
   (void)error_flag;  // a point with no finite distance goes to the all-exact scan, which raises the flag
 }

@@ -179,7 +179,13 @@ def pose_to_pose7(pose, reference_packing=False):
 
 
 def max_threads() -> int:
-    return lib.oracle_omp_max_threads()
+    """Threads the oracle's OpenMP loops should use: what this job owns, not what the host has (a GPU box shows all
+    256 host cores to a job that owns a 16-core share; 256 threads there ran the 64-object test 10x slower)."""
+    try:
+        owned = len(os.sched_getaffinity(0))
+    except AttributeError:
+        owned = os.cpu_count() or 1
+    return max(1, min(lib.oracle_omp_max_threads(), owned, 16))
 
 
 # ---- reference mode (point-to-plane / MAD rejection / picky / pyramid): oracle/icp_oracle.c, second half ----

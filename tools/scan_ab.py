@@ -15,7 +15,7 @@ import numpy as np  # noqa: E402
 import pose_estimation_amd as pa  # noqa: E402
 import synth_twin as st  # noqa: E402
 
-KEYS = {"MODE": "MI355_ICP_SCAN_MODE", "PPL": "MI355_ICP_SCAN_PPL", "TARGET_BLOCKS": "MI355_ICP_TARGET_BLOCKS", "MIN_TILES": "MI355_ICP_MIN_TILES_PER_SPLIT", "SHAPE": "MI355_ICP_XBF16_SHAPE"}
+KEYS = {"MODE": "MI355_ICP_SCAN_MODE", "PPL": "MI355_ICP_SCAN_PPL", "TARGET_BLOCKS": "MI355_ICP_TARGET_BLOCKS", "MIN_TILES": "MI355_ICP_MIN_TILES_PER_SPLIT", "SHAPE": "MI355_ICP_XBF16_SHAPE", "SORT": "MI355_ICP_SORT_SOURCES"}
 
 
 def main():
@@ -24,10 +24,22 @@ def main():
     ap.add_argument("--nt", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--jobs", type=int, default=1, help="batched: this many objects, each n x nt (BASELINE config[3] style)")
+    ap.add_argument("--sorted-source", action="store_true", help="upload the source clouds in Morton order (what-if: lanes of a wave hold neighbouring points)")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     nt = a.nt or a.n
     pairs = [st.make_pair(pa.synth_cloud, a.n, nt, object_index=(k if a.jobs > 1 else -1)) for k in range(a.jobs)]
+    if a.sorted_source:
+        def morton(p):
+            q = ((p - p.min(0)) / (p.max(0) - p.min(0) + 1e-9) * 1023).astype(np.uint64)
+            def spread(v):
+                v = (v | (v << 16)) & 0x030000FF
+                v = (v | (v << 8)) & 0x0300F00F
+                v = (v | (v << 4)) & 0x030C30C3
+                v = (v | (v << 2)) & 0x09249249
+                return v
+            return np.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), kind="stable")
+        pairs = [(np.ascontiguousarray(s[morton(s)]), t, g) for s, t, g in pairs]
     engines = []
     for v in a.variants:
         for k in KEYS.values():

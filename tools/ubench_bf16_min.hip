@@ -41,7 +41,47 @@ __device__ __forceinline__ uint32_t min14_lds2(const f32x16& acc, uint32_t seed,
   return m3(t3, t4, t5);
 }
 
-template <int MODE>  // 0 M, 1 V2, 2 V3, 3 B2, 4 B3, 5 B3 with two values per MFMA through ds_min_u32
+// float minima written as asm, so hipcc adds no canonicalising v_max (IEEE mode) in front of them
+__device__ __forceinline__ float fmin3(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float fmin2(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float fminimum3(float a, float b, float c) {
+  float r;
+  asm("v_minimum3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+template <int KIND>  // 0: 8 v_min3_f32, 1: 16 v_min_f32, 2: 8 v_minimum3_f32 (gfx950)
+__device__ __forceinline__ uint32_t fmin16(const f32x16& a, uint32_t seed_bits) {
+  const float seed = __uint_as_float(seed_bits);
+  if (KIND == 1) {
+    float r = seed;
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) {  // four independent chains keep the adds apart
+      r = fmin2(r, a[k]);
+    }
+    float r1 = a[1], r2 = a[2], r3 = a[3];
+#pragma unroll
+    for (int k = 4; k < 16; k += 4) {
+      r1 = fmin2(r1, a[k + 1]);
+      r2 = fmin2(r2, a[k + 2]);
+      r3 = fmin2(r3, a[k + 3]);
+    }
+    return __float_as_uint(fmin2(fmin2(r, r1), fmin2(r2, r3)));
+  }
+  auto f = [](float x, float y, float z) { return KIND == 0 ? fmin3(x, y, z) : fminimum3(x, y, z); };
+  const float t0 = f(a[0], a[1], a[2]), t1 = f(a[3], a[4], a[5]), t2 = f(a[6], a[7], a[8]), t3 = f(a[9], a[10], a[11]);
+  const float t4 = f(a[12], a[13], a[14]), t5 = f(a[15], t0, t1), t6 = f(t2, t3, t4);
+  return __float_as_uint(f(t5, t6, seed));
+}
+
+template <int MODE>  // 0 M, 1 V2, 2 V3, 3 B2, 4 B3, 5 B3 with two values per MFMA through ds_min_u32; 6/7/8: MFMA + float minima (fmin16<0/1/2>); 9/10/11: those minima alone
 __global__ __launch_bounds__(256, 2) void k(float* out, int iters, const u32x4* in) {
   f32x16 acc[4];
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -57,13 +97,16 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters, const u32x4* 
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      if (MODE == 3 || MODE == 4 || MODE == 5) asm volatile("" : "+v"(fa), "+v"(acc[(m + 2) & 3]), "+v"(cm[(m + 3) & 3]));
-      if (MODE == 0 || MODE == 3 || MODE == 4 || MODE == 5)
+      if (MODE == 3 || MODE == 4 || MODE == 5 || MODE == 6 || MODE == 7 || MODE == 8) asm volatile("" : "+v"(fa), "+v"(acc[(m + 2) & 3]), "+v"(cm[(m + 3) & 3]));
+      if (MODE == 0 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 6 || MODE == 7 || MODE == 8)
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), zero, 0, 0, 0);
       if (MODE == 1 || MODE == 3) cm[m] = min16<true>(acc[(m + 2) & 3], cm[m]);
       if (MODE == 2 || MODE == 4) cm[m] = min16<false>(acc[(m + 2) & 3], cm[m]);
       if (MODE == 5) cm[m] = min14_lds2(acc[(m + 2) & 3], cm[m], &slots[m][threadIdx.x]);
-      if (MODE == 1 || MODE == 2) asm volatile("" : "+v"(acc[(m + 2) & 3]));  // keep the minima in the loop
+      if (MODE == 6 || MODE == 9) cm[m] = fmin16<0>(acc[(m + 2) & 3], cm[m]);
+      if (MODE == 7 || MODE == 10) cm[m] = fmin16<1>(acc[(m + 2) & 3], cm[m]);
+      if (MODE == 8 || MODE == 11) cm[m] = fmin16<2>(acc[(m + 2) & 3], cm[m]);
+      if (MODE == 1 || MODE == 2 || MODE >= 9) asm volatile("" : "+v"(acc[(m + 2) & 3]));  // keep the minima in the loop
     }
   }
   float s = 0;
@@ -101,6 +144,10 @@ int main() {
     printf("waves/SIMD=%d  cycles per step per SIMD at 2.4 GHz:  (MFMA only %.1f) | pairwise tree (hipcc: min/min3 mix) %.1f | 8 v_min3_u32 %.1f | MFMA + mix %.1f | MFMA + 8 v_min3_u32 %.1f\n",
            wps, cyc(m), cyc(v2), cyc(v3), cyc(b2), cyc(b3));
     printf("              MFMA + 7 v_min3_u32 + 2 ds_min_u32 (two of the 16 results through the LDS pipe): %.1f\n", cyc(b5));
+    const float f6 = run<6>(out, in, grid, iters), f7 = run<7>(out, in, grid, iters), f8 = run<8>(out, in, grid, iters);
+    const float f9 = run<9>(out, in, grid, iters), f10 = run<10>(out, in, grid, iters), f11 = run<11>(out, in, grid, iters);
+    printf("              float minima (asm, no canonicalise): MFMA + 8 v_min3_f32 %.1f | MFMA + 16 v_min_f32 %.1f | MFMA + 8 v_minimum3_f32 %.1f || alone: %.1f | %.1f | %.1f\n",
+           cyc(f6), cyc(f7), cyc(f8), cyc(f9), cyc(f10), cyc(f11));
   }
   return 0;
 }
