@@ -197,6 +197,18 @@ int mi355_icp_correspond(mi355_icp_ctx* ctx, int n_jobs, const int* source_ids, 
                          const double* poses, float max_correspondence_distance, int32_t* out_index,
                          float* out_dist2, double* out_sums);
 
+/* Diagnostic for the parity tests (no reference counterpart; no product path calls it): the lower bounds the
+ * matrix-core filter scan works with.  Runs the production scan kernel (same code, instantiated with a dump switch)
+ * for source cloud `source_id` under `pose` against target cloud `target_id` and returns, for EVERY source point and
+ * EVERY run of 128 consecutive targets of the Morton-sorted copy, the lower bound L the scan computed for the exact
+ * float32 minimum of that run (0 where the scan makes no statement: non-finite bound).
+ *   out_lower        n_runs x n_source floats, run-major: out_lower[g * n_source + i], i in upload order
+ *   out_run_targets  n_runs x 128 int32: the original indices of run g's targets, -1 for padding slots
+ *   inout_n_runs     in: capacity of the buffers in runs; out: number of runs (padded target count / 128)
+ * Fails with MI355_ICP_ERR_INVALID_ARGUMENT if the capacity is too small (inout_n_runs still receives the count). */
+int mi355_icp_debug_filter_bounds(mi355_icp_ctx* ctx, int source_id, int target_id, const double* pose, float* out_lower,
+                                  int32_t* out_run_targets, size_t* inout_n_runs);
+
 /* ---- reference mode: what cv::ppf_match_3d::ICP really runs ---------- */
 
 /* The constructor arguments of the reference call site, cv::ppf_match_3d::ICP(iterations, tolerance,

@@ -114,6 +114,7 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355_icp_correspond": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    "mi355_icp_debug_filter_bounds": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_size_t)]),
     "mi355_icp_align_reference": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _P(ReferenceParams),
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355_icp_reference_pass": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,

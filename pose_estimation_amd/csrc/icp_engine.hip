@@ -671,8 +671,14 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(c->overflow_count_host, c->overflow_count, static_cast<size_t>(n_active) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   if (defer) {
-    if (sbx) launch_overflow_exact(c->stream, c->jobs_dev, n_active, kOverflowCap, S, T, c->overflow_list, c->overflow_count, c->out_index,
-                                   c->out_dist2, c->error_flag);
+    if (sbx && xf) {  // a sorted copy with tile spheres exists: only the tiles a point can still reach (any target size)
+      const float* xp = X.planes;
+      launch_overflow_tiles(c->stream, c->jobs_dev, n_active, kOverflowCap, S, DevicePlanes{xp + 4 * xstride, xp + 5 * xstride, xp + 6 * xstride},
+                            X.perm, X.table, c->overflow_list, c->overflow_count, c->out_index, c->out_dist2, c->error_flag);
+    } else if (sbx) {
+      launch_overflow_exact(c->stream, c->jobs_dev, n_active, kOverflowCap, S, T, c->overflow_list, c->overflow_count, c->out_index,
+                            c->out_dist2, c->error_flag);
+    }
     HIP_TRY(c, hipGetLastError());
     return MI355_ICP_OK;
   }
@@ -697,10 +703,12 @@ void book_overflow(mi355_icp_ctx* c, int n_active) {
   }
 }
 
-// The device-side pass streams the whole target cloud once per overflow point (12 B per target and point, out of L2 /
-// Infinity Cache).  That beats a host round trip + gathered tiled scan as long as the cloud is small: at 1M targets
-// and the ~250 points a pass leaves there, it costs 0.4 ms against 0.2 ms (profiles/r01o_overflow_paths.txt).
-bool defer_pays(const mi355_icp_ctx* c, int n_active) {
+// Is the device-side overflow pass the cheaper one?  With a sorted copy of the targets (every expansion filter) it scans
+// only the tiles a point can still reach and always is.  The fused filter has no such copy: its pass streams the whole
+// target cloud once per listed point (12 B per target and point, out of L2 / Infinity Cache), which beats a host round
+// trip + gathered tiled scan only while the cloud is small (profiles/r01o_overflow_paths.txt).
+bool defer_pays(const mi355_icp_ctx* c, const Plan& plan, int n_active) {
+  if (plan.xfilter) return true;
   uint32_t tiles = 0;
   for (int k = 0; k < n_active; ++k) tiles = std::max(tiles, c->jobs_host[k].tgt_tiles);
   return tiles <= 256;
@@ -714,7 +722,7 @@ int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, boo
   // Slab-sharded: the exchange sits between the kernels and the synchronisation, so a rank cannot decide on its own to
   // repeat a pass.  The per-job "my device-side overflow pass was too small" flags therefore travel WITH the sums;
   // every rank sees their total and all of them repeat the pass through the host path together.
-  const bool defer = plan.fused && defer_pays(c, n_active);
+  const bool defer = plan.fused && defer_pays(c, plan, n_active);
   bool retry = false;
   int st = run_pass_once(c, plan, n_active, profile, local_only, defer, &retry);
   if (st == MI355_ICP_OK && retry) st = run_pass_once(c, plan, n_active, profile, local_only, false, &retry);
@@ -880,7 +888,7 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
 int run_ref_pass(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, float rejection_scale, size_t owner_total,
                  bool profile) {
   bool retry = false;
-  int st = run_ref_pass_once(c, plan, level, n_active, rejection_scale, owner_total, profile, plan.fused && defer_pays(c, n_active), &retry);
+  int st = run_ref_pass_once(c, plan, level, n_active, rejection_scale, owner_total, profile, plan.fused && defer_pays(c, plan, n_active), &retry);
   if (st == MI355_ICP_OK && retry) st = run_ref_pass_once(c, plan, level, n_active, rejection_scale, owner_total, profile, false, &retry);
   return st;
 }
@@ -1213,6 +1221,65 @@ int mi355_icp_correspond(mi355_icp_ctx* c, int n_jobs, const int* source_ids, co
     cursor += J.src_n;
   }
   return check_error_flag(c);
+}
+
+int mi355_icp_debug_filter_bounds(mi355_icp_ctx* c, int source_id, int target_id, const double* pose, float* out_lower,
+                                  int32_t* out_run_targets, size_t* inout_n_runs) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  c->err.clear();
+  c->call_pruned = false;
+  if (!pose || !inout_n_runs) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "debug_filter_bounds: bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  Plan plan;
+  int st = make_plan(c, 1, &source_id, &target_id, 0.0f, plan);
+  if (st != MI355_ICP_OK) return st;
+  JobDesc J = plan.jobs[0];
+  const CloudEntry& T = c->targets.clouds[static_cast<size_t>(target_id)];
+  const CloudEntry& S = c->sources.clouds[static_cast<size_t>(source_id)];
+  const size_t n_runs = T.padded / kXbRun;
+  const size_t capacity = *inout_n_runs;
+  *inout_n_runs = n_runs;
+  if (!out_lower && !out_run_targets) return MI355_ICP_OK;  // size query
+  if (capacity < n_runs) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "debug_filter_bounds: buffers hold fewer runs than the target has");
+  if (n_runs * static_cast<size_t>(S.padded) > (1ull << 28)) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "debug_filter_bounds: runs x points too large for a diagnostic dump");
+  if (!pose_to_f32(pose, J.pose)) return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "debug_filter_bounds: non-finite pose");
+  // one unsplit job whose output slots start at 0, walked in upload order (the dump is indexed by point position)
+  J.n_split = 1;
+  J.split_q = J.tgt_tiles;
+  J.split_r = 0;
+  J.out_off = 0;
+  J.scan_blocks = (S.n + 511u) / 512u;
+  plan.jobs[0] = J;
+  plan.max_split = 1;
+  plan.out_total = S.padded;
+  plan.fused = plan.xfilter = true;
+  plan.xkind = 3;
+  plan.pruned = false;
+  if ((st = ensure_buffers(c, plan, 1)) != MI355_ICP_OK) return st;
+  if ((st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;
+  float* dump = nullptr;
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&dump), n_runs * S.padded * sizeof(float)));
+  auto finish = [&](int code) { (void)hipStreamSynchronize(c->stream); (void)hipFree(dump); return code; };
+  c->jobs_host[0] = J;
+  if (hipMemsetAsync(dump, 0, n_runs * S.padded * sizeof(float), c->stream) != hipSuccess ||
+      hipMemcpyAsync(c->jobs_dev, c->jobs_host, sizeof(JobDesc), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    return finish(fail(c, MI355_ICP_ERR_HIP, "debug_filter_bounds: staging failed"));
+  const uint32_t rank_stride = plan.key_rows() * plan.out_total;
+  launch_nn_scan_xbf16_dump(c->stream, c->jobs_dev, J.scan_blocks, c->sources.view(), c->targets.xt.bf, c->targets.xt.table, c->keys3,
+                            plan.out_total, rank_stride, dump, S.padded);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+    return finish(fail(c, MI355_ICP_ERR_HIP, "debug_filter_bounds: the dump launch failed"));
+  if (out_lower)
+    for (size_t g = 0; g < n_runs; ++g)
+      if (S.n && hipMemcpy(out_lower + g * S.n, dump + g * S.padded, S.n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        return finish(fail(c, MI355_ICP_ERR_HIP, "debug_filter_bounds: copy back failed"));
+  if (out_run_targets) {
+    std::vector<uint32_t> perm(T.padded);
+    if (hipMemcpy(perm.data(), c->targets.xt.perm + T.off, T.padded * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+      return finish(fail(c, MI355_ICP_ERR_HIP, "debug_filter_bounds: copy back failed"));
+    for (size_t p = 0; p < T.padded; ++p) out_run_targets[p] = p < T.n ? static_cast<int32_t>(perm[p]) : -1;
+  }
+  return finish(MI355_ICP_OK);
 }
 
 int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* target_ids,

@@ -505,34 +505,57 @@ __global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xmfma_kernel(const J
 //
 // f32-input MFMA runs on the vector ALUs (measured: no overlap with VALU work, tools/ubench_mfma_valu.hip), so the
 // kernel above buys nothing.  v_mfma_f32_32x32x16_bf16 is a different unit: 1024 products of a K = 16 contraction in 32
-// cycles, of which it holds the vector issue port for 8.  Sixteen K slots are enough for the expansion surrogate of
-// points QUANTISED to two bfloat16 pieces per coordinate (16 significand bits):
+// cycles.  Sixteen K slots are enough for the expansion surrogate of points QUANTISED to two bfloat16 pieces per
+// coordinate (16 significand bits).  Notation: u = 2^-24; q the transformed source point, t a target, c the tile centre
+// (all float32); qc = fl(q - c), tc = fl(t - c); r^2 >= |tc|^2 and >= |tc'|^2 for every target of the tile (rounded up
+// at upload); N := |qc|^2 + r^2.
 //
-//   qc' = hi + lo of -2 fl(q - c) (times -1/2),   tc' = hi + lo of fl(t - c),   tt' = fl(|tc'|^2) in three pieces
-//   slots 0-11: (th, th, tl, tl) x (qh, ql, qh, ql) per coordinate  = q'.tc' exactly (every product is exact in f32)
-//   slots 12-14: (tt1, tt2, tt3) x (1, 1, 1)                       = tt'          slot 15: 1 x b, a bias (see min16)
-//   s = |qc'|^2 + (MFMA - b)   ~   |qc' - tc'|^2, the squared distance between the QUANTISED points.
+//   q'  = -2 qc (exact), split into bf16 pieces q'h + q'l, |q' - (q'h + q'l)| <= 2^-16 |q'| per coordinate
+//         (two round-to-nearest bf16 roundings: 2^-8 of 2^-8); qc' := -(q'h + q'l) / 2
+//   tc' = th + tl likewise (xtarget_kernels.hip), tt' = fl(|tc'|^2) from double, in three bf16 pieces t1 + t2 + t3
+//   slots 0-11: (th, th, tl, tl) x (q'h, q'l, q'h, q'l) per coordinate   = q'.tc' (every product is exact in float32)
+//   slots 12-14: (t1, t2, t3) x (1, 1, 1)                                = tt'     slot 15: 1 x b, a bias (see min16)
+//   s = fl(MFMA + fl(qq - b)),  qq = fl(|qc'|^2)      ~   S := |qc' - tc'|^2, the squared distance of the QUANTISED points.
 //
-// Moving a point by delta changes a squared distance d^2 by at most 2 d |delta| + |delta|^2 <= eps d^2 + (1 + 1/eps)
-// |delta|^2 for any eps > 0.  With eps = 2^-6 and |delta| <= 2^-16 (|qc| + r) the second term is below 2^-24.9
-// (|qc|^2 + r^2), so
-//        (1 - 2^-6) d^2 - E  <=  s  <=  (1 + 2^-6) d^2 + E,     E = 2^-16 (|qc|^2 + r_tile^2) + 2^-120
-// where E = 256 u also covers every rounding on the way: the float32 centring of q and t and the contract formula
-// itself (the 30.4 u of the VALU filter's derivation), tt', |qc'|^2, the bias and the final additions
-// (< 12 u), and up to 4 u of relative error in each of the MFMA's 16 accumulation steps (sum of |terms| <=
-// 3.1 (|qc|^2 + r^2) with the bias; truncating accumulation would be 2 u per step).  The absolute floor 2^-120 is for
-// the matrix unit flushing subnormal operand pieces, products or sums (17 x 2^-126 at most, plus 6 x 2^-126 (|q'| + r)
-// for flushed low pieces, which the relative part covers once |qc| + r >= 2^-106): squared distances that small make
-// every granule a candidate and the all-exact scan answers.  Hence per granule
-//        L = max((s_min - E) * 0.9845, 0)  <=  exact minimum of the granule  <=  (s_min + E) * 1.0160 = U
-// and the rest is the VALU filter's scheme: three smallest L and the smallest U per source point; the exact resolve
-// re-scans the one or two granules with L <= U_min on the original coordinates; more go to the all-exact scan.
+// What the code needs is ONE inequality per granule:  exact contract minimum d^2 >= L := max((s_min - E) * 0.99902, 0),
+// which follows from  s <= (1 + 2^-10) d^2 + E  for every pair  (0.99902 < 1 / (1 + 2^-10)).  The terms of that
+// inequality, each as a multiple of u N:
+//   (a) quantisation.  qc' - tc' differs from qc - tc by at most D = 2^-16 (|qc| + r), so with e = 2^-10:
+//       S <= (1 + e) |qc - tc|^2 + (1 + 1/e) D^2,  and (1 + 2^10) 2^-32 (|qc| + r)^2 <= 2050 * 2^-32 * N        =   8.1 u N
+//   (b) centring.  qc - tc differs from q - t by at most u (|qc| + r) (two float32 subtractions), so
+//       |qc - tc|^2 <= |q - t|^2 + 2 |q - t| u (|qc| + r) + ... <= |q - t|^2 + 4.2 u N                           =   4.2 u N
+//   (c) the contract value itself: d^2 is within 5 u |q - t|^2 <= 10 u N of |q - t|^2 (3 sub, 3 mul, 2 add)     =  10   u N
+//   (d) qq: three roundings of partial sums <= |q'|^2, times 1/4                                                  =   3   u N
+//   (e) tt': fl() of the double sum and the dropped fourth piece, 2 u r^2                                         =   2   u N
+//   (f) the two float32 additions that form s from the MFMA result (|s| <= 2 N)                                   =   4   u N
+//   (g) the matrix unit's accumulation.  Sum of |terms| T: cross terms <= (1 + 2^-7)^2 2 |qc| |tc| <= 1.016 N,
+//       tt' pieces <= 1.008 r^2, bias <= 1.008 |qc|^2 + 2^-14 N: T <= 2.03 N.  WORST-CASE MODEL: the 16 products are
+//       exact (8-bit x 8-bit significands) and are added in any order, in float32 or wider, each addition - or each
+//       operand aligned to the largest exponent - rounded OR TRUNCATED: at most 16 errors of one float32 ulp of a
+//       quantity <= T, i.e. 16 * 2u * T                                                                           =  65   u N
+//       (tools/probe_mfma_bf16.hip measures <= 4.2 u T for the whole sum on 2*10^6 cancelling contractions:
+//       profiles/r01n_probe_mfma_bf16.txt, re-run by tests/test_gpu_mfma_probe.py - 15x inside the model.)
+//   total (1 + e) * ((b) + (c)) + the rest                                                                       <  97   u N
+// E = 2^-16 N + 2^-120 = 256 u N: 2.6x the worst case.  (Round 1 shipped 2^-17 = 128 u N, which the model above
+// still fits, by 1.3x; the wider band costs ~3x the overflow points - a few hundred of 10^6 - and no scan time.)
+// The absolute floor 2^-120 is for the matrix unit flushing subnormal operand pieces, products or sums (17 x 2^-126 at
+// most, plus 6 x 2^-126 (|q'| + r) for flushed low pieces, which the relative part covers once |qc| + r >= 2^-106):
+// squared distances that small make every granule a candidate and the all-exact scan answers.  A point whose E is not
+// finite (overflowing coordinates) publishes L = 0 three times: everything is a candidate for it.
+// tests/test_gpu_filter_bounds.py reads the per-granule L back (mi355_icp_debug_filter_bounds, the same kernel
+// instantiated with kDump) and asserts L <= the oracle's exact granule minimum for EVERY (point, granule) on the
+// adversarial clouds of the parity suite - the invariant itself, not its consequence.
+//
+// The scan keeps, per source point and wave half, the three granules with the smallest L; the exact resolve
+// (resolve_xfilter_kernel) re-scans granule 1 on the original coordinates, granule 2 if L2 <= the exact minimum d*
+// found so far, and sends the point to the all-exact scan if L3 <= d* (a granule the scan did not keep could matter).
 //
 // Geometry.  A wave computes 32 targets x 32 sources per MFMA.  D: lane l holds source column (l & 31) and the 16 rows
 // 8j + 4(l >> 5) + k, so each HALF of the wave sees half of the rows; the operand image (xtarget_kernels.hip) assigns
 // those rows to one contiguous 128-target run of the sorted copy per 256-target chunk, and each half keeps its own
 // keys - no cross-lane traffic at all; the resolve merges the two key rows like two more target splits.
-// VALU work per pair: the minimum over the 16 accumulator registers (1 issue slot) + ~0.14 slots of bookkeeping.
+// VALU work per pair: the minimum over the 16 accumulator registers (8 v_min3_u32 per MFMA: 44.8 cycles per MFMA + minima
+// at two waves per SIMD, tools/ubench_bf16_min.hip) + ~0.14 slots of bookkeeping.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifdef MI355_PIN_OFF
@@ -581,7 +604,9 @@ __device__ __forceinline__ uint32_t min16(const f32x16& acc, uint32_t seed) {
 // ds_write to the tile, 8 LDS instructions next to the 8 fragment reads that do the work, at a 32-byte lane stride that
 // conflicts two ways (SQ_LDS_BANK_CONFLICT = 73 % of SQ_ACTIVE_INST_LDS in profiles/r01o_pmc_summary.txt; 33.6 -> 32.0 ms
 // at 1M<->1M without it: profiles/r02b_scan_ab_lds_dma.txt).
-template <int kSets, int kThreads>
+// kDump (mi355_icp_debug_filter_bounds only, never the product path): additionally writes the lower bound L of EVERY
+// (point, 128-target run) to dump[run * dump_stride + point position] - what the parity tests check the bound on.
+template <int kSets, int kThreads, bool kDump = false>
 __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDesc* __restrict__ jobs,
                                                                        const float* __restrict__ sx,
                                                                        const float* __restrict__ sy,
@@ -589,7 +614,8 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
                                                                        const uint4* __restrict__ bf_image,
                                                                        const float4* __restrict__ tile_table,
                                                                        unsigned long long* __restrict__ keys4,
-                                                                       uint32_t key_stride, uint32_t rank_stride) {
+                                                                       uint32_t key_stride, uint32_t rank_stride,
+                                                                       float* __restrict__ dump = nullptr, uint32_t dump_stride = 0) {
   // [buffer][k half][row slot]: 2 x 32 KiB, + 96 slots the fragment prefetch of a tile's last two steps runs into
   // (blocks 32-34 do not exist: whatever is read there feeds MFMAs whose results are dropped)
   constexpr uint32_t kLdsPad = 96;
@@ -646,7 +672,7 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
       split_bf16(q2y[m] + c2y, py, vy);
       split_bf16(q2z[m] + c2z, pz, vz);
       const float qq = 0.25f * __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));  // |qc'|^2 of the quantised point (x 1/4: exact)
-      ee[m] = __builtin_fmaf(7.62939453125e-06f, qq + tc.w, 7.5231638e-37f);  // 2^-17 (|qc'|^2 + r^2) + 2^-120
+      ee[m] = __builtin_fmaf(1.52587890625e-05f, qq + tc.w, 7.5231638e-37f);  // E = 2^-16 (|qc'|^2 + r^2) + 2^-120
       unsafe[m] = unsafe[m] || !(ee[m] < 1.0e37f);                              // inf / NaN bound: exact scan instead
       const uint32_t bias = (__float_as_uint(__builtin_fmaf(2.0f, ee[m], qq)) + 0xFFFFu) >> 16;  // bf16, rounded up
       adj[m] = qq - bf16_value(bias);  // s = MFMA + adj
@@ -714,6 +740,8 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
         const float s = __uint_as_float(cmin[m]) + adj[m];
         const float lo = __builtin_fmaxf((s - ee[m]) * 0.99902f, 0.0f);
         cmin[m] = 0x7F800000u;
+        if constexpr (kDump)  // NaN (a non-finite bound) is reported as 0: "no statement", like the keys of an unsafe point
+          dump[static_cast<size_t>(run) * dump_stride + J.out_off + sb * kScanSrcPerBlock + src_local + m * 32] = (unsafe[m] || !(lo == lo)) ? 0.0f : lo;
         // once the scan has passed a point's neighbourhood its three best granules rarely change: the sorted insert
         // (12 selects) is skipped unless some lane of the wave needs it (rarely, with the sources in Morton order too)
         if (__builtin_amdgcn_ballot_w64(lo < l3[m]) != 0) {
@@ -761,6 +789,16 @@ void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uin
     hipLaunchKernelGGL((nn_scan_xbf16_kernel<4, 256>), grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x,
                        src.y, src.z, static_cast<const uint4*>(bf_image), static_cast<const float4*>(tile_table), keys4, key_stride,
                        rank_stride);
+}
+
+// the production kernel instantiated with kDump: one job, unsplit, L of every (point, run) to `dump` (diagnostic entry point)
+void launch_nn_scan_xbf16_dump(void* stream, const JobDesc* jobs_dev, uint32_t blocks_x, DevicePlanes src, const void* bf_image,
+                               const void* tile_table, unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride,
+                               float* dump, uint32_t dump_stride) {
+  if (!blocks_x) return;
+  hipLaunchKernelGGL((nn_scan_xbf16_kernel<4, 256, true>), dim3(blocks_x, 1), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev,
+                     src.x, src.y, src.z, static_cast<const uint4*>(bf_image), static_cast<const float4*>(tile_table), keys4, key_stride,
+                     rank_stride, dump, dump_stride);
 }
 
 // points_per_lane selects the workgroup's source span exactly as for the VALU kernel (256 * ppl = 128 * kSets points)

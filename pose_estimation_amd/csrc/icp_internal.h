@@ -162,6 +162,9 @@ void launch_nn_scan_xmfma(void* stream, int points_per_lane, const JobDesc* jobs
 void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
                           const void* bf_image, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
                           uint32_t rank_stride, int shape);
+void launch_nn_scan_xbf16_dump(void* stream, const JobDesc* jobs_dev, uint32_t blocks_x, DevicePlanes src, const void* bf_image,
+                               const void* tile_table, unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride,
+                               float* dump, uint32_t dump_stride);
 // run_len: targets per remembered granule (kFusedChunk, or kXbRun with two key rows per split: split_mul = 2)
 // src_perm != nullptr: `src` is a Morton-ordered copy (position -> original index in src_perm); results and overflow ids
 // are written at original indices
@@ -176,6 +179,9 @@ constexpr uint32_t kOverflowCap = 1024;  // overflow points per job the device-s
 void launch_overflow_exact(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t cap, DevicePlanes src, DevicePlanes tgt,
                            const uint32_t* overflow_list, const uint32_t* overflow_count, int32_t* out_index, float* out_dist2,
                            uint32_t* error_flag);
+void launch_overflow_tiles(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t cap, DevicePlanes src, DevicePlanes sorted_tgt,
+                           const uint32_t* tgt_perm, const void* tgt_table, const uint32_t* overflow_list, const uint32_t* overflow_count,
+                           int32_t* out_index, float* out_dist2, uint32_t* error_flag);
 void launch_accumulate(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
                        DevicePlanes tgt, const int32_t* index, const float* dist2, double* partials);
 void launch_gather_points(void* stream, DevicePlanes src, uint32_t src_off, const uint32_t* list, uint32_t n, float* out_planes,

@@ -635,8 +635,10 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
     if (L3 <= __uint_as_float(res_d) || res_j == 0xFFFFFFFFu) {  // a third candidate granule (or more), or nothing finite found
       const uint32_t pos = atomicAdd(&overflow_count[blockIdx.y], 1u);
       overflow_list[J.out_off + pos] = orig;
-      out_index[J.out_off + orig] = 0;  // valid placeholder, see resolve_fused_kernel
-      out_dist2[J.out_off + orig] = __builtin_inff();
+      // the best pair found so far - an upper bound the overflow pass (overflow_tiles_kernel) prunes with; index -1 = none.
+      // Every listed point is rewritten by that pass, or by the host path, before anything reads these slots.
+      out_index[J.out_off + orig] = static_cast<int32_t>(res_j);
+      out_dist2[J.out_off + orig] = __uint_as_float(res_d);
       return;
     }
     out_index[J.out_off + orig] = static_cast<int32_t>(res_j);
@@ -704,6 +706,90 @@ __global__ __launch_bounds__(kTile) void overflow_exact_kernel(
     if (j == 0xFFFFFFFFu || j >= J.tgt_n) {  // nothing but NaN / padding: same report as the all-exact resolve
       atomicOr(error_flag, 1u);
       j = 0;
+    }
+    out_index[J.out_off + local] = static_cast<int32_t>(j);
+    out_dist2[J.out_off + local] = __uint_as_float(d);
+  }
+}
+
+// The same job for the paths that own a Morton-sorted copy of the targets (every expansion filter): one 256-thread
+// workgroup per listed point scans, with the contract formula, the TILES THE POINT CAN STILL REACH - those whose bounding
+// sphere (the per-tile table of xtarget_kernels.hip) may hold a target at or below d0, the best distance the resolve found
+// in the granules it did scan (an upper bound of the answer; +inf if it found none: then every tile is scanned).  A tile
+// out of reach holds neither the minimum nor a tie with it (sphere_lower_bound rounds towards "reachable"), so the
+// (d2, original index)-lexicographic minimum over the reachable tiles is the all-exact answer.  Typically 2-10 of the
+// 1024 tiles of a 10^6-point scene: the pass costs microseconds at any target size, so the overflow points never need
+// the host (round 1 went through a host round trip + gathered all-exact scan above 262k targets).
+__global__ __launch_bounds__(kBlockThreads) void overflow_tiles_kernel(
+    const JobDesc* __restrict__ jobs, const float* __restrict__ sx, const float* __restrict__ sy,
+    const float* __restrict__ sz, const float* __restrict__ sox, const float* __restrict__ soy,
+    const float* __restrict__ soz, const uint32_t* __restrict__ tperm, const float4* __restrict__ ttable,
+    const uint32_t* __restrict__ overflow_list, const uint32_t* __restrict__ overflow_count,
+    int32_t* __restrict__ out_index, float* __restrict__ out_dist2, uint32_t* __restrict__ error_flag) {
+  __shared__ unsigned long long smask[kBlockThreads / 64];
+  __shared__ uint32_t sd[kBlockThreads / 64], sj[kBlockThreads / 64];
+  const JobDesc& J = jobs[blockIdx.y];
+  if (blockIdx.x >= overflow_count[blockIdx.y]) return;
+  const uint32_t local = overflow_list[J.out_off + blockIdx.x];
+  float pose[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
+  const uint32_t i = J.src_off + local;
+  float qx, qy, qz;
+  transform_point(pose, sx[i], sy[i], sz[i], qx, qy, qz);
+  const float d0 = out_dist2[J.out_off + local];            // never NaN (resolve_xfilter_kernel)
+  float best = d0;
+  uint32_t best_j = static_cast<uint32_t>(out_index[J.out_off + local]);  // 0xFFFFFFFF = none yet
+  const uint32_t n_tiles = J.tgt_tiles, tile_base = J.tgt_off / kTile, tid = threadIdx.x;
+  for (uint32_t t0 = 0; t0 < n_tiles; t0 += kBlockThreads) {
+    const uint32_t t = t0 + tid;
+    const bool reach = t < n_tiles && sphere_reachable(qx, qy, qz, 0.0f, ttable[tile_base + t], d0);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(reach);
+    if ((tid & 63u) == 0) smask[tid >> 6] = m;
+    __syncthreads();
+    for (uint32_t w = 0; w < kBlockThreads / 64; ++w) {
+      unsigned long long todo = smask[w];
+      while (todo) {
+        const uint32_t tile = t0 + w * 64 + static_cast<uint32_t>(__builtin_ctzll(todo));
+        todo &= todo - 1;
+        float d[kTile / kBlockThreads];
+        uint32_t pj[kTile / kBlockThreads];
+#pragma unroll
+        for (int k = 0; k < kTile / kBlockThreads; ++k) {
+          const uint32_t p = J.tgt_off + tile * kTile + k * kBlockThreads + tid;
+          d[k] = dist2(qx, qy, qz, sox[p], soy[p], soz[p]);
+          pj[k] = tperm[p];
+        }
+#pragma unroll
+        for (int k = 0; k < kTile / kBlockThreads; ++k) {
+          const bool real = tile * kTile + k * kBlockThreads + tid < J.tgt_n;  // padding slots sit at 3e38 with index 0
+          if (real && (d[k] < best || (d[k] == best && pj[k] < best_j))) {
+            best = d[k];
+            best_j = pj[k];
+          }
+        }
+      }
+    }
+    __syncthreads();  // smask is rewritten by the next round
+  }
+  const uint32_t wd = wave_min_u32(__float_as_uint(best));
+  const uint32_t wj = wave_min_u32(__float_as_uint(best) == wd ? best_j : 0xFFFFFFFFu);
+  if ((tid & 63u) == 0) {
+    sd[tid >> 6] = wd;
+    sj[tid >> 6] = wj;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t d = sd[0], j = sj[0];
+    for (int w = 1; w < kBlockThreads / 64; ++w)
+      if (sd[w] < d || (sd[w] == d && sj[w] < j)) {
+        d = sd[w];
+        j = sj[w];
+      }
+    if (j == 0xFFFFFFFFu || j >= J.tgt_n) {  // nothing but NaN / +inf distances: the oracle's report for "nothing below +inf"
+      atomicOr(error_flag, 1u);
+      j = 0;
+      d = 0x7F800000u;
     }
     out_index[J.out_off + local] = static_cast<int32_t>(j);
     out_dist2[J.out_off + local] = __uint_as_float(d);
@@ -1134,6 +1220,14 @@ void launch_overflow_exact(void* stream, const JobDesc* jobs_dev, int n_jobs, ui
   hipLaunchKernelGGL(overflow_exact_kernel, dim3(cap, static_cast<uint32_t>(n_jobs)), dim3(kTile), 0,
                      static_cast<hipStream_t>(stream), jobs_dev, src.x, src.y, src.z, tgt.x, tgt.y, tgt.z, overflow_list, overflow_count,
                      out_index, out_dist2, error_flag);
+}
+
+void launch_overflow_tiles(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t cap, DevicePlanes src, DevicePlanes sorted_tgt,
+                           const uint32_t* tgt_perm, const void* tgt_table, const uint32_t* overflow_list, const uint32_t* overflow_count,
+                           int32_t* out_index, float* out_dist2, uint32_t* error_flag) {
+  hipLaunchKernelGGL(overflow_tiles_kernel, dim3(cap, static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
+                     jobs_dev, src.x, src.y, src.z, sorted_tgt.x, sorted_tgt.y, sorted_tgt.z, tgt_perm, static_cast<const float4*>(tgt_table),
+                     overflow_list, overflow_count, out_index, out_dist2, error_flag);
 }
 
 void launch_nn_pruned(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes sorted_src,

@@ -231,6 +231,19 @@ class IcpEngine:
                                              d2.ctypes.data if want_pairs else None, sums.ctypes.data))
         return idx, d2, sums
 
+    def debug_filter_bounds(self, pose: np.ndarray, source_id: int = 0, target_id: int = 0):
+        """Diagnostic (parity tests): (lower [n_runs, n_source] float32, run_targets [n_runs, 128] int32, -1 = padding) as
+        the matrix-core filter scan computes them for every (source point, 128-target run)."""
+        p = np.ascontiguousarray(pose, dtype=np.float64).reshape(16)
+        n = C.c_size_t(0)
+        self._check(lib.mi355_icp_debug_filter_bounds(self._h, source_id, target_id, p.ctypes.data, None, None, C.byref(n)))
+        ns = self._source_sizes[source_id]
+        lower = np.empty((n.value, ns), dtype=np.float32)
+        runs = np.empty((n.value, 128), dtype=np.int32)
+        self._check(lib.mi355_icp_debug_filter_bounds(self._h, source_id, target_id, p.ctypes.data, lower.ctypes.data,
+                                                      runs.ctypes.data, C.byref(n)))
+        return lower, runs
+
     # -- reference mode (pyramid + MAD rejection + picky + point-to-plane)
     def align_reference(self, init_poses: np.ndarray, iterations: int = 250, tolerance: float = 0.005,
                         rejection_scale: float = 2.5, num_levels: int = 8, source_ids=None, target_ids=None,
