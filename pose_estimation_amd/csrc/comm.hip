@@ -12,6 +12,7 @@
 // Integer reductions (radix-select histograms, picky owner keys) are exact in any order: ncclAllReduce natively.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 
 #include "icp_internal.h"
@@ -28,9 +29,24 @@ __global__ void rank_order_sum_kernel(const double* __restrict__ gathered, int n
   out[i] = acc;
 }
 
-__global__ void overflow_excess_kernel(const uint32_t* __restrict__ counts, uint32_t cap, int n, double* __restrict__ out) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) out[k] = counts[k] > cap ? 1.0 : 0.0;
+// Up to 8 job descriptors travel as KERNEL ARGUMENTS (the packet's kernarg segment) and one wave writes them to the device
+// tables: one launch instead of a host-to-device copy per table per pass - a copy is a blit kernel plus its ordering on the
+// stream, several microseconds each, which is what a pass on a coarse pyramid level costs in total.
+struct StageArgs {
+  uint32_t n, has_ref, first, pad_;
+  JobDesc jobs[8];
+  RefJobDesc rjobs[8];
+};
+__global__ void stage_jobs_kernel(StageArgs a, JobDesc* __restrict__ jobs, RefJobDesc* __restrict__ rjobs) {
+  constexpr uint32_t kJ = sizeof(JobDesc) / 4, kR = sizeof(RefJobDesc) / 4;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(a.jobs);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(jobs + a.first);
+  for (uint32_t w = threadIdx.x; w < a.n * kJ; w += blockDim.x) dst[w] = src[w];
+  if (a.has_ref) {
+    const uint32_t* rs = reinterpret_cast<const uint32_t*>(a.rjobs);
+    uint32_t* rd = reinterpret_cast<uint32_t*>(rjobs + a.first);
+    for (uint32_t w = threadIdx.x; w < a.n * kR; w += blockDim.x) rd[w] = rs[w];
+  }
 }
 
 int hip_fail(hipError_t e, const char** err) {
@@ -145,9 +161,23 @@ void comm_release(CommState& cs) {
   cs = CommState{};
 }
 
-void launch_overflow_excess(void* stream, const uint32_t* counts, uint32_t cap, int n, double* out) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(overflow_excess_kernel, dim3((static_cast<uint32_t>(n) + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), counts, cap, n, out);
+int stage_jobs(void* stream, const JobDesc* jobs_host, const RefJobDesc* rjobs_host, int n, JobDesc* jobs_dev, RefJobDesc* rjobs_dev) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n > 32) {  // large batches: plain copies from the pinned tables
+    hipError_t e = hipMemcpyAsync(jobs_dev, jobs_host, static_cast<size_t>(n) * sizeof(JobDesc), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && rjobs_host) e = hipMemcpyAsync(rjobs_dev, rjobs_host, static_cast<size_t>(n) * sizeof(RefJobDesc), hipMemcpyHostToDevice, s);
+    return e == hipSuccess ? MI355_ICP_OK : MI355_ICP_ERR_HIP;
+  }
+  for (int first = 0; first < n; first += 8) {
+    StageArgs a{};
+    a.n = static_cast<uint32_t>(std::min(8, n - first));
+    a.has_ref = rjobs_host ? 1u : 0u;
+    a.first = static_cast<uint32_t>(first);
+    std::memcpy(a.jobs, jobs_host + first, a.n * sizeof(JobDesc));
+    if (rjobs_host) std::memcpy(a.rjobs, rjobs_host + first, a.n * sizeof(RefJobDesc));
+    hipLaunchKernelGGL(stage_jobs_kernel, dim3(1), dim3(256), 0, s, a, jobs_dev, rjobs_dev);
+  }
+  return hipGetLastError() == hipSuccess ? MI355_ICP_OK : MI355_ICP_ERR_HIP;
 }
 
 }  // namespace mi355

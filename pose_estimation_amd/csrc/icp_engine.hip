@@ -76,6 +76,7 @@ struct Plan {
   bool xfilter = false;        // expansion-filter scan on the sorted/centred target copy (largest launches); implies fused
   int xkind = 0;               // 0 VALU kernel, 1 f32 MFMA kernel, 2 both side by side, 3 split-bf16 MFMA kernel
   bool pruned = false;         // OPTIONAL exact pruned scan (MI355_ICP_SCAN_MODE=pruned), never chosen by the planner
+  bool merged_keys = false;    // small all-exact launches (JobDesc::sub_split): one atomically merged key row, cleared per pass
   bool sorted_src = false;     // the matrix-core scan and its resolve walk the SOURCE cloud in Morton order too (below)
   uint32_t key_rows() const { return (xkind == 3 ? 2u : 1u) * max_split; }  // key rows per rank (wave halves publish separately)
   uint32_t key_ranks() const { return xfilter && xkind != 3 ? 4u : 3u; }       // the VALU expansion kernels also publish U
@@ -125,6 +126,7 @@ struct mi355_icp_ctx {
 
   // reference-mode work buffers
   unsigned long long* owner = nullptr; size_t owner_cap = 0;
+  uint32_t owner_epoch = 0;  // pass tag of the picky owner keys (picky_key): 1..63, 0 = the table must be cleared first
   uint8_t* selected = nullptr;         size_t selected_cap = 0;
   double* ref_partials = nullptr;      size_t ref_partials_cap = 0;
   double* ref_sums_dev = nullptr;      size_t ref_jobs_cap = 0;
@@ -204,6 +206,19 @@ int fail(mi355_icp_ctx* c, int code, const std::string& msg) {
 
 template <typename T>
 int grow(mi355_icp_ctx* c, T*& ptr, size_t& cap, size_t need);
+
+// The one synchronisation of a pass.  A blocking hipStreamSynchronize sleeps on an interrupt and wakes tens of microseconds
+// after the copy has landed - as long as a whole pass on a coarse pyramid level.  Poll the stream for a bounded while
+// first (a short pass ends within it), then block like before (long scans: no core is burnt waiting for them).
+int sync_pass(mi355_icp_ctx* c) {
+  for (int spin = 0; spin < 2000; ++spin) {
+    const hipError_t e = hipStreamQuery(c->stream);
+    if (e == hipSuccess) return MI355_ICP_OK;
+    if (e != hipErrorNotReady) return fail(c, MI355_ICP_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MI355_ICP_OK;
+}
 
 int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* const* xyz, const size_t* n_points,
                   size_t stride_bytes, uint32_t pad_multiple, float pad_value, bool allow_empty, const char* what) {
@@ -324,13 +339,17 @@ int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs) {
     if (c->sums_host) { HIP_TRY(c, hipHostFree(c->sums_host)); c->sums_host = nullptr; }
     c->jobs_cap = 0;
     const size_t want = std::max<size_t>(n_jobs, 8) * 2;
-    // + one double per job: the overflow-excess flag that rides along with the sums in a slab-sharded pass
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sums_dev), want * (MI355_ICP_NSUMS + 1) * sizeof(double)));
+    // + two doubles per job behind the rows: the overflow-excess flag (exchanged with the sums in a slab-sharded pass) and
+    // the overflow count (final_reduce_kernel)
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sums_dev), want * (MI355_ICP_NSUMS + 2) * sizeof(double)));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->jobs_dev), want * sizeof(JobDesc)));
     HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->jobs_host), want * sizeof(JobDesc), hipHostMallocDefault));
-    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->sums_host), want * (MI355_ICP_NSUMS + 1) * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->sums_host), want * (MI355_ICP_NSUMS + 2) * sizeof(double), hipHostMallocDefault));
     c->jobs_cap = want;
   }
+  // the per-job overflow counters are zero between passes (the final-reduce kernels reset them); make that true at the
+  // start of every call too, whatever an earlier call left behind when it failed half way
+  if (plan.fused) HIP_TRY(c, hipMemsetAsync(c->overflow_count, 0, c->overflow_jobs_cap * sizeof(uint32_t), c->stream));
   return MI355_ICP_OK;
 }
 
@@ -431,6 +450,28 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   }
   plan.out_total = static_cast<uint32_t>(out_off);
   plan.partial_total = static_cast<uint32_t>(partial_off);
+  // Small all-exact launches (the coarse pyramid levels of reference mode, small models): even one workgroup per
+  // (512 source slots, tile) leaves most of the chip idle while each of them works through 1024 x 512 pairs on one
+  // CU - ~37 us whatever the cloud holds.  Cut every tile into 2, 4 or 8 runs of chunks, one workgroup each, until the
+  // launch has a few thousand of them (6 x 20k<->100k with the reference's parameters: 11 such passes per request).
+  if (!plan.fused && !plan.pruned && !c->scan_sgpr) {
+    uint64_t wgs = 0;
+    for (const JobDesc& J : plan.jobs) wgs += static_cast<uint64_t>(J.scan_blocks) * J.tgt_tiles;
+    uint32_t sub = 1;
+    while (sub < 8 && wgs * sub < 4096) sub *= 2;
+    if (sub > 1) {
+      plan.merged_keys = true;
+      plan.max_split = 1;  // key rows: the workgroups of a point merge into one (atomicMin)
+      plan.max_blocks_x = 0;
+      for (JobDesc& J : plan.jobs) {
+        J.sub_split = sub;
+        J.n_split = J.tgt_tiles * sub;
+        J.split_q = 1;  // unused by the kernel in this mode; kept consistent for readers of the descriptor
+        J.split_r = 0;
+        plan.max_blocks_x = std::max(plan.max_blocks_x, J.scan_blocks * J.n_split);
+      }
+    }
+  }
   if (plan.pruned)  // the pruned kernel keeps a bitmap of needed tiles in LDS
     for (const JobDesc& J : plan.jobs)
       if (J.tgt_tiles > kPrunedMaxTiles) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "MI355_ICP_SCAN_MODE=pruned: a target cloud has more than 16M points");
@@ -487,6 +528,7 @@ int run_overflow_fallback(mi355_icp_ctx* c, const Plan& plan, int n_active, cons
     const uint32_t padded = (n + kSrcPad - 1) / kSrcPad * kSrcPad;
     launch_gather_points(c->stream, S, M.src_off, c->overflow_list + M.out_off, n, c->fb_planes + off, padded_total, padded);
     JobDesc J = M;
+    J.sub_split = 0;
     J.src_off = static_cast<uint32_t>(off);
     J.src_n = n;
     J.src_blocks = (n + kSrcPerBlock - 1) / kSrcPerBlock;
@@ -655,7 +697,6 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
     launch_nn_scan_fused(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, T, c->keys3, plan.out_total, rank_stride);
   }
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-  HIP_TRY(c, hipMemsetAsync(c->overflow_count, 0, static_cast<size_t>(n_active) * sizeof(uint32_t), c->stream));
   if (sbx && xf) {
     const float* xp = X.planes;
     const size_t st = xstride;
@@ -669,8 +710,7 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
                          c->out_dist2, c->partials, c->overflow_list, c->overflow_count, c->error_flag);
   }
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(c->overflow_count_host, c->overflow_count, static_cast<size_t>(n_active) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  if (defer) {
+  if (defer) {  // the counts reach the host with the sums (final-reduce kernels), after the pass's one synchronisation
     if (sbx && xf) {  // a sorted copy with tile spheres exists: only the tiles a point can still reach (any target size)
       const float* xp = X.planes;
       launch_overflow_tiles(c->stream, c->jobs_dev, n_active, kOverflowCap, S, DevicePlanes{xp + 4 * xstride, xp + 5 * xstride, xp + 6 * xstride},
@@ -682,6 +722,7 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
     HIP_TRY(c, hipGetLastError());
     return MI355_ICP_OK;
   }
+  HIP_TRY(c, hipMemcpyAsync(c->overflow_count_host, c->overflow_count, static_cast<size_t>(n_active) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   bool any = false;
   for (int k = 0; k < n_active; ++k) any = any || c->overflow_count_host[k] != 0;
@@ -689,17 +730,13 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
   return MI355_ICP_OK;
 }
 
-// After the final synchronisation of a pass that deferred its overflow handling: were all counts within what the device
-// pass covers?  (If not, the caller repeats the pass with the host path.)
-bool overflow_within_cap(const mi355_icp_ctx* c, int n_active) {
-  bool ok = true;
-  for (int k = 0; k < n_active; ++k) ok = ok && c->overflow_count_host[k] <= kOverflowCap;
-  return ok;
-}
-void book_overflow(mi355_icp_ctx* c, int n_active) {
+// After the final synchronisation of a pass that deferred its overflow handling: `counts` is the tail the final-reduce
+// kernel wrote behind the sums (one double per job; the flags beside it say whether any exceeded what the device pass
+// covers - then the caller repeats the pass with the host path and nothing is booked here).
+void book_overflow(mi355_icp_ctx* c, const double* counts, int n_active) {
   for (int k = 0; k < n_active; ++k) {
-    c->overflow_points_total += c->overflow_count_host[k];
-    c->prof.overflow_points += c->overflow_count_host[k];
+    c->overflow_points_total += static_cast<uint64_t>(counts[k]);
+    c->prof.overflow_points += static_cast<uint64_t>(counts[k]);
   }
 }
 
@@ -731,7 +768,7 @@ int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, boo
 
 int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only, bool defer, bool* retry) {
   *retry = false;
-  HIP_TRY(c, hipMemcpyAsync(c->jobs_dev, c->jobs_host, static_cast<size_t>(n_active) * sizeof(JobDesc), hipMemcpyHostToDevice, c->stream));
+  if (stage_jobs(c->stream, c->jobs_host, nullptr, n_active, c->jobs_dev, nullptr) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
   uint32_t bx = 0, sbx = 0;
   double pairs = 0.0;
   for (int k = 0; k < n_active; ++k) {
@@ -759,35 +796,34 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if (sbx) launch_accumulate(c->stream, c->jobs_dev, n_active, sbx, S, T, c->out_index, c->out_dist2, c->partials);
   } else {
+    if (plan.merged_keys) HIP_TRY(c, hipMemsetAsync(c->keys, 0xFF, static_cast<size_t>(plan.out_total) * sizeof(unsigned long long), c->stream));
     if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
     if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   }
-  launch_final_reduce(c->stream, c->jobs_dev, n_active, c->partials, c->sums_dev);
+  // sums_dev: [n x 17 sums][n overflow-excess flags][n overflow counts]
+  launch_final_reduce(c->stream, c->jobs_dev, n_active, c->partials, c->sums_dev, plan.fused ? c->overflow_count : nullptr,
+                      defer ? kOverflowCap : 0xFFFFFFFFu);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
   HIP_TRY(c, hipGetLastError());
   const bool exchange = c->comm.attached() && !local_only;
-  const size_t n_sums = static_cast<size_t>(n_active) * MI355_ICP_NSUMS;
-  if (exchange) {
+  const size_t n_sums = static_cast<size_t>(n_active) * MI355_ICP_NSUMS, n_act = static_cast<size_t>(n_active);
+  if (exchange) {  // the rows and the flags: every rank learns whether ANY rank's device-side overflow pass was too small
     const char* why = nullptr;
-    double* flags = c->sums_dev + n_sums;
-    if (defer) launch_overflow_excess(c->stream, c->overflow_count, kOverflowCap, n_active, flags);
-    else HIP_TRY(c, hipMemsetAsync(flags, 0, static_cast<size_t>(n_active) * sizeof(double), c->stream));
-    const int cst = comm_sum_f64_rank_order(c->comm, c->sums_dev, n_sums + static_cast<size_t>(n_active), c->stream, &why);
+    const int cst = comm_sum_f64_rank_order(c->comm, c->sums_dev, n_sums + n_act, c->stream, &why);
     if (cst != MI355_ICP_OK) return fail(c, cst == MI355_ICP_ERR_HIP ? MI355_ICP_ERR_HIP : MI355_ICP_ERR_COMM, std::string("cross-rank exchange: ") + (why ? why : "?"));
   }
-  HIP_TRY(c, hipMemcpyAsync(c->sums_host, c->sums_dev, (n_sums + (exchange ? static_cast<size_t>(n_active) : 0)) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->sums_host, c->sums_dev, (n_sums + 2 * n_act) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (const int sst = sync_pass(c); sst != MI355_ICP_OK) return sst;
   if (defer) {
-    bool settled = overflow_within_cap(c, n_active);
-    if (exchange)  // the decision must be the same on every rank: was any flag raised anywhere?
-      for (int k = 0; k < n_active; ++k) settled = settled && c->sums_host[n_sums + static_cast<size_t>(k)] == 0.0;
+    bool settled = true;  // the decision must be the same on every rank: the flags are summed over the ranks
+    for (size_t k = 0; k < n_act; ++k) settled = settled && c->sums_host[n_sums + k] == 0.0;
     if (!settled) {
       *retry = true;
       return MI355_ICP_OK;
     }
-    book_overflow(c, n_active);
+    book_overflow(c, c->sums_host + n_sums + n_act, n_active);
   }
   c->prof.iterations += 1;
   c->prof.pairs_evaluated += pairs;
@@ -854,6 +890,7 @@ DevicePlanes level_view(const CloudSet& set, int level) { return level ? set.lev
 
 int ensure_ref_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs, size_t owner_total) {
   int st;
+  if (std::max<size_t>(owner_total, 1) > c->owner_cap) c->owner_epoch = 0;  // a fresh table holds garbage: clear before use
   if ((st = grow(c, c->owner, c->owner_cap, std::max<size_t>(owner_total, 1))) != MI355_ICP_OK) return st;
   if ((st = grow(c, c->selected, c->selected_cap, std::max<size_t>(plan.out_total, 1))) != MI355_ICP_OK) return st;
   if ((st = grow(c, c->ref_partials, c->ref_partials_cap, static_cast<size_t>(std::max<uint32_t>(plan.partial_total, 1)) * kRefSums)) != MI355_ICP_OK) return st;
@@ -866,14 +903,17 @@ int ensure_ref_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs, size_t
     if (c->thr_host) { HIP_TRY(c, hipHostFree(c->thr_host)); c->thr_host = nullptr; }
     c->ref_jobs_cap = 0;
     const size_t want = std::max<size_t>(n_jobs, 8) * 2;
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->ref_sums_dev), want * kRefSums * sizeof(double)));
+    // + three doubles per job behind the rows: overflow-excess flag, rejection threshold, overflow count (ref_final_reduce_kernel)
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->ref_sums_dev), want * (kRefSums + 3) * sizeof(double)));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->thr_dev), want * sizeof(float)));
     if (c->select_work) { HIP_TRY(c, hipFree(c->select_work)); c->select_work = nullptr; }
+    // [want x 2048 histogram bins][want x 4 words of selection state]: the histograms form one block a slab-sharded pass
+    // adds up across ranks
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->select_work), want * (2048 + 4) * sizeof(uint32_t)));
     HIP_TRY(c, hipMemsetAsync(c->select_work, 0, want * (2048 + 4) * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->rjobs_dev), want * sizeof(RefJobDesc)));
     HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->rjobs_host), want * sizeof(RefJobDesc), hipHostMallocDefault));
-    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->ref_sums_host), want * kRefSums * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->ref_sums_host), want * (kRefSums + 3) * sizeof(double), hipHostMallocDefault));
     HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->thr_host), want * sizeof(float), hipHostMallocDefault));
     c->ref_jobs_cap = want;
   }
@@ -896,8 +936,14 @@ int run_ref_pass(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, fl
 int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, float rejection_scale, size_t owner_total,
                       bool profile, bool defer, bool* retry) {
   *retry = false;
-  HIP_TRY(c, hipMemcpyAsync(c->jobs_dev, c->jobs_host, static_cast<size_t>(n_active) * sizeof(JobDesc), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->rjobs_dev, c->rjobs_host, static_cast<size_t>(n_active) * sizeof(RefJobDesc), hipMemcpyHostToDevice, c->stream));
+  // this pass's tag of the owner keys: one smaller prefix per pass, the table cleared once per 63 passes (picky_key)
+  if (c->owner_epoch == 0 || c->owner_epoch >= 63) {
+    HIP_TRY(c, hipMemsetAsync(c->owner, 0xFF, c->owner_cap * sizeof(unsigned long long), c->stream));
+    c->owner_epoch = 0;
+  }
+  c->owner_epoch += 1;
+  for (int k = 0; k < n_active; ++k) c->rjobs_host[k].owner_prefix = 63u - c->owner_epoch;
+  if (stage_jobs(c->stream, c->jobs_host, c->rjobs_host, n_active, c->jobs_dev, c->rjobs_dev) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
   uint32_t bx = 0, sbx = 0;
   double pairs = 0.0;
   for (int k = 0; k < n_active; ++k) {
@@ -922,36 +968,62 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
     const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile, defer);
     if (fst != MI355_ICP_OK) return fst;
   } else {
+    if (plan.merged_keys) HIP_TRY(c, hipMemsetAsync(c->keys, 0xFF, static_cast<size_t>(plan.out_total) * sizeof(unsigned long long), c->stream));
     if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
     if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
   }
+  const bool sharded = c->comm.attached();
+  const char* why = nullptr;
   if (rejection_scale > 0.0f) {
     uint32_t max_n = 0;
     for (int k = 0; k < n_active; ++k) max_n = std::max(max_n, c->jobs_host[k].src_n);
-    launch_rejection_select(c->stream, c->jobs_dev, n_active, max_n, c->out_dist2, rejection_scale, c->thr_dev, c->select_work);
+    if (!sharded) {
+      launch_rejection_select(c->stream, c->jobs_dev, n_active, max_n, c->out_dist2, rejection_scale, c->thr_dev, c->select_work, c->select_work + c->ref_jobs_cap * 2048);
+    } else {
+      // slab-sharded: the median and the MAD are those of ALL ranks' distances - every rank histograms its slab, the
+      // 2048-bin counts are added across ranks (integers: exact in any order), every rank picks the same digit
+      for (int pass = 0; pass < 6; ++pass) {
+        launch_select_hist(c->stream, c->jobs_dev, n_active, max_n, c->out_dist2, c->select_work, c->select_work + c->ref_jobs_cap * 2048, pass);
+        const int cst = comm_sum_u32(c->comm, c->select_work, static_cast<size_t>(n_active) * 2048, c->stream, &why);
+        if (cst != MI355_ICP_OK) return fail(c, cst, std::string("cross-rank histogram: ") + (why ? why : "?"));
+        launch_select_pick(c->stream, c->jobs_dev, n_active, c->select_work, c->select_work + c->ref_jobs_cap * 2048, pass, rejection_scale, c->thr_dev);
+      }
+    }
   } else {
     for (int k = 0; k < n_active; ++k) c->thr_host[k] = std::numeric_limits<float>::infinity();
     HIP_TRY(c, hipMemcpyAsync(c->thr_dev, c->thr_host, static_cast<size_t>(n_active) * sizeof(float), hipMemcpyHostToDevice, c->stream));
   }
-  HIP_TRY(c, hipMemsetAsync(c->owner, 0xFF, std::max<size_t>(owner_total, 1) * sizeof(unsigned long long), c->stream));
-  if (sbx) {
-    launch_picky_scatter(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, c->out_index, c->out_dist2, c->thr_dev, c->owner);
-    launch_ref_accumulate(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, S, T, c->targets.normal_view(), c->out_index,
-                          c->out_dist2, c->thr_dev, c->owner, c->selected, c->ref_partials);
+  if (sbx || sharded) {
+    if (sbx) launch_picky_scatter(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, c->out_index, c->out_dist2, c->thr_dev, c->owner);
+    if (sharded) {  // targets are replicated: the owner of a target is the smallest key any rank offered
+      const int cst = comm_min_u64(c->comm, c->owner, std::max<size_t>(owner_total, 1), c->stream, &why);
+      if (cst != MI355_ICP_OK) return fail(c, cst, std::string("cross-rank owner table: ") + (why ? why : "?"));
+    }
+    if (sbx) launch_ref_accumulate(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, S, T, c->targets.normal_view(), c->out_index,
+                                   c->out_dist2, c->thr_dev, c->owner, c->selected, c->ref_partials);
   }
-  launch_ref_final_reduce(c->stream, c->jobs_dev, n_active, c->ref_partials, c->ref_sums_dev);
+  // ref_sums_dev: [n x 29 sums][n overflow-excess flags][n thresholds][n overflow counts]
+  launch_ref_final_reduce(c->stream, c->jobs_dev, n_active, c->ref_partials, c->ref_sums_dev, c->thr_dev, plan.fused ? c->overflow_count : nullptr,
+                          defer ? kOverflowCap : 0xFFFFFFFFu);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(c->ref_sums_host, c->ref_sums_dev, static_cast<size_t>(n_active) * kRefSums * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->thr_host, c->thr_dev, static_cast<size_t>(n_active) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const size_t n_sums = static_cast<size_t>(n_active) * kRefSums, n_act = static_cast<size_t>(n_active);
+  if (sharded) {
+    const int cst = comm_sum_f64_rank_order(c->comm, c->ref_sums_dev, n_sums + n_act, c->stream, &why);
+    if (cst != MI355_ICP_OK) return fail(c, cst == MI355_ICP_ERR_HIP ? MI355_ICP_ERR_HIP : MI355_ICP_ERR_COMM, std::string("cross-rank exchange: ") + (why ? why : "?"));
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->ref_sums_host, c->ref_sums_dev, (n_sums + 3 * n_act) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (const int sst = sync_pass(c); sst != MI355_ICP_OK) return sst;
+  for (size_t k = 0; k < n_act; ++k) c->thr_host[k] = static_cast<float>(c->ref_sums_host[n_sums + n_act + k]);
   if (defer) {
-    if (!overflow_within_cap(c, n_active)) {
+    bool settled = true;
+    for (size_t k = 0; k < n_act; ++k) settled = settled && c->ref_sums_host[n_sums + k] == 0.0;
+    if (!settled) {
       *retry = true;
       return MI355_ICP_OK;
     }
-    book_overflow(c, n_active);
+    book_overflow(c, c->ref_sums_host + n_sums + 2 * n_act, n_active);
   }
   c->prof.iterations += 1;
   c->prof.pairs_evaluated += pairs;

@@ -97,7 +97,12 @@ struct JobDesc {
   float max_d2;              // accept a pair iff d2 <= max_d2 (+inf keeps all)
   uint32_t scan_blocks;      // ceil(src_n / (256 * points_per_lane)): scan workgroups along the source
   float pose[12];            // float32 rounding of the row-major 3x4 [R|t] the pass is evaluated under
-  uint32_t pad_[3];
+  uint32_t sub_split;        // all-exact scan of SMALL launches only: > 1 cuts every tile into this many runs of chunks, one
+                             // workgroup each (n_split = tgt_tiles * sub_split; 0 or 1 = whole tiles).  A tile is 1024
+                             // targets x 512 source slots: tens of microseconds on one CU whatever the cloud holds, which is
+                             // what a pass costs on the coarse pyramid levels of reference mode unless it is cut finer.
+  uint32_t src_n_total;      // slab-sharded reference mode: points of the WHOLE level cloud over all ranks (0 = src_n)
+  uint32_t pad_;
 };
 static_assert(sizeof(JobDesc) == 112, "JobDesc layout");
 
@@ -107,10 +112,24 @@ struct RefJobDesc {
   uint32_t owner_off;    // first slot of this job's target in the picky owner table
   uint32_t normal_off;   // first point of the job's target cloud in the LEVEL-0 normal planes
   uint32_t step;         // level stride: level point j is level-0 point j * step
-  uint32_t pad_;
+  uint32_t owner_prefix; // this pass's tag in the owner keys (picky_key): smaller in every later pass
+  uint32_t src_index_base;  // index, in the WHOLE level cloud, of this rank's first level point (0 unless slab-sharded)
+  uint32_t pad_[3];
   float pose_start[12];  // float32 pose the level started from (defines the point the plane equation is written for)
 };
-static_assert(sizeof(RefJobDesc) == 64, "RefJobDesc layout");
+static_assert(sizeof(RefJobDesc) == 80, "RefJobDesc layout");
+
+// "Picky" owner key of an accepted pair: atomicMin over these makes the smallest distance win, the lowest source index on
+// ties.  The 6-bit prefix is the pass's tag, DEcreasing from pass to pass, so a key of this pass beats whatever an earlier
+// pass (or another job or level that used the slot) left behind and the table needs no clearing between passes - only once
+// per 63 passes, when the tag wraps (all-ones = "never written" sorts after every tag).  31 bits of distance (finite
+// non-negative float32 bits are < 2^31), 27 bits of source index: 134M points per model.
+constexpr uint32_t kPickyIndexBits = 27;
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned long long picky_key(uint32_t prefix, float d, uint32_t source_index) {
+  return (static_cast<unsigned long long>(prefix) << 58) | (static_cast<unsigned long long>(__float_as_uint(d)) << kPickyIndexBits) | source_index;
+}
+#endif
 
 int solve_point_to_plane(const double* sums29, double* x6);
 void euler_pose(const double* x6, double* pose16);
@@ -191,12 +210,17 @@ void launch_scatter_results(void* stream, const uint32_t* list, uint32_t n, cons
 void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
                     DevicePlanes tgt, const unsigned long long* keys, uint32_t key_stride, int32_t* out_index,
                     float* out_dist2, double* partials, uint32_t* error_flag);
-void launch_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums);
+void launch_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums,
+                         uint32_t* overflow_count, uint32_t overflow_cap);
 
 void launch_subsample(void* stream, const float* in, size_t in_stride, uint32_t in_off, float* out, size_t out_stride,
                       uint32_t out_off, uint32_t n_level, uint32_t n_padded, uint32_t step, float pad);
 void launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_n, const float* dist2, float scale,
-                             float* thr, uint32_t* work);
+                             float* thr, uint32_t* hists, uint32_t* states);
+void launch_select_hist(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_n, const float* dist2, uint32_t* hists,
+                        uint32_t* states, int pass);
+void launch_select_pick(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t* hists, uint32_t* states, int pass, float scale,
+                        float* thr);
 void launch_picky_scatter(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
                           uint32_t max_src_blocks, const int32_t* index, const float* dist2, const float* thr,
                           unsigned long long* owner);
@@ -204,7 +228,8 @@ void launch_ref_accumulate(void* stream, const JobDesc* jobs_dev, const RefJobDe
                            uint32_t max_src_blocks, DevicePlanes src, DevicePlanes tgt, DevicePlanes normals,
                            const int32_t* index, const float* dist2, const float* thr, const unsigned long long* owner,
                            uint8_t* selected, double* partials);
-void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums);
+void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums, const float* thr,
+                             uint32_t* overflow_count, uint32_t overflow_cap);
 
 // ---- sorted / tile-centred target copy for the expansion filter (xtarget_kernels.hip) ----
 int xtarget_sort_temp_bytes(uint32_t n, size_t* bytes);
@@ -262,8 +287,7 @@ int comm_min_u64(CommState& cs, unsigned long long* dev_buf, size_t count, void*
 // host-side all-gather of a few bytes per rank (cloud sizes at the start of a sharded reference-mode call)
 int comm_allgather_host(CommState& cs, const void* send, void* recv, size_t bytes_per_rank, void* stream, const char** err);
 void comm_release(CommState& cs);  // frees the staging buffers and destroys a native communicator
-// out[k] = counts[k] > cap ? 1.0 : 0.0 (rides along with the sums so that every rank learns whether ANY rank's
-// device-side overflow pass was too small, and all of them repeat the pass through the host path together)
-void launch_overflow_excess(void* stream, const uint32_t* counts, uint32_t cap, int n, double* out);
+// this pass's job descriptors (and reference-mode descriptors, or nullptr) to the device tables, asynchronously on `stream`
+int stage_jobs(void* stream, const JobDesc* jobs_host, const RefJobDesc* rjobs_host, int n, JobDesc* jobs_dev, RefJobDesc* rjobs_dev);
 
 }  // namespace mi355

@@ -97,8 +97,17 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
   // balanced runs of tiles (all non-empty because n_split <= tgt_tiles); sp is the fast index of blockIdx.x and
   // n_split is 1, 2, 4 or a multiple of 8, so workgroups b and b+8 (one XCD: MI355X_MICROARCH.md "Workgroup
   // dispatch") walk the same run of target tiles at about the same time and that XCD's L2 serves the re-reads
-  const uint32_t tile0 = sp * J.split_q + (sp < J.split_r ? sp : J.split_r);
-  const uint32_t tile1 = tile0 + J.split_q + (sp < J.split_r ? 1u : 0u);
+  uint32_t tile0 = sp * J.split_q + (sp < J.split_r ? sp : J.split_r);
+  uint32_t tile1 = tile0 + J.split_q + (sp < J.split_r ? 1u : 0u);
+  // small launches (JobDesc::sub_split): split sp is one run of chunks of ONE tile
+  uint32_t chunk0 = 0, chunk1 = kChunksPerTile;
+  if (J.sub_split > 1) {
+    tile0 = sp / J.sub_split;
+    tile1 = tile0 + 1;
+    const uint32_t per = kChunksPerTile / J.sub_split;  // sub_split divides kChunksPerTile (planner)
+    chunk0 = (sp - tile0 * J.sub_split) * per;
+    chunk1 = chunk0 + per;
+  }
 
   const uint32_t tid = threadIdx.x;
   float pose[12];
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
     transform_point(pose, sx[i], sy[i], sz[i], qx[p], qy[p], qz[p]);
     best[p] = __builtin_inff();
     prev[p] = __builtin_inff();
-    cid[p] = tile0 * kChunksPerTile;
+    cid[p] = tile0 * kChunksPerTile + chunk0;
   }
 
   const float4* __restrict__ gx = reinterpret_cast<const float4*>(tx + J.tgt_off);
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
     const float4* __restrict__ LY = lds[cur][1];
     const float4* __restrict__ LZ = lds[cur][2];
     const uint32_t chunk_base = tile * kChunksPerTile;
-    for (uint32_t c = 0; c < kChunksPerTile; ++c) {
+    for (uint32_t c = chunk0; c < chunk1; ++c) {
 #pragma unroll
       for (uint32_t g = 0; g < kChunk / 4; ++g) {
         const float4 X = LX[c * (kChunk / 4) + g];  // wave-uniform address: LDS broadcast
@@ -177,12 +186,16 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
     cur ^= 1;
   }
 
-  const uint32_t out = sp * key_stride + J.out_off + sb * kScanSrcPerBlock + tid;
+  // One key row per split - except in sub_split mode, where the (many, small) workgroups of a point merge into ONE row with
+  // an integer atomicMin: the unsigned minimum of (d2 bits, chunk id) is the same whatever the order, and the resolve then
+  // reads one key per point instead of one per workgroup (the host clears the row before the launch).
+  const uint32_t out = (J.sub_split > 1 ? 0u : sp * key_stride) + J.out_off + sb * kScanSrcPerBlock + tid;
 #pragma unroll
   for (int p = 0; p < kPointsPerLane; ++p) {
     const unsigned long long key =
         (static_cast<unsigned long long>(__float_as_uint(best[p])) << 32) | static_cast<unsigned long long>(cid[p]);
-    keys[out + p * kBlockThreads] = key;
+    if (J.sub_split > 1) atomicMin(&keys[out + p * kBlockThreads], key);
+    else keys[out + p * kBlockThreads] = key;
   }
 #ifdef MI355_ICP_DIAG
   if (g_diag_stamps && threadIdx.x == 0) {
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
 #pragma unroll
   for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
   const float max_d2 = J.max_d2;
-  const uint32_t n_split = J.n_split;
+  const uint32_t n_split = J.sub_split > 1 ? 1u : J.n_split;  // sub_split mode: the scan merged its workgroups into row 0
 
   double acc[MI355_ICP_NSUMS];
 #pragma unroll
@@ -1112,9 +1125,14 @@ __global__ __launch_bounds__(kBlockThreads) void scatter_results_kernel(const ui
 // N2 final reduction: one workgroup per job sums that job's per-block partials in a fixed order
 // (thread t takes blocks t, t+256, ... ascending; then the block_sum tree), so a given cloud,
 // pose and slab always reduces to the same bits.
+// Tail of `sums` behind the n = gridDim.x rows: [n flags][n counts] - this pass's overflow count of every job (what the
+// host books after the pass's single synchronisation) and whether it exceeded what the device-side overflow pass covers
+// (slab-sharded runs add the flags up across ranks with the sums).  The counter is reset here for the next pass: every
+// kernel that adds to it or reads it in this pass has run.
 __global__ __launch_bounds__(kBlockThreads) void final_reduce_kernel(const JobDesc* __restrict__ jobs,
                                                                       const double* __restrict__ partials,
-                                                                      double* __restrict__ sums) {
+                                                                      double* __restrict__ sums, uint32_t* __restrict__ overflow_count,
+                                                                      uint32_t overflow_cap) {
   __shared__ double scratch[kBlockThreads / 64][MI355_ICP_NSUMS];
   const JobDesc& J = jobs[blockIdx.x];
   double acc[MI355_ICP_NSUMS];
@@ -1127,6 +1145,13 @@ __global__ __launch_bounds__(kBlockThreads) void final_reduce_kernel(const JobDe
   }
   const double r = block_sum<MI355_ICP_NSUMS>(acc, scratch);
   if (threadIdx.x < MI355_ICP_NSUMS) sums[static_cast<size_t>(blockIdx.x) * MI355_ICP_NSUMS + threadIdx.x] = r;
+  if (threadIdx.x == 0) {
+    double* tail = sums + static_cast<size_t>(gridDim.x) * MI355_ICP_NSUMS;
+    const uint32_t n = overflow_count ? overflow_count[blockIdx.x] : 0u;
+    tail[blockIdx.x] = n > overflow_cap ? 1.0 : 0.0;
+    tail[gridDim.x + blockIdx.x] = static_cast<double>(n);
+    if (overflow_count) overflow_count[blockIdx.x] = 0u;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1262,9 +1287,10 @@ void launch_scatter_results(void* stream, const uint32_t* list, uint32_t n, cons
                      static_cast<hipStream_t>(stream), list, n, idx_tmp, d2_tmp, out_index, out_dist2, out_off);
 }
 
-void launch_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums) {
+void launch_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums,
+                         uint32_t* overflow_count, uint32_t overflow_cap) {
   hipLaunchKernelGGL(final_reduce_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0,
-                     static_cast<hipStream_t>(stream), jobs_dev, partials, sums);
+                     static_cast<hipStream_t>(stream), jobs_dev, partials, sums, overflow_count, overflow_cap);
 }
 
 }  // namespace mi355

@@ -163,10 +163,11 @@ struct SelectState {
   uint32_t prefix, mask, k;
   float med;
 };
-constexpr uint32_t kSelectWork = 2048u + 4u;  // uint32 of scratch per job: its histogram, then its SelectState
-__device__ __forceinline__ uint32_t* select_hist_of(uint32_t* work, uint32_t job) { return work + static_cast<size_t>(job) * kSelectWork; }
-__device__ __forceinline__ SelectState* select_state_of(uint32_t* work, uint32_t job) {
-  return reinterpret_cast<SelectState*>(work + static_cast<size_t>(job) * kSelectWork + 2048u);
+// scratch: the jobs' 2048-bin histograms form one contiguous block (a slab-sharded pass adds it up across ranks between
+// the two kernels), their SelectStates another
+__device__ __forceinline__ uint32_t* select_hist_of(uint32_t* hists, uint32_t job) { return hists + static_cast<size_t>(job) * 2048u; }
+__device__ __forceinline__ SelectState* select_state_of(uint32_t* states, uint32_t job) {
+  return reinterpret_cast<SelectState*>(states + static_cast<size_t>(job) * 4u);
 }
 
 __device__ __forceinline__ float select_value(const float* __restrict__ d, uint32_t i, int stage, float med) {
@@ -176,7 +177,7 @@ __device__ __forceinline__ float select_value(const float* __restrict__ d, uint3
 
 // grid = (chunks, n_jobs), block = kSelThreads.  pass = 0..5 (3 per stage)
 __global__ __launch_bounds__(kSelThreads) void select_hist_kernel(const JobDesc* __restrict__ jobs, const float* __restrict__ dist2,
-                                                                   uint32_t* __restrict__ work, int pass) {
+                                                                   uint32_t* __restrict__ work, uint32_t* __restrict__ states, int pass) {
   __shared__ uint32_t hist[2048];
   const JobDesc& J = jobs[blockIdx.y];
   const uint32_t n = J.src_n;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(kSelThreads) void select_hist_kernel(const JobDesc*
   const int stage = pass / 3, sub = pass % 3;
   const int shift = sub == 0 ? 21 : (sub == 1 ? 10 : 0);
   const uint32_t nb = sub == 2 ? 1024u : 2048u;
-  const SelectState st = *select_state_of(work, blockIdx.y);
+  const SelectState st = *select_state_of(states, blockIdx.y);
   uint32_t* ghist = select_hist_of(work, blockIdx.y);
   const uint32_t prefix = sub == 0 ? 0u : st.prefix, mask = sub == 0 ? 0u : st.mask;
   for (uint32_t b = threadIdx.x; b < 2048; b += kSelThreads) hist[b] = 0;
@@ -201,11 +202,12 @@ __global__ __launch_bounds__(kSelThreads) void select_hist_kernel(const JobDesc*
 
 // grid = n_jobs, block = kSelThreads
 __global__ __launch_bounds__(kSelThreads) void select_pick_kernel(const JobDesc* __restrict__ jobs, uint32_t* __restrict__ work,
-                                                                   int pass, float scale, float* __restrict__ thr_out) {
+                                                                   uint32_t* __restrict__ states, int pass, float scale,
+                                                                   float* __restrict__ thr_out) {
   __shared__ uint32_t bcast[2];
   __shared__ uint32_t wave_tot[kSelThreads / 64];
   const JobDesc& J = jobs[blockIdx.x];
-  const uint32_t n = J.src_n;
+  const uint32_t n = J.src_n_total ? J.src_n_total : J.src_n;  // slab-sharded: the rank is taken among ALL ranks' values
   if (n == 0) {
     if (threadIdx.x == 0 && pass == 5) thr_out[blockIdx.x] = __builtin_inff();
     return;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(kSelThreads) void select_pick_kernel(const JobDesc*
   const int sub = pass % 3;
   const int shift = sub == 0 ? 21 : (sub == 1 ? 10 : 0);
   const uint32_t nb = sub == 2 ? 1024u : 2048u;
-  SelectState st = *select_state_of(work, blockIdx.x);
+  SelectState st = *select_state_of(states, blockIdx.x);
   const uint32_t k = sub == 0 ? (n - 1) / 2 : st.k;
   uint32_t* h = select_hist_of(work, blockIdx.x);
   const uint32_t c0 = h[2 * threadIdx.x], c1 = h[2 * threadIdx.x + 1];
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(kSelThreads) void select_pick_kernel(const JobDesc*
       const float t = scale * s;
       thr_out[blockIdx.x] = t + st.med;
     }
-    *select_state_of(work, blockIdx.x) = st;
+    *select_state_of(states, blockIdx.x) = st;
   }
 }
 
@@ -264,16 +266,15 @@ __global__ __launch_bounds__(kBlockThreads) void picky_scatter_kernel(const JobD
   const JobDesc& J = jobs[blockIdx.y];
   if (blockIdx.x >= J.src_blocks) return;
   const float t = thr[blockIdx.y];
-  const uint32_t owner_off = rjobs[blockIdx.y].owner_off;
+  const RefJobDesc& RJ = rjobs[blockIdx.y];
+  const uint32_t owner_off = RJ.owner_off;
 #pragma unroll
   for (int p = 0; p < kResolvePointsPerLane; ++p) {
     const uint32_t local = blockIdx.x * kSrcPerBlock + p * kBlockThreads + threadIdx.x;
     if (local < J.src_n) {
       const float d = dist2[J.out_off + local];
-      if (d < t) {
-        const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | local;
-        atomicMin(&owner[owner_off + static_cast<uint32_t>(index[J.out_off + local])], key);
-      }
+      if (d < t)
+        atomicMin(&owner[owner_off + static_cast<uint32_t>(index[J.out_off + local])], picky_key(RJ.owner_prefix, d, RJ.src_index_base + local));
     }
   }
 }
@@ -305,8 +306,7 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
     if (local < J.src_n) {
       const float d = dist2[J.out_off + local];
       const uint32_t j = static_cast<uint32_t>(index[J.out_off + local]);
-      const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | local;
-      const bool sel = (d < t) && owner[RJ.owner_off + j] == key;
+      const bool sel = (d < t) && owner[RJ.owner_off + j] == picky_key(RJ.owner_prefix, d, RJ.src_index_base + local);
       selected[J.out_off + local] = sel ? 1 : 0;
       if (sel) {
         const uint32_t i = J.src_off + local;
@@ -335,9 +335,12 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
   if (threadIdx.x < kRefSums) partials[static_cast<size_t>(J.partial_off + sb) * kRefSums + threadIdx.x] = r;
 }
 
+// Tail of `sums` behind the n = gridDim.x rows: [n flags][n thresholds][n counts] - see final_reduce_kernel; the rejection
+// thresholds ride along so that the pass needs ONE device-to-host copy.
 __global__ __launch_bounds__(kBlockThreads) void ref_final_reduce_kernel(const JobDesc* __restrict__ jobs,
                                                                           const double* __restrict__ partials,
-                                                                          double* __restrict__ sums) {
+                                                                          double* __restrict__ sums, const float* __restrict__ thr,
+                                                                          uint32_t* __restrict__ overflow_count, uint32_t overflow_cap) {
   __shared__ double scratch[kBlockThreads / 64][kRefSums];
   const JobDesc& J = jobs[blockIdx.x];
   double acc[kRefSums];
@@ -350,6 +353,14 @@ __global__ __launch_bounds__(kBlockThreads) void ref_final_reduce_kernel(const J
   }
   const double r = block_sum<kRefSums>(acc, scratch);
   if (threadIdx.x < kRefSums) sums[static_cast<size_t>(blockIdx.x) * kRefSums + threadIdx.x] = r;
+  if (threadIdx.x == 0) {
+    double* tail = sums + static_cast<size_t>(gridDim.x) * kRefSums;
+    const uint32_t n = overflow_count ? overflow_count[blockIdx.x] : 0u;
+    tail[blockIdx.x] = n > overflow_cap ? 1.0 : 0.0;
+    tail[gridDim.x + blockIdx.x] = static_cast<double>(thr[blockIdx.x]);  // float -> double is exact
+    tail[2 * gridDim.x + blockIdx.x] = static_cast<double>(n);
+    if (overflow_count) overflow_count[blockIdx.x] = 0u;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -361,23 +372,34 @@ void launch_subsample(void* stream, const float* in, size_t in_stride, uint32_t 
                      step, pad);
 }
 
-// max_n: largest job of the launch.  work: n_jobs * (2048 + 4) uint32 of scratch, zeroed once at allocation (the pick
-// kernel leaves the histograms clear); small launches keep the one-workgroup kernel (a dozen launches cost more).
+// max_n: largest job of the launch.  hists / states: scratch zeroed once at allocation (the pick kernel leaves the
+// histograms clear); small launches keep the one-workgroup kernel (a dozen launches cost more).
 void launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_n, const float* dist2, float scale,
-                             float* thr, uint32_t* work) {
+                             float* thr, uint32_t* hists, uint32_t* states) {
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (max_n < 65536u || !work) {
+  if (max_n < 65536u || !hists) {
     hipLaunchKernelGGL(rejection_select_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kSelThreads), 0, st, jobs_dev, dist2, scale,
                        thr);
     return;
   }
-  const uint32_t chunks = std::min<uint32_t>(256u, (max_n + 8u * kSelThreads - 1) / (8u * kSelThreads));  // >= 8 values per thread
   for (int pass = 0; pass < 6; ++pass) {
-    hipLaunchKernelGGL(select_hist_kernel, dim3(chunks, static_cast<uint32_t>(n_jobs)), dim3(kSelThreads), 0, st, jobs_dev, dist2, work,
-                       pass);
-    hipLaunchKernelGGL(select_pick_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kSelThreads), 0, st, jobs_dev, work, pass, scale,
-                       thr);
+    launch_select_hist(stream, jobs_dev, n_jobs, max_n, dist2, hists, states, pass);
+    launch_select_pick(stream, jobs_dev, n_jobs, hists, states, pass, scale, thr);
   }
+}
+
+// the two halves of one radix pass of the many-workgroup selection, separately: a slab-sharded pass adds the histograms
+// up across ranks in between
+void launch_select_hist(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_n, const float* dist2, uint32_t* hists,
+                        uint32_t* states, int pass) {
+  const uint32_t chunks = std::max<uint32_t>(1u, std::min<uint32_t>(256u, (max_n + 8u * kSelThreads - 1) / (8u * kSelThreads)));  // >= 8 values per thread
+  hipLaunchKernelGGL(select_hist_kernel, dim3(chunks, static_cast<uint32_t>(n_jobs)), dim3(kSelThreads), 0, static_cast<hipStream_t>(stream),
+                     jobs_dev, dist2, hists, states, pass);
+}
+void launch_select_pick(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t* hists, uint32_t* states, int pass, float scale,
+                        float* thr) {
+  hipLaunchKernelGGL(select_pick_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kSelThreads), 0, static_cast<hipStream_t>(stream), jobs_dev,
+                     hists, states, pass, scale, thr);
 }
 
 void launch_picky_scatter(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
@@ -396,9 +418,10 @@ void launch_ref_accumulate(void* stream, const JobDesc* jobs_dev, const RefJobDe
                      normals.x, normals.y, normals.z, index, dist2, thr, owner, selected, partials);
 }
 
-void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums) {
+void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums, const float* thr,
+                             uint32_t* overflow_count, uint32_t overflow_cap) {
   hipLaunchKernelGGL(ref_final_reduce_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0,
-                     static_cast<hipStream_t>(stream), jobs_dev, partials, sums);
+                     static_cast<hipStream_t>(stream), jobs_dev, partials, sums, thr, overflow_count, overflow_cap);
 }
 
 }  // namespace mi355
