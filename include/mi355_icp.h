@@ -154,6 +154,13 @@ int mi355_icp_set_sources(mi355_icp_ctx* ctx, int n_clouds, const float* const* 
  * `n_ranks` (sizes differ by at most one, lower ranks get the extra).  [host] */
 int mi355_icp_slab_range(size_t n, int rank, int n_ranks, size_t* begin, size_t* count);
 
+/* Slab-sharded reference mode: which points of the slab [begin, begin + count) of a cloud of n_total points belong to
+ * pyramid level `level` of the WHOLE cloud (level l keeps the global indices 0, 2^l, 2 * 2^l, ... below
+ * (n_total >> l) << l, as the single-GPU pyramid does): offset of the first one inside the slab, how many there are,
+ * the level index of the first, and the size of the whole level.  Any output may be NULL.  [host] */
+int mi355_icp_level_slab(size_t n_total, size_t begin, size_t count, int level, size_t* first_local, size_t* n_level_local,
+                         size_t* level_index_base, size_t* n_level_total);
+
 /* ---- alignment ----------------------------------------------------------- */
 
 /* Refines `n_jobs` poses in one batched call.  Job k aligns source cloud

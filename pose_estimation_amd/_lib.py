@@ -110,6 +110,8 @@ SIGNATURES = {
     "mi355_icp_set_targets": (C.c_int, [_ctx, C.c_int, _P(C.c_void_p), _P(C.c_size_t), C.c_size_t]),
     "mi355_icp_set_sources": (C.c_int, [_ctx, C.c_int, _P(C.c_void_p), _P(C.c_size_t), C.c_size_t]),
     "mi355_icp_slab_range": (C.c_int, [C.c_size_t, C.c_int, C.c_int, _P(C.c_size_t), _P(C.c_size_t)]),
+    "mi355_icp_level_slab": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _P(C.c_size_t), _P(C.c_size_t), _P(C.c_size_t),
+                                       _P(C.c_size_t)]),
     "mi355_icp_align": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _P(Params), C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355_icp_correspond": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,

@@ -13,6 +13,23 @@
 
 namespace mi355 {
 
+// Which points of the slab [begin, begin + count) of a cloud of n_total points belong to pyramid level `level` of the WHOLE
+// cloud (its points are the global indices j * 2^level, j < n_total >> level): the first one's offset inside the slab,
+// how many, the level index j of the first, and the size of the whole level.
+void level_slab(uint64_t n_total, uint64_t begin, uint64_t count, int level, uint64_t* first_local, uint64_t* n_local, uint64_t* index_base,
+                uint64_t* n_level_total) {
+  const uint64_t step = 1ull << level;
+  const uint64_t n_lvl = n_total >> level;
+  const uint64_t j_lo = (begin + step - 1) / step;
+  uint64_t j_hi = (begin + count + step - 1) / step;  // first j with j * step >= begin + count
+  if (j_hi > n_lvl) j_hi = n_lvl;
+  *n_local = j_hi > j_lo ? j_hi - j_lo : 0;
+  *first_local = *n_local ? j_lo * step - begin : 0;
+  *index_base = j_lo < n_lvl ? j_lo : n_lvl;  // a slab past the level's last point numbers from the level's end
+  *n_level_total = n_lvl;
+}
+
+
 // One-sided (Hestenes) Jacobi SVD of a 3x3: rotates column pairs of G = H V until
 // they are mutually orthogonal; then column norms are the singular values and
 // the normalised columns are U.  Robust for rank-deficient H (coplanar /
@@ -293,6 +310,18 @@ int mi355_icp_slab_range(size_t n, int rank, int n_ranks, size_t* begin, size_t*
   const size_t r = static_cast<size_t>(rank);
   *begin = r * base + (r < extra ? r : extra);
   *count = base + (r < extra ? 1 : 0);
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_level_slab(size_t n_total, size_t begin, size_t count, int level, size_t* first_local, size_t* n_level_local,
+                         size_t* level_index_base, size_t* n_level_total) {
+  if (level < 0 || level > 31 || begin > n_total || count > n_total - begin) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  uint64_t f = 0, n = 0, base = 0, all = 0;
+  mi355::level_slab(n_total, begin, count, level, &f, &n, &base, &all);
+  if (first_local) *first_local = static_cast<size_t>(f);
+  if (n_level_local) *n_level_local = static_cast<size_t>(n);
+  if (level_index_base) *level_index_base = static_cast<size_t>(base);
+  if (n_level_total) *n_level_total = static_cast<size_t>(all);
   return MI355_ICP_OK;
 }
 

@@ -49,6 +49,8 @@ struct LevelPlanes {  // compacted copy of every cloud of a set at pyramid level
   float* planes = nullptr;
   size_t stride = 0;
   std::vector<CloudEntry> clouds;
+  std::vector<uint32_t> index_base;  // per cloud: index, in the WHOLE level cloud, of this rank's first level point (0 unless sharded)
+  std::vector<uint32_t> n_total;     // per cloud: points of the whole level cloud over all ranks (= clouds[k].n unless sharded)
   XCopy xt;  // targets only
   DevicePlanes view() const { return DevicePlanes{planes, planes + stride, planes + 2 * stride}; }
 };
@@ -59,6 +61,9 @@ struct CloudSet {
   size_t stride = 0;
   std::vector<CloudEntry> clouds;
   std::vector<LevelPlanes> levels;  // levels[l - 1] = level l, built on demand by reference mode
+  // slab-sharded reference mode: the slab this rank holds of every cloud - [begin, begin + n) of `total` points - which
+  // decides WHICH of its points belong to a pyramid level (global indices 0, step, 2 step, ...).  Empty = not sharded.
+  std::vector<uint64_t> shard_begin, shard_total;
   XCopy xt;  // level-0 expansion-filter copy (targets only)
   DevicePlanes view() const { return DevicePlanes{planes, planes + stride, planes + 2 * stride}; }
   DevicePlanes normal_view() const { return DevicePlanes{normals, normals + stride, normals + 2 * stride}; }
@@ -289,6 +294,8 @@ int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* co
     free_xcopy(lv.xt);
   }
   set.levels.clear();
+  set.shard_begin.clear();
+  set.shard_total.clear();
   free_xcopy(set.xt);
   set.planes = planes;
   set.normals = normals;
@@ -796,7 +803,7 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if (sbx) launch_accumulate(c->stream, c->jobs_dev, n_active, sbx, S, T, c->out_index, c->out_dist2, c->partials);
   } else {
-    if (plan.merged_keys) HIP_TRY(c, hipMemsetAsync(c->keys, 0xFF, static_cast<size_t>(plan.out_total) * sizeof(unsigned long long), c->stream));
+    if (plan.merged_keys && plan.out_total) HIP_TRY(c, hipMemsetAsync(c->keys, 0xFF, static_cast<size_t>(plan.out_total) * sizeof(unsigned long long), c->stream));
     if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
     if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
@@ -847,17 +854,38 @@ int check_error_flag(mi355_icp_ctx* c) {
 // =====================================================================================================
 // Reference mode: pyramid + MAD rejection + picky + point-to-plane, batched over jobs.
 
-// Builds (once per upload) the compacted planes of pyramid level `level` >= 1 for every cloud of `set`.
-int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multiple, float pad_value) {
+// Builds (once per upload, and again when the sharding changes) the compacted planes of pyramid level `level` >= 1 for
+// every cloud of `set`.  shard_begin / shard_total: this rank's slab of every cloud (nullptr = the clouds are whole).
+int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multiple, float pad_value,
+                 const std::vector<uint64_t>* shard_begin = nullptr, const std::vector<uint64_t>* shard_total = nullptr) {
+  const std::vector<uint64_t> none;
+  const std::vector<uint64_t>& want_begin = shard_begin ? *shard_begin : none;
+  const std::vector<uint64_t>& want_total = shard_total ? *shard_total : none;
+  if (want_begin != set.shard_begin || want_total != set.shard_total) {  // levels built for another slab geometry: drop them
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto& lv : set.levels) {
+      if (lv.planes) HIP_TRY(c, hipFree(lv.planes));
+      free_xcopy(lv.xt);
+    }
+    set.levels.clear();
+    set.shard_begin = want_begin;
+    set.shard_total = want_total;
+  }
   while (static_cast<int>(set.levels.size()) < level) {
     const int l = static_cast<int>(set.levels.size()) + 1;
     const uint32_t step = 1u << l;
     LevelPlanes lv;
+    std::vector<uint32_t> first;
     uint64_t total = 0;
-    for (const CloudEntry& e : set.clouds) {
-      const uint32_t n = e.n / step;
-      const uint64_t padded = (static_cast<uint64_t>(n) + pad_multiple - 1) / pad_multiple * pad_multiple;
-      lv.clouds.push_back(CloudEntry{static_cast<uint32_t>(total), n, static_cast<uint32_t>(padded)});
+    for (size_t k = 0; k < set.clouds.size(); ++k) {
+      const CloudEntry& e = set.clouds[k];
+      uint64_t f = 0, n = e.n / step, base = 0, n_all = e.n / step;
+      if (!set.shard_begin.empty()) level_slab(set.shard_total[k], set.shard_begin[k], e.n, l, &f, &n, &base, &n_all);
+      const uint64_t padded = (n + pad_multiple - 1) / pad_multiple * pad_multiple;
+      lv.clouds.push_back(CloudEntry{static_cast<uint32_t>(total), static_cast<uint32_t>(n), static_cast<uint32_t>(padded)});
+      lv.index_base.push_back(static_cast<uint32_t>(base));
+      lv.n_total.push_back(static_cast<uint32_t>(n_all));
+      first.push_back(static_cast<uint32_t>(f));
       total += padded;
     }
     lv.stride = static_cast<size_t>(std::max<uint64_t>(total, pad_multiple));
@@ -865,7 +893,7 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
     hipError_t e = hipSuccess;
     if (total == 0) e = hipMemsetAsync(lv.planes, 0, 3 * lv.stride * sizeof(float), c->stream);
     for (size_t k = 0; k < set.clouds.size() && e == hipSuccess; ++k)
-      launch_subsample(c->stream, set.planes, set.stride, set.clouds[k].off, lv.planes, lv.stride, lv.clouds[k].off,
+      launch_subsample(c->stream, set.planes, set.stride, set.clouds[k].off + first[k], lv.planes, lv.stride, lv.clouds[k].off,
                        lv.clouds[k].n, lv.clouds[k].padded, step, pad_value);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) {  // the level is not adopted: give its planes back
@@ -968,7 +996,7 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
     const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile, defer);
     if (fst != MI355_ICP_OK) return fst;
   } else {
-    if (plan.merged_keys) HIP_TRY(c, hipMemsetAsync(c->keys, 0xFF, static_cast<size_t>(plan.out_total) * sizeof(unsigned long long), c->stream));
+    if (plan.merged_keys && plan.out_total) HIP_TRY(c, hipMemsetAsync(c->keys, 0xFF, static_cast<size_t>(plan.out_total) * sizeof(unsigned long long), c->stream));
     if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
     if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
@@ -1361,10 +1389,40 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
   c->err.clear();
   if (n_jobs < 1 || !init_poses || !rp) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: bad arguments");
   if (rp->iterations < 1 || rp->num_levels < 1 || rp->num_levels > 24) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: iterations >= 1 and 1 <= num_levels <= 24 required");
-  if (c->comm.attached()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: not available on a slab-sharded context (the MAD threshold needs a global selection)");
   HIP_TRY(c, hipSetDevice(c->device));
   int st = check_reference_inputs(c, n_jobs, source_ids, target_ids);
   if (st != MI355_ICP_OK) return st;
+  // Slab-sharded (a communicator is attached): every rank holds a contiguous slab of each source cloud.  The ranks tell
+  // each other their slab sizes once per call; from them every rank knows where its slab begins in the whole cloud,
+  // hence which of its points belong to a pyramid level (global indices 0, step, 2 step, ...) and their global level
+  // indices (the tie rule of the picky dedupe is "lowest source index": it must be the index in the WHOLE cloud).
+  const bool sharded = c->comm.attached();
+  std::vector<uint64_t> shard_begin, shard_total;
+  if (sharded) {
+    const size_t n_clouds = c->sources.clouds.size();
+    std::vector<uint32_t> mine(n_clouds + 1), all((n_clouds + 1) * static_cast<size_t>(c->comm.size));
+    mine[0] = static_cast<uint32_t>(n_clouds);
+    for (size_t k = 0; k < n_clouds; ++k) mine[k + 1] = c->sources.clouds[k].n;
+    const char* why = nullptr;
+    const int cst = comm_allgather_host(c->comm, mine.data(), all.data(), mine.size() * sizeof(uint32_t), c->stream, &why);
+    if (cst != MI355_ICP_OK) return fail(c, cst, std::string("align_reference: exchanging the slab sizes: ") + (why ? why : "?"));
+    shard_begin.assign(n_clouds, 0);
+    shard_total.assign(n_clouds, 0);
+    for (int r = 0; r < c->comm.size; ++r) {
+      const uint32_t* row = all.data() + static_cast<size_t>(r) * (n_clouds + 1);
+      if (row[0] != n_clouds) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: the ranks hold different numbers of source clouds");
+      for (size_t k = 0; k < n_clouds; ++k) {
+        if (r < c->comm.rank) shard_begin[k] += row[k + 1];
+        shard_total[k] += row[k + 1];
+      }
+    }
+    for (size_t k = 0; k < n_clouds; ++k)
+      if (shard_total[k] >= (1ull << 32)) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: a sharded source cloud has 2^32 points or more");
+  }
+  // points of the whole (all ranks) source cloud `s` on pyramid level `level`, and this rank's part of it
+  auto level_total = [&](int s, int level) -> uint64_t {
+    return (sharded ? shard_total[static_cast<size_t>(s)] : c->sources.clouds[static_cast<size_t>(s)].n) >> level;
+  };
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
   c->call_pruned = (rp->flags & MI355_ICP_FLAG_PRUNED_SCAN) != 0;
   const bool profile = c->profile_always || (rp->flags & MI355_ICP_FLAG_PROFILE) != 0;
@@ -1385,14 +1443,16 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
     std::vector<int> part, psid, ptid;
     for (int k = 0; k < n_jobs; ++k) {
       if (js[k].status != MI355_ICP_OK) continue;
-      const uint32_t ns_l = c->sources.clouds[sid(k)].n / step, nt_l = c->targets.clouds[tid(k)].n / step;
-      if (ns_l < 6 || nt_l < 1) continue;
+      const uint64_t ns_l = level_total(sid(k), level);
+      const uint32_t nt_l = c->targets.clouds[tid(k)].n / step;
+      if (ns_l < 6 || nt_l < 1) continue;  // decided on the WHOLE cloud: every rank keeps the same jobs
+      if (ns_l >= (1ull << kPickyIndexBits)) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: more than 2^27 model points on a level (picky owner keys hold 27 index bits)");
       part.push_back(k);
       psid.push_back(sid(k));
       ptid.push_back(tid(k));
     }
     if (part.empty()) continue;
-    if ((st = ensure_level(c, c->sources, level, kSrcPad, 0.0f)) != MI355_ICP_OK) return st;
+    if ((st = ensure_level(c, c->sources, level, kSrcPad, 0.0f, sharded ? &shard_begin : nullptr, sharded ? &shard_total : nullptr)) != MI355_ICP_OK) return st;
     if ((st = ensure_level(c, c->targets, level, kTile, kTargetPad)) != MI355_ICP_OK) return st;
     Plan plan;
     const int np = static_cast<int>(part.size());
@@ -1439,6 +1499,11 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
         R.owner_off = owner_off[a];
         R.normal_off = c->targets.clouds[ptid[a]].off;
         R.step = step;
+        if (sharded) {  // global level indices and counts (level 0: the slab itself)
+          J.src_n_total = static_cast<uint32_t>(level_total(psid[a], level));
+          R.src_index_base = level ? c->sources.levels[static_cast<size_t>(level) - 1].index_base[static_cast<size_t>(psid[a])]
+                                   : static_cast<uint32_t>(shard_begin[static_cast<size_t>(psid[a])]);
+        }
         c->jobs_host[q] = J;
         c->rjobs_host[q] = R;
       }
@@ -1454,7 +1519,7 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
           continue;
         }
         euler_pose(x, L.posex);
-        const double fval = std::sqrt(sums[27]) / static_cast<double>(plan.jobs[static_cast<size_t>(a)].src_n);
+        const double fval = std::sqrt(sums[27]) / static_cast<double>(level_total(psid[a], level));  // all ranks' points of the level
         L.fval_perc = fval / L.fval_old;
         L.fval_old = fval;
         if (fval < L.fval_min) L.fval_min = fval;
@@ -1484,6 +1549,7 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
   c->err.clear();
   c->call_pruned = false;
   if (!pose_start || !pose_cur || level < 0 || level > 23) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: bad arguments");
+  if (c->comm.attached()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: a single-context diagnostic; detach the communicator (mi355_icp_align_reference is the slab-sharded entry point)");
   HIP_TRY(c, hipSetDevice(c->device));
   int st = check_reference_inputs(c, 1, &source_id, &target_id);
   if (st != MI355_ICP_OK) return st;
@@ -1721,6 +1787,8 @@ int mi355_icp_scene_commit_target(mi355_icp_ctx* c) {
     free_xcopy(lv.xt);
   }
   set.levels.clear();
+  set.shard_begin.clear();
+  set.shard_total.clear();
   free_xcopy(set.xt);
   set.planes = planes;
   set.stride = padded;

@@ -152,6 +152,8 @@ void launch_scene_to_planes(void* stream, const float* in, uint32_t n, float* pl
                             uint32_t n_padded, float pad, uint32_t* counters);
 
 // ---- host math (host_math.cpp) ----
+void level_slab(uint64_t n_total, uint64_t begin, uint64_t count, int level, uint64_t* first_local, uint64_t* n_local, uint64_t* index_base,
+                uint64_t* n_level_total);
 int solve_rigid(const double* sums, double* pose16);
 int host_update(const mi355_icp_params* p, const double* sums, int iteration, double* pose16, double* prev_mse,
                 int* out_done, int* out_converged);

@@ -609,22 +609,25 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
         uj[k] = wave_min_u32(__float_as_uint(md) == ud[k] ? mj : 0xFFFFFFFFu);
       }
     };
-    // Phase A: granule 1 of every point, four points per step (one at a time, a wave's 64 points are 64 dependent
-    // memory round trips: 0.15 ms at any size).  A step with fewer than four points left repeats its first one.
+    // Phase A: granule 1 of every point, kStep points per step (one at a time, a wave's 64 points are 64 dependent
+    // memory round trips: 0.15 ms at any size).  A step with fewer than kStep points left repeats its first one.
+    // kStep = 8 for the 128-target granule of the matrix-core filter: 8 x 2 x 4 loads in flight per lane, 8 round trips
+    // per wave (6 x 20k points against 100k targets: 48 -> ~30 us; the 64-target granule keeps 4 x 1 x 4).
+    constexpr int kStep = kRun >= 128 ? 8 : 4;
     unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
     while (todo) {
-      int s[4];
-      bool real[4];
+      int s[kStep];
+      bool real[kStep];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < kStep; ++k) {
         real[k] = todo != 0;
         s[k] = real[k] ? __builtin_ctzll(todo) : s[0];
         todo &= todo - (todo != 0);
       }
-      uint32_t ud[4], uj[4];
-      scan_granules(std::integral_constant<int, 4>{}, s, g1, ud, uj);
+      uint32_t ud[kStep], uj[kStep];
+      scan_granules(std::integral_constant<int, kStep>{}, s, g1, ud, uj);
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < kStep; ++k)
         if (real[k] && lane == static_cast<uint32_t>(s[k])) {
           res_d = ud[k];
           res_j = uj[k];

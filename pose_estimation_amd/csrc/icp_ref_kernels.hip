@@ -127,9 +127,12 @@ __device__ uint32_t radix_select(uint32_t n, uint32_t k, uint32_t* hist /* 2048 
 }
 
 // grid = n_jobs, block = kSelThreads.  thr[job] = scale * (1.48257968f * median|d2 - med|) + med, float32 ops as the oracle.
+// The six radix passes re-read the job's distances; the first `cache_n` of them are kept in LDS (dynamic, up to 128 KiB of
+// the CU's 160) so that global memory is walked once instead of six times (20k points: 31 -> ~15 us).
 __global__ __launch_bounds__(kSelThreads) void rejection_select_kernel(const JobDesc* __restrict__ jobs,
                                                                         const float* __restrict__ dist2, float scale,
-                                                                        float* __restrict__ thr_out) {
+                                                                        float* __restrict__ thr_out, uint32_t cache_n) {
+  extern __shared__ float cache[];
   __shared__ uint32_t hist[2048];
   __shared__ uint32_t bcast[2];
   __shared__ uint32_t wave_tot[kSelThreads / 64];
@@ -140,10 +143,14 @@ __global__ __launch_bounds__(kSelThreads) void rejection_select_kernel(const Job
     return;
   }
   const float* __restrict__ d = dist2 + J.out_off;
+  const uint32_t cached = n < cache_n ? n : cache_n;
+  for (uint32_t i = threadIdx.x; i < cached; i += kSelThreads) cache[i] = d[i];
+  __syncthreads();
   const uint32_t k = (n - 1) / 2;
-  const float med = __uint_as_float(radix_select(n, k, hist, bcast, wave_tot, [&](uint32_t i) { return d[i]; }));
+  const float med = __uint_as_float(radix_select(n, k, hist, bcast, wave_tot, [&](uint32_t i) { return i < cached ? cache[i] : d[i]; }));
   const float mad = __uint_as_float(radix_select(n, k, hist, bcast, wave_tot, [&](uint32_t i) {
-    return static_cast<float>(__builtin_fabs(static_cast<double>(d[i]) - static_cast<double>(med)));
+    const float v = i < cached ? cache[i] : d[i];
+    return static_cast<float>(__builtin_fabs(static_cast<double>(v) - static_cast<double>(med)));
   }));
   if (threadIdx.x == 0) {
     const float s = 1.48257968f * mad;
@@ -378,8 +385,11 @@ void launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, 
                              float* thr, uint32_t* hists, uint32_t* states) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (max_n < 65536u || !hists) {
-    hipLaunchKernelGGL(rejection_select_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kSelThreads), 0, st, jobs_dev, dist2, scale,
-                       thr);
+    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(rejection_select_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+    const uint32_t cache_n = std::min<uint32_t>(max_n, big_lds ? 32768u : 12288u);
+    hipLaunchKernelGGL(rejection_select_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kSelThreads), cache_n * sizeof(float), st, jobs_dev,
+                       dist2, scale, thr, cache_n);
     return;
   }
   for (int pass = 0; pass < 6; ++pass) {

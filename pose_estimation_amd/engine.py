@@ -50,6 +50,15 @@ def slab_range(n: int, rank: int, n_ranks: int) -> tuple[int, int]:
     return b.value, c.value
 
 
+def level_slab(n_total: int, begin: int, count: int, level: int) -> tuple[int, int, int, int]:
+    """(first_local, n_level_local, level_index_base, n_level_total) of a slab on a pyramid level (mi355_icp_level_slab)."""
+    f, n, b, t = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+    st = lib.mi355_icp_level_slab(n_total, begin, count, level, C.byref(f), C.byref(n), C.byref(b), C.byref(t))
+    if st != _lib.OK:
+        raise IcpError(st, "level_slab")
+    return f.value, n.value, b.value, t.value
+
+
 def solve_rigid(sums: np.ndarray) -> np.ndarray:
     sums = np.ascontiguousarray(sums, dtype=np.float64)
     assert sums.shape == (NSUMS,)

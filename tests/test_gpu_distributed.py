@@ -23,6 +23,76 @@ def _free_port():
     return port
 
 
+def _ref_worker(rank, world, port, q):
+    """Slab-sharded REFERENCE mode (pyramid, MAD rejection, picky, point-to-plane) through the engine's own loop: global
+    rank select by summed histograms, owner table reduced with min, rank-ordered 29 sums - over a gloo all-gather."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import pose_estimation_amd as pa
+    from pose_estimation_amd import distributed as pd
+    import synth_twin as st
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        targets, slabs = [], []
+        for k, (ns, nt) in enumerate(REF_SIZES):
+            targets.append(pa.synth_cloud(st.TARGET_SEED + 16 * k, nt, normals=True))
+            b, c = pa.slab_range(ns, rank, world)
+            slabs.append(pa.synth_cloud(st.SOURCE_SEED + 16 * k, c, first_index=b, noise_seed=st.NOISE_SEED + 16 * k,
+                                        sigma=st.SIGMA, transform=st.perturbation(k)))
+        with pa.IcpEngine(0) as eng:
+            eng.set_targets(targets)
+            eng.set_sources(slabs)
+            pd.attach_external_comm(eng)
+            res = eng.align_reference(np.stack(REF_INITS), 120, 0.005, 2.5, 6, source_ids=REF_IDS, target_ids=REF_IDS)
+            eng.comm_detach()
+        q.put((rank, res.poses, res.residual, res.passes, res.status))
+    finally:
+        dist.destroy_process_group()
+
+
+REF_SIZES = ((40001, 60000), (9777, 21000))      # sizes that do not divide by the rank count or the level strides
+REF_IDS = [0, 1, 0]
+REF_INITS = [np.eye(4), np.eye(4), np.array([[1, 0, 0, 0.01], [0, 1, 0, -0.02], [0, 0, 1, 0.015], [0, 0, 0, 1.0]])]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_sharded_reference_mode_matches_the_single_process_engine_and_the_oracle(engine, world):
+    import torch.multiprocessing as mp
+    import pose_estimation_amd as pa
+    import oracle_lib as ora
+    import synth_twin as st
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ref_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for other in got[1:]:      # every rank holds the same bits
+        assert np.array_equal(other[1], got[0][1]) and np.array_equal(other[2], got[0][2]) and np.array_equal(other[3], got[0][3])
+    _, poses, residual, passes, status = got[0]
+    tgts = [pa.synth_cloud(st.TARGET_SEED + 16 * k, nt, normals=True) for k, (ns, nt) in enumerate(REF_SIZES)]
+    srcs = [pa.synth_cloud(st.SOURCE_SEED + 16 * k, ns, noise_seed=st.NOISE_SEED + 16 * k, sigma=st.SIGMA, transform=st.perturbation(k))
+            for k, (ns, nt) in enumerate(REF_SIZES)]
+    engine.set_targets(tgts)
+    engine.set_sources(srcs)
+    one = engine.align_reference(np.stack(REF_INITS), 120, 0.005, 2.5, 6, source_ids=REF_IDS, target_ids=REF_IDS)
+    for k, sid in enumerate(REF_IDS):
+        o = ora.icp_reference(srcs[sid], tgts[sid], REF_INITS[k], 120, 0.005, 2.5, 6, nthreads=ora.max_threads())
+        assert status[k] == 0 and passes[k] == one.passes[k] == o["passes"], (k, passes[k], one.passes[k], o["passes"])
+        assert np.linalg.norm(poses[k] - one.poses[k]) <= 1e-9      # thresholds, masks and winners are identical; only the
+        assert abs(residual[k] - one.residual[k]) <= 1e-12          # association order of the 29 sums differs
+        assert np.linalg.norm(poses[k] - o["pose"]) <= 1e-5
+
+
 def _worker(rank, world, port, q, native_loop=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)

@@ -1,29 +1,21 @@
-"""Randomised A/B of the matrix-core filter path (and of the optional pruned scan) against the all-exact scan (both on the GPU, bit-for-bit): clouds of
-random size, scale (1e-4 .. 1e4), offset from the origin, anisotropy and clustering, under random rigid poses.  The
-exact engine is itself pinned to the oracle by test_gpu_parity.py; this battery is about the filter's error band
-(icp_fused_kernels.hip) on geometry the named tests do not cover.  MI355_ICP_STRESS_CASES raises the case count."""
+"""Randomised battery for the matrix-core filter path, the all-exact scan and the optional pruned scan: clouds of random
+size, scale (1e-4 .. 1e4), offset from the origin, anisotropy and clustering, under random rigid poses.  Every case is
+checked against the ORACLE (exact KD-tree, every point) and the three HIP paths against each other, bit for bit; this
+battery is about the filter's error band (icp_fused_kernels.hip) on geometry the named tests do not cover.
+MI355_ICP_STRESS_CASES raises the case count."""
 import os
 
 import numpy as np
 import pytest
 
+import oracle_lib as ora
 import synth_twin as st
 
 pytestmark = pytest.mark.gpu
 CASES = int(os.environ.get("MI355_ICP_STRESS_CASES", "24"))
 
 
-def engine_with_mode(mode):
-    import pose_estimation_amd as pa
-    old = os.environ.get("MI355_ICP_SCAN_MODE")
-    os.environ["MI355_ICP_SCAN_MODE"] = mode
-    try:
-        return pa.IcpEngine(0)
-    finally:
-        if old is None:
-            os.environ.pop("MI355_ICP_SCAN_MODE")
-        else:
-            os.environ["MI355_ICP_SCAN_MODE"] = old
+from gpu_util import engine_with_mode  # noqa: E402
 
 
 def random_cloud(rng, n):
@@ -63,6 +55,9 @@ def test_matrix_core_filter_equals_the_exact_scan_on_random_geometry():
                 eng.set_targets([tgt])
                 eng.set_sources([src])
                 out.append(eng.correspond(pose[None]))
+            oi, od, osums = ora.correspond(pose, src, tgt, nthreads=ora.max_threads())       # the oracle, every point
+            assert np.array_equal(out[1][0], oi), f"case {case}: all-exact scan differs from the oracle ({ns} x {nt})"
+            assert np.array_equal(out[1][1].view(np.uint32), od.view(np.uint32)), f"case {case}: all-exact distances differ from the oracle"
             assert np.array_equal(out[0][0], out[1][0]), f"case {case}: indices differ ({ns} x {nt})"
             assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32)), f"case {case}: distances differ"
             np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-11, atol=0)

@@ -126,3 +126,30 @@ def test_cpp_harness_reference_mode_matches_python_engine(engine):
         assert np.linalg.norm(poses[k] - res.poses[k]) <= 1e-7, k   # candidate builders differ in the last ulp of cos/sin
         o = ora.icp_reference(model, scene, inits[k], 250, 0.005, 2.5, 8)
         assert np.linalg.norm(poses[k] - o["pose"]) <= POSE_TOL
+
+
+def test_sharded_code_path_with_one_rank_is_bit_identical(engine):
+    """A one-rank external communicator sends every exchange of slab-sharded reference mode through the engine's
+    collective layer (histogram sum, owner-table min, rank-ordered sums, slab-size gather): the results must be the
+    single-GPU run's, bit for bit, and the threshold path switches to the many-workgroup selection."""
+    src, tgt, gt = pair6(30011, 41000)
+    engine.set_targets([tgt])
+    engine.set_sources([src])
+    init = np.stack([np.eye(4), st.rigid_transform(1.0, (0.2, 1, -0.4), (0.01, -0.02, 0.015)) @ gt])
+    ref = engine.align_reference(init, 120, 0.005, 2.5, 7, source_ids=[0, 0], target_ids=[0, 0])
+    sizes = []
+
+    def allgather(send):
+        sizes.append(len(send))
+        return bytes(send)
+
+    engine.comm_attach_external(0, 1, allgather)
+    try:
+        got = engine.align_reference(init, 120, 0.005, 2.5, 7, source_ids=[0, 0], target_ids=[0, 0])
+    finally:
+        engine.comm_detach()
+    assert np.array_equal(got.passes, ref.passes) and np.array_equal(got.poses, ref.poses) and np.array_equal(got.residual, ref.residual)
+    assert sizes[0] == 8                               # the slab sizes: (cloud count, n) as uint32
+    assert 2 * 2048 * 4 in sizes and 2 * 30 * 8 in sizes    # two jobs: histograms, and 29 sums + the flag each
+    again = engine.align_reference(init, 120, 0.005, 2.5, 7, source_ids=[0, 0], target_ids=[0, 0])   # and back to unsharded
+    assert np.array_equal(again.poses, ref.poses)
