@@ -116,27 +116,74 @@ def cpu_baseline(src, tgt, iters, iters_1thread):
     }
 
 
-def launch_ranks(n, argv, extra_env=None):
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT touching HIP or torch (the launcher must stay GPU-free): the KFD topology's
+    nodes that have SIMDs, cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.  None if it cannot be told."""
+    import glob
+    n = 0
+    try:
+        for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            for line in open(f):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except OSError:
+        return None
+    if n == 0:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def launch_ranks(n, argv, extra_env=None, check_devices=True):
     """Plain `python bench.py --gpus N` (N > 1, no WORLD_SIZE): start N fresh rank processes - one per device,
     RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set - and relay rank 0's stdout.  Called before this process imports torch or
-    touches HIP: children are ordinary child processes, never a re-exec of a GPU-initialised one.  Returns the exit code."""
+    touches HIP: children are ordinary child processes, never a re-exec of a GPU-initialised one.  A rank that dies takes
+    the others with it (they would wait for it in the rendezvous for minutes).  Returns the exit code."""
     import socket
     import subprocess
+    import tempfile
+    if check_devices:
+        have = visible_gpu_count()
+        if have is not None and have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible to this process: refusing to start the ranks", file=sys.stderr)
+            return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if out0:
-        sys.stdout.write(out0)
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if any(c not in (None, 0) for c in codes):   # one rank failed: the rest would hang in the rendezvous / a collective
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+            break
+        time.sleep(0.05)
+    out0.seek(0)
+    text = out0.read()
+    if text:
+        sys.stdout.write(text)
         sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
@@ -151,6 +198,8 @@ def launcher_selftest():
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if os.environ.get("MI355_BENCH_SELFTEST_DIE_RANK") == str(rank):
+        raise SystemExit(3)   # tests/test_bench_launcher_cpu.py: a rank that dies before the rendezvous
     dist.init_process_group("gloo", rank=rank, world_size=world)
     seen = torch.zeros(world, dtype=torch.int64)
     seen[rank] = 1 + int(os.environ["LOCAL_RANK"])
@@ -164,7 +213,7 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # nothing GPU-related has been imported yet: spawn the ranks and relay rank 0's line
-        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:], check_devices=not (a.launcher_selftest or os.environ.get("MI355_BENCH_SKIP_DEVICE_CHECK"))))
     if a.launcher_selftest:
         return launcher_selftest()
     rank = int(os.environ.get("RANK", "0"))
@@ -174,7 +223,13 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: refusing to print a mislabelled line")
     torch = dist = None
+    json_fd = 1
     if dist_mode:
+        # librccl prints a version banner on STDOUT when its first communicator comes up; the contract is ONE JSON line
+        # there.  Everything this process prints goes to stderr from here on, the line itself to the saved stdout.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -345,7 +400,8 @@ def main():
             if a.cpu_baseline_iters == a.steps:
                 out["pose_vs_cpu_frobenius"] = float(np.linalg.norm(res.poses[0] - cpu_pose))
             out["cpu_baseline"] = cb
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist_mode:
         if collective == "rccl-native":
             eng.comm_detach()

@@ -20,8 +20,8 @@ def _clean_env():
 
 @pytest.mark.timeout(300)
 def test_plain_invocation_spawns_the_ranks_and_relays_one_json_line():
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launcher-selftest"], env=_clean_env(), capture_output=True,
-                       text=True, timeout=280)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launcher-selftest"], env=dict(_clean_env(), MI355_BENCH_SKIP_DEVICE_CHECK="1"),
+                       capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -41,5 +41,24 @@ def test_a_failing_rank_fails_the_launch():
     sys.path.insert(0, ROOT)
     import bench
     # rank bodies that die at once (unknown flag): the launcher must report failure, not success with no line
-    code = bench.launch_ranks(2, ["--gpus", "2", "--no-such-flag"])
+    code = bench.launch_ranks(2, ["--gpus", "2", "--no-such-flag"], check_devices=False)
     assert code == 1
+
+
+@pytest.mark.timeout(120)
+def test_one_dead_rank_does_not_leave_the_others_waiting():
+    """Rank 1 dies at once, rank 0 would sit in the rendezvous for minutes: the launcher must end the run promptly."""
+    sys.path.insert(0, ROOT)
+    import time
+    import bench
+    t0 = time.time()
+    code = bench.launch_ranks(2, ["--gpus", "2", "--launcher-selftest"], extra_env={"MI355_BENCH_SELFTEST_DIE_RANK": "1"}, check_devices=False)
+    assert code == 1 and time.time() - t0 < 60
+
+
+def test_more_gpus_than_visible_is_refused_before_any_rank_starts(monkeypatch, capsys):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda: 1)
+    assert bench.launch_ranks(2, ["--gpus", "2"]) == 2
+    assert "only 1 GPU(s) are visible" in capsys.readouterr().err
