@@ -642,6 +642,16 @@ int run_pruned_index_phase(mi355_icp_ctx* c, int n_active, uint32_t sbx, DeviceP
   return MI355_ICP_OK;
 }
 
+// Overflow points per job the device-side pass takes before the host path has to: kOverflowCap, or 1/256 of the largest
+// active source cloud where that is more (the matrix-core filter leaves ~0.05 % of a 10^6-point cloud unsettled per pass;
+// a fixed 1024 would send every pass of a 4M-point model through the host).  The launch grid is this many workgroups per
+// job; the ones past a job's count leave at once.
+uint32_t overflow_cap(const mi355_icp_ctx* c, int n_active) {
+  uint32_t n = 0;
+  for (int k = 0; k < n_active; ++k) n = std::max(n, c->jobs_host[k].src_n);
+  return std::max<uint32_t>(kOverflowCap, n / 256u);
+}
+
 // Fused-filter path up to "index and dist2 of every point are final": filter scan -> exact resolve of the candidate
 // chunks -> (rarely) the all-exact scan for points whose candidates overflowed the band.  Records ev[1] after the scan.
 // `defer`: the points the resolve could not settle are answered on the device (overflow_exact_kernel, up to kOverflowCap
@@ -720,10 +730,10 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
   if (defer) {  // the counts reach the host with the sums (final-reduce kernels), after the pass's one synchronisation
     if (sbx && xf) {  // a sorted copy with tile spheres exists: only the tiles a point can still reach (any target size)
       const float* xp = X.planes;
-      launch_overflow_tiles(c->stream, c->jobs_dev, n_active, kOverflowCap, S, DevicePlanes{xp + 4 * xstride, xp + 5 * xstride, xp + 6 * xstride},
+      launch_overflow_tiles(c->stream, c->jobs_dev, n_active, overflow_cap(c, n_active), S, DevicePlanes{xp + 4 * xstride, xp + 5 * xstride, xp + 6 * xstride},
                             X.perm, X.table, c->overflow_list, c->overflow_count, c->out_index, c->out_dist2, c->error_flag);
     } else if (sbx) {
-      launch_overflow_exact(c->stream, c->jobs_dev, n_active, kOverflowCap, S, T, c->overflow_list, c->overflow_count, c->out_index,
+      launch_overflow_exact(c->stream, c->jobs_dev, n_active, overflow_cap(c, n_active), S, T, c->overflow_list, c->overflow_count, c->out_index,
                             c->out_dist2, c->error_flag);
     }
     HIP_TRY(c, hipGetLastError());
@@ -811,7 +821,7 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
   }
   // sums_dev: [n x 17 sums][n overflow-excess flags][n overflow counts]
   launch_final_reduce(c->stream, c->jobs_dev, n_active, c->partials, c->sums_dev, plan.fused ? c->overflow_count : nullptr,
-                      defer ? kOverflowCap : 0xFFFFFFFFu);
+                      defer ? overflow_cap(c, n_active) : 0xFFFFFFFFu);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
   HIP_TRY(c, hipGetLastError());
   const bool exchange = c->comm.attached() && !local_only;
@@ -1033,7 +1043,7 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
   }
   // ref_sums_dev: [n x 29 sums][n overflow-excess flags][n thresholds][n overflow counts]
   launch_ref_final_reduce(c->stream, c->jobs_dev, n_active, c->ref_partials, c->ref_sums_dev, c->thr_dev, plan.fused ? c->overflow_count : nullptr,
-                          defer ? kOverflowCap : 0xFFFFFFFFu);
+                          defer ? overflow_cap(c, n_active) : 0xFFFFFFFFu);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   HIP_TRY(c, hipGetLastError());
   const size_t n_sums = static_cast<size_t>(n_active) * kRefSums, n_act = static_cast<size_t>(n_active);
