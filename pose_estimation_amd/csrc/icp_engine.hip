@@ -40,6 +40,7 @@ struct XCopy {
   uint32_t* perm = nullptr;
   float* table = nullptr;
   void* bf = nullptr;
+  float* bf_table = nullptr;  // per tile: (centre x, y, z, r^2) the bf16 operand image was written around - shared by kXbCentreGroup tiles
   float* sub = nullptr;  // per 64-point run (centre x, y, z, r^2) on the uncentred coordinates: the pruned scans
   float* super = nullptr;  // per 16 tiles: a sphere around their spheres (first level of the pruned scans' tile search)
   bool valid = false;
@@ -92,6 +93,7 @@ void free_xcopy(XCopy& x) {  // the caller has drained the stream
   (void)hipFree(x.perm);
   (void)hipFree(x.table);
   (void)hipFree(x.bf);
+  (void)hipFree(x.bf_table);
   (void)hipFree(x.sub);
   (void)hipFree(x.super);
   x = XCopy{};
@@ -595,6 +597,7 @@ int ensure_xcopy(mi355_icp_ctx* c, DevicePlanes view, size_t stride, const std::
   if (!x.perm) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.perm), stride * sizeof(uint32_t)));
   if (!x.table) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.table), 4 * (stride / kTile) * sizeof(float)));
   if (!x.bf) HIP_TRY(c, hipMalloc(&x.bf, (stride / kTile) * static_cast<size_t>(kXbTileVecs) * 16));
+  if (!x.bf_table) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.bf_table), 4 * (stride / kTile) * sizeof(float)));
   if (!x.sub) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.sub), (stride / 64) * 4 * sizeof(float)));
   if (!x.super) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.super), (stride / kTile / kSuperTiles + 1) * 4 * sizeof(float)));
   uint32_t* code = c->xt_scratch;
@@ -606,10 +609,11 @@ int ensure_xcopy(mi355_icp_ctx* c, DevicePlanes view, size_t stride, const std::
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // `meta` is a pageable temporary
   launch_xt_fill(c->stream, x.planes, stride, x.perm, x.bf);
   HIP_TRY(c, hipMemsetAsync(x.table, 0, 4 * (stride / kTile) * sizeof(float), c->stream));
+  HIP_TRY(c, hipMemsetAsync(x.bf_table, 0, 4 * (stride / kTile) * sizeof(float), c->stream));
   launch_bbox(c->stream, view, meta_dev, meta_dev + n_clouds, n_clouds, max_n, c->xt_box);
   for (int k = 0; k < n_clouds; ++k)
     if (xtarget_build_cloud(c->stream, view, clouds[k].off, clouds[k].n, c->xt_box + 6 * k, code, index, code2, order, c->xt_temp,
-                            temp_bytes, x.planes, stride, x.perm, x.table, x.bf, x.sub) != 0)
+                            temp_bytes, x.planes, stride, x.perm, x.table, x.bf, x.sub, x.bf_table) != 0)
       return fail(c, MI355_ICP_ERR_HIP, "rocprim::radix_sort_pairs failed");
   launch_super_tiles(c->stream, x.table, static_cast<uint32_t>(stride / kTile), x.super);
   HIP_TRY(c, hipGetLastError());
@@ -642,14 +646,15 @@ int run_pruned_index_phase(mi355_icp_ctx* c, int n_active, uint32_t sbx, DeviceP
   return MI355_ICP_OK;
 }
 
-// Overflow points per job the device-side pass takes before the host path has to: kOverflowCap, or 1/256 of the largest
-// active source cloud where that is more (the matrix-core filter leaves ~0.05 % of a 10^6-point cloud unsettled per pass;
-// a fixed 1024 would send every pass of a 4M-point model through the host).  The launch grid is this many workgroups per
+// Overflow points per job the device-side pass takes before the host path has to: kOverflowCap, or 1/128 of the largest
+// active source cloud where that is more (the matrix-core filter leaves ~0.25 % of a cloud unsettled per pass whatever
+// its size - the band over the nearest-neighbour distance is scale-free; a fixed 1024 would send every pass of a
+// 10^6-point model through the host).  The launch grid is this many workgroups per
 // job; the ones past a job's count leave at once.
 uint32_t overflow_cap(const mi355_icp_ctx* c, int n_active) {
   uint32_t n = 0;
   for (int k = 0; k < n_active; ++k) n = std::max(n, c->jobs_host[k].src_n);
-  return std::max<uint32_t>(kOverflowCap, n / 256u);
+  return std::max<uint32_t>(kOverflowCap, n / 128u);
 }
 
 // Fused-filter path up to "index and dist2 of every point are final": filter scan -> exact resolve of the candidate
@@ -685,7 +690,7 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
     const size_t st = xstride;
     const int ppl = plan.scan_ppl == 2 ? 2 : 4;  // the MFMA kernel spans 128 * {4, 8} points per workgroup
     if (bx && plan.xkind == 3) {
-      launch_nn_scan_xbf16(c->stream, c->jobs_dev, n_active, bx, Sscan, X.bf, X.table, c->keys3, plan.out_total, rank_stride, c->xbf16_shape);
+      launch_nn_scan_xbf16(c->stream, c->jobs_dev, n_active, bx, Sscan, X.bf, X.bf_table, c->keys3, plan.out_total, rank_stride, c->xbf16_shape);
     } else if (bx && plan.xkind == 0) {
       launch_nn_scan_xfilter(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, xp, xp + st, xp + 2 * st, xp + 3 * st,
                              X.table, c->keys3, plan.out_total, rank_stride);
@@ -1375,7 +1380,7 @@ int mi355_icp_debug_filter_bounds(mi355_icp_ctx* c, int source_id, int target_id
       hipMemcpyAsync(c->jobs_dev, c->jobs_host, sizeof(JobDesc), hipMemcpyHostToDevice, c->stream) != hipSuccess)
     return finish(fail(c, MI355_ICP_ERR_HIP, "debug_filter_bounds: staging failed"));
   const uint32_t rank_stride = plan.key_rows() * plan.out_total;
-  launch_nn_scan_xbf16_dump(c->stream, c->jobs_dev, J.scan_blocks, c->sources.view(), c->targets.xt.bf, c->targets.xt.table, c->keys3,
+  launch_nn_scan_xbf16_dump(c->stream, c->jobs_dev, J.scan_blocks, c->sources.view(), c->targets.xt.bf, c->targets.xt.bf_table, c->keys3,
                             plan.out_total, rank_stride, dump, S.padded);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
     return finish(fail(c, MI355_ICP_ERR_HIP, "debug_filter_bounds: the dump launch failed"));

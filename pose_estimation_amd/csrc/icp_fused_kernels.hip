@@ -507,8 +507,9 @@ __global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xmfma_kernel(const J
 // kernel above buys nothing.  v_mfma_f32_32x32x16_bf16 is a different unit: 1024 products of a K = 16 contraction in 32
 // cycles.  Sixteen K slots are enough for the expansion surrogate of points QUANTISED to two bfloat16 pieces per
 // coordinate (16 significand bits).  Notation: u = 2^-24; q the transformed source point, t a target, c the tile centre
-// (all float32); qc = fl(q - c), tc = fl(t - c); r^2 >= |tc|^2 and >= |tc'|^2 for every target of the tile (rounded up
-// at upload); N := |qc|^2 + r^2.
+// (all float32) - since round 2 the centre of a GROUP of kXbCentreGroup consecutive tiles, so that the split of q below
+// is redone once per group, not once per tile; qc = fl(q - c), tc = fl(t - c); r^2 >= |tc|^2 and >= |tc'|^2 for every
+// target of the group (rounded up at upload); N := |qc|^2 + r^2.
 //
 //   q'  = -2 qc (exact), split into bf16 pieces q'h + q'l, |q' - (q'h + q'l)| <= 2^-16 |q'| per coordinate
 //         (two round-to-nearest bf16 roundings: 2^-8 of 2^-8); qc' := -(q'h + q'l) / 2
@@ -658,12 +659,15 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
   __syncthreads();
   uint32_t cur = 0;
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint4 bq[kSets];
+  float adj[kSets], ee[kSets];
   for (uint32_t tile = tile0; tile < tile1; ++tile) {
     const bool more = tile + 1 < tile1;
-    const float4 tc = tile_table[tile_base + tile];  // centre xyz, r^2 (wave-uniform)
+    // The operand image of kXbCentreGroup consecutive tiles shares one centre and one r^2 (xtarget_kernels.hip): the
+    // source points are re-split into bf16 pieces at the first tile of the walk and whenever a new group begins
+    if (tile == tile0 || tile % kXbCentreGroup == 0) {
+    const float4 tc = tile_table[tile_base + tile];  // the group's centre xyz and r^2 (wave-uniform)
     const float c2x = 2.0f * tc.x, c2y = 2.0f * tc.y, c2z = 2.0f * tc.z;
-    uint4 bq[kSets];
-    float adj[kSets], ee[kSets];
 #pragma unroll
     for (int m = 0; m < kSets; ++m) {
       uint32_t px, py, pz;
@@ -678,6 +682,7 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
       adj[m] = qq - bf16_value(bias);  // s = MFMA + adj
       const uint32_t w0 = hi ? pz : px;
       bq[m] = make_uint4(w0, w0, hi ? 0x3F803F80u : py, hi ? (0x00003F80u | (bias << 16)) : py);
+    }
     }
     const uint4* __restrict__ A = lds + cur * kXbTileVecs + (hi ? kTile : 0) + (lane & 31u);
     // Two accumulator sets in flight over the tile's 32 MFMA blocks, one MFMA then the 8 integer minima of an EARLIER

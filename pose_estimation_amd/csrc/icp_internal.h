@@ -26,6 +26,12 @@ constexpr int kXbChunk = 256;
 constexpr int kXbChunksPerTile = kTile / kXbChunk;
 constexpr int kXbRun = 128;
 constexpr int kXbTileVecs = 2 * kTile;                   // uint4 per tile of the bf16 operand image: [k half][row slot]
+// The operand image of kXbCentreGroup consecutive tiles is written around ONE shared centre (and carries one shared r^2),
+// so the scan re-splits its source points into bf16 pieces once per group instead of once per tile (36 vector
+// instructions per source set each time).  The price is a band E that grows with the group's radius: at 1M<->1M groups
+// of 1 / 2 / 4 tiles scan in 28.35 / 27.86 / 27.15 ms and leave 563 / 1210 / 2636 of 10^6 points to the overflow pass
+// (0.23 -> 0.25 ms of resolve): profiles/r02q_scan_ab_centre_groups.txt.
+constexpr int kXbCentreGroup = 4;
 
 #if defined(__HIPCC__)
 // bfloat16 pieces of a float32 (round to nearest even; NaN stays NaN, +-inf stays +-inf).  x ~ hi + lo with
@@ -237,7 +243,7 @@ void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, 
 int xtarget_sort_temp_bytes(uint32_t n, size_t* bytes);
 int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const uint32_t* box, uint32_t* code,
                         uint32_t* index, uint32_t* code2, uint32_t* order, void* temp, size_t temp_bytes, float* xt,
-                        size_t stride, uint32_t* perm, float* table, void* bf_image, void* sub_table);
+                        size_t stride, uint32_t* perm, float* table, void* bf_image, void* sub_table, float* bf_table);
 void launch_super_tiles(void* stream, const float* table, uint32_t n_tiles_total, float* super_table);
 void launch_bbox(void* stream, DevicePlanes planes, const uint32_t* cloud_off, const uint32_t* cloud_n, int n_clouds, uint32_t max_n,
                  uint32_t* box);

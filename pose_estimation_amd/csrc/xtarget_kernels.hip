@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __re
                                                                 const uint32_t* __restrict__ order, float* __restrict__ xt,
                                                                 size_t stride, uint32_t* __restrict__ perm,
                                                                 float* __restrict__ table, uint4* __restrict__ bf_image,
-                                                                float4* __restrict__ sub_table) {
+                                                                float4* __restrict__ sub_table, float* __restrict__ bf_table) {
   __shared__ float slo[4][3], shi[4][3];
   __shared__ double sr2[4];
   const uint32_t t0 = blockIdx.x * kTile;
@@ -181,6 +181,73 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __re
   }
   block_minmax<kBlockThreads>(lo, hi, slo, shi);
   const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
+  // The matrix-core operand image is centred per GROUP of kXbCentreGroup tiles (icp_internal.h): every workgroup of a
+  // group reads the whole group's points, so all of them arrive at the same centre and the same r^2 without talking to
+  // each other.
+  const uint32_t group0 = (blockIdx.x / kXbCentreGroup) * kXbCentreGroup * kTile;   // first sorted position of the group
+  float gx_[kXbCentreGroup - 1][4], gy_[kXbCentreGroup - 1][4], gz_[kXbCentreGroup - 1][4];
+  bool greal[kXbCentreGroup - 1][4];
+  float glo[3] = {lo[0], lo[1], lo[2]}, ghi[3] = {hi[0], hi[1], hi[2]};   // this tile's box (block-wide), then the others' points
+  {
+    float plo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, phi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    int slot = 0;
+#pragma unroll
+    for (int g = 0; g < kXbCentreGroup; ++g) {
+      const uint32_t tg = group0 + g * kTile;
+      if (tg == t0) continue;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t sp = tg + k * kBlockThreads + threadIdx.x;
+        greal[slot][k] = sp < n;
+        if (greal[slot][k]) {
+          const uint32_t sidx = order[sp];
+          gx_[slot][k] = px[off + sidx];
+          gy_[slot][k] = py[off + sidx];
+          gz_[slot][k] = pz[off + sidx];
+          plo[0] = __builtin_fminf(plo[0], gx_[slot][k]); phi[0] = __builtin_fmaxf(phi[0], gx_[slot][k]);
+          plo[1] = __builtin_fminf(plo[1], gy_[slot][k]); phi[1] = __builtin_fmaxf(phi[1], gy_[slot][k]);
+          plo[2] = __builtin_fminf(plo[2], gz_[slot][k]); phi[2] = __builtin_fmaxf(phi[2], gz_[slot][k]);
+        }
+      }
+      ++slot;
+    }
+    __syncthreads();  // slo / shi are reused
+    block_minmax<kBlockThreads>(plo, phi, slo, shi);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      glo[a] = __builtin_fminf(glo[a], plo[a]);
+      ghi[a] = __builtin_fmaxf(ghi[a], phi[a]);
+    }
+  }
+  const float bcx = 0.5f * glo[0] + 0.5f * ghi[0], bcy = 0.5f * glo[1] + 0.5f * ghi[1], bcz = 0.5f * glo[2] + 0.5f * ghi[2];
+  // |tc'|^2 of a point quantised around the group centre, and its bf16 pieces
+  auto quantise = [&](float xx, float yy, float zz, uint32_t (&h)[3], uint32_t (&l)[3], float& bdx, float& bdy, float& bdz) -> double {
+    bdx = xx - bcx; bdy = yy - bcy; bdz = zz - bcz;   // the float32 subtractions the bound is written for
+    h[0] = bf16_bits(bdx); h[1] = bf16_bits(bdy); h[2] = bf16_bits(bdz);
+    l[0] = bf16_bits(bdx - bf16_value(h[0])); l[1] = bf16_bits(bdy - bf16_value(h[1])); l[2] = bf16_bits(bdz - bf16_value(h[2]));
+    const double qx = static_cast<double>(bf16_value(h[0])) + bf16_value(l[0]), qy = static_cast<double>(bf16_value(h[1])) + bf16_value(l[1]),
+                 qz = static_cast<double>(bf16_value(h[2])) + bf16_value(l[2]);
+    return qx * qx + qy * qy + qz * qz;
+  };
+  double br2 = 0.0;   // max over the GROUP of |tc|^2 and |tc'|^2 around the group centre
+  {
+    int slot = 0;
+#pragma unroll
+    for (int g = 0; g < kXbCentreGroup; ++g) {
+      if (group0 + g * kTile == t0) continue;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (greal[slot][k]) {
+          uint32_t h[3], l[3];
+          float ddx, ddy, ddz;
+          const double n2q = quantise(gx_[slot][k], gy_[slot][k], gz_[slot][k], h, l, ddx, ddy, ddz);
+          const double n2 = static_cast<double>(ddx) * ddx + static_cast<double>(ddy) * ddy + static_cast<double>(ddz) * ddz;
+          br2 = n2 > br2 ? n2 : br2;
+          br2 = n2q > br2 ? n2q : br2;
+        }
+      ++slot;
+    }
+  }
   double r2 = 0.0;
   float* tcx = xt + off;
 #pragma unroll
@@ -204,11 +271,13 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __re
       const uint32_t w = k * kBlockThreads + threadIdx.x;
       const uint32_t cc = w >> 8, hh = (w >> 7) & 1u, u = w & 127u;
       const uint32_t slot = (cc * 8 + (u >> 4)) * 32 + 8 * ((u >> 2) & 3u) + 4 * hh + (u & 3u);
-      const uint32_t hx = bf16_bits(dx), hy = bf16_bits(dy), hz = bf16_bits(dz);
-      const uint32_t lx = bf16_bits(dx - bf16_value(hx)), ly = bf16_bits(dy - bf16_value(hy)), lz = bf16_bits(dz - bf16_value(hz));
-      const double qx = static_cast<double>(bf16_value(hx)) + bf16_value(lx), qy = static_cast<double>(bf16_value(hy)) + bf16_value(ly),
-                   qz = static_cast<double>(bf16_value(hz)) + bf16_value(lz);
-      const double n2q = qx * qx + qy * qy + qz * qz;
+      uint32_t hq[3], lq[3];
+      float bdx, bdy, bdz;
+      const double n2q = quantise(x[k], y[k], z[k], hq, lq, bdx, bdy, bdz);   // around the GROUP centre
+      const uint32_t hx = hq[0], hy = hq[1], hz = hq[2], lx = lq[0], ly = lq[1], lz = lq[2];
+      const double n2b = static_cast<double>(bdx) * bdx + static_cast<double>(bdy) * bdy + static_cast<double>(bdz) * bdz;
+      br2 = n2b > br2 ? n2b : br2;
+      br2 = n2q > br2 ? n2q : br2;
       const float ttq = static_cast<float>(n2q);
       const uint32_t t1 = bf16_bits(ttq);
       const float rem1 = ttq - bf16_value(t1);
@@ -217,7 +286,6 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __re
       uint4* img = bf_image + static_cast<size_t>((off + t0) / kTile) * kXbTileVecs;
       img[slot] = make_uint4(hx | (hx << 16), lx | (lx << 16), hy | (hy << 16), ly | (ly << 16));
       img[kTile + slot] = make_uint4(hz | (hz << 16), lz | (lz << 16), t1 | (t2 << 16), t3 | 0x3F800000u);  // slot 15: 1.0 (bias row)
-      r2 = n2q > r2 ? n2q : r2;
     }
   }
 #pragma unroll
@@ -234,6 +302,22 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __re
     const float r = __uint_as_float(__float_as_uint(static_cast<float>(m)) + 1u);  // next float up: r^2 >= every |tc|^2 (m >= 0, finite)
     float* row = table + 4 * static_cast<size_t>((off + t0) / kTile);
     row[0] = cx; row[1] = cy; row[2] = cz; row[3] = r;
+  }
+  // the group's r^2 for the matrix-core image (every workgroup of the group computes the same value)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double other = __shfl_xor(br2, o, 64);
+    br2 = other > br2 ? other : br2;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63u) == 0) sr2[threadIdx.x >> 6] = br2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = sr2[0];
+    for (int w = 1; w < 4; ++w) m = sr2[w] > m ? sr2[w] : m;
+    const float r = __uint_as_float(__float_as_uint(static_cast<float>(m)) + 1u);
+    float* row = bf_table + 4 * static_cast<size_t>((off + t0) / kTile);
+    row[0] = bcx; row[1] = bcy; row[2] = bcz; row[3] = r;
   }
 }
 
@@ -301,7 +385,7 @@ int xtarget_sort_temp_bytes(uint32_t n, size_t* bytes) {
 // Enqueues the whole build for one cloud on `stream`.  code/index/code2/order: n entries each; temp: sort scratch.
 int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const uint32_t* box, uint32_t* code,
                         uint32_t* index, uint32_t* code2, uint32_t* order, void* temp, size_t temp_bytes, float* xt,
-                        size_t stride, uint32_t* perm, float* table, void* bf_image, void* sub_table) {
+                        size_t stride, uint32_t* perm, float* table, void* bf_image, void* sub_table, float* bf_table) {
   if (!n) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(morton_kernel, dim3((n + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, st, planes.x, planes.y,
@@ -309,7 +393,7 @@ int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_
   size_t tb = temp_bytes;
   if (rocprim::radix_sort_pairs(temp, tb, code, code2, index, order, n, 0, 30, st, false) != hipSuccess) return 1;
   hipLaunchKernelGGL(centre_kernel, dim3((n + kTile - 1) / kTile), dim3(kBlockThreads), 0, st, planes.x, planes.y, planes.z, off, n,
-                     order, xt, stride, perm, table, static_cast<uint4*>(bf_image), static_cast<float4*>(sub_table));
+                     order, xt, stride, perm, table, static_cast<uint4*>(bf_image), static_cast<float4*>(sub_table), bf_table);
   return 0;
 }
 
