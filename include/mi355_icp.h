@@ -262,8 +262,8 @@ int mi355_icp_solve_point_to_plane(const double* sums29, double out_x[6]);
  * (reference pose_estimation/src/pose_estimation.cpp): NaN removal (:248), the sphere filter filter_points
  * (:347-372) and the distance band around a fitted plane in remove_planes (:310-333).  Arithmetic follows those
  * lines (float32, their operation order, the band compared in double); kept points stay in their original order
- * (the reference's loops emit indices in thread-arrival order under `omp critical`).  The RANSAC plane fit itself
- * (:285-297) is PCL's and stays with the caller, who passes the coefficients in. */
+ * (the reference's loops emit indices in thread-arrival order under `omp critical`).  The plane comes from
+ * mi355_icp_scene_fit_plane below (the replacement of the pcl::SACSegmentation call at :285-297) or from the caller. */
 typedef enum mi355_scene_filter_kind {
   MI355_SCENE_FILTER_FINITE = 0,               /* keep points whose x, y, z are all finite */
   MI355_SCENE_FILTER_SPHERE_KEEP_INSIDE = 1,   /* p[0..2] centre, p[3] radius: keep d <= radius  (filter_out != "inliers") */
@@ -290,6 +290,35 @@ int mi355_icp_scene_filter(mi355_icp_ctx* ctx, int n_filters, const mi355_scene_
 /* Copies the current scene back as packed xyz rows (for the host-side RANSAC between plane removals).
  * Replaces: the pcl cloud -> cv::Mat N x 3 copy (pose_estimation.cpp:263-276). */
 int mi355_icp_scene_download(mi355_icp_ctx* ctx, float* out_xyz, size_t capacity_points, size_t* out_n_points);
+
+/* RANSAC plane fit of the current scene ("RANSAC plane fit ... becomes a small batched kernel").
+ * Replaces: the pcl::SACSegmentation call of PoseEstimation::remove_planes (reference pose_estimation.cpp:285-297:
+ * SACMODEL_PLANE, SAC_RANSAC, setOptimizeCoefficients(true), setDistanceThreshold(0.0001), setMaxIterations(100)), whose
+ * coefficients then feed MI355_SCENE_FILTER_PLANE_BAND_REMOVE (:310-333).  PCL's structure, restated (its source is not
+ * in the reference, its random sample sequence is not reproducible: the fitted plane agrees with PCL's only to within
+ * what two RANSAC runs of PCL agree with each other - parity unpinned; oracle/icp_oracle.c pins THIS definition):
+ *   hypotheses  h = 0 .. max_iterations-1: three distinct points drawn by a counter-based generator keyed by `seed`
+ *               (up to 16 attempts per hypothesis for a non-degenerate triple); plane through them, float32:
+ *               n = (p1-p0) x (p2-p0) normalised, d = -n.p0
+ *   support     number of points with |a x + b y + c z + d| <= distance_threshold (float32), all hypotheses in ONE pass
+ *               over the scene
+ *   choice      PCL's adaptive rule replayed in hypothesis order: a hypothesis with more support than any before it
+ *               becomes the best and sets k = log(1 - probability) / log(1 - w^3), w = support / points; the search
+ *               ends with the first h + 1 >= k
+ *   refinement  (optimize != 0) least squares on the best hypothesis's inliers: centroid and covariance in double,
+ *               eigenvector of the smallest eigenvalue, sign kept towards the hypothesis; support is counted again
+ * Non-finite points never support a plane.  out_coefficients: a, b, c, d of ax + by + cz + d = 0 with |(a,b,c)| = 1. */
+typedef struct mi355_plane_fit_params {
+  float    distance_threshold; /* reference: 0.0001 */
+  int32_t  max_iterations;     /* reference: 100; 1 .. 1024 */
+  double   probability;        /* PCL default 0.99 */
+  uint64_t seed;
+  int32_t  optimize;           /* reference: setOptimizeCoefficients(true) */
+  int32_t  reserved;
+} mi355_plane_fit_params;
+
+int mi355_icp_scene_fit_plane(mi355_icp_ctx* ctx, const mi355_plane_fit_params* params, float out_coefficients[4],
+                              size_t* out_inliers, int* out_iterations);
 
 /* Normals of the current scene by k-nearest-neighbour PCA.
  * Replaces: cv::ppf_match_3d::computeNormalsPC3d(pc_scene, pc_scene_normals, 20, true, viewpoint)

@@ -951,3 +951,133 @@ void oracle_normals(const float* xyz, size_t n, int k, int flip, const float vie
   if (!out_idx) free(idx);
   free(d2);
 }
+
+/* ======================================================================== */
+/* RANSAC plane fit of the scene: what the reference asks PCL for at pose_estimation/src/pose_estimation.cpp:285-297
+ *   (pcl::SACSegmentation: SACMODEL_PLANE, SAC_RANSAC, setOptimizeCoefficients(true), setDistanceThreshold(0.0001),
+ *   setMaxIterations(100)); third-party, source absent from /root/reference, and its random sample sequence is not
+ *   reproducible.  PARITY UNPINNED: this restates PCL's published structure (RandomSampleConsensus::computeModel's
+ *   adaptive loop, the plane model's three-point fit and covariance refinement) with every implementation-defined
+ *   choice pinned here - the generator (the counter-based one of the synthetic clouds), float32 hypothesis and distance
+ *   arithmetic with every product and sum rounded separately, double moments - and is what
+ *   mi355_icp_scene_fit_plane (include/mi355_icp.h) is checked against. */
+static uint64_t pf_mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+static uint32_t pf_draw(uint64_t seed, uint64_t ctr, uint32_t n) {
+  uint64_t x = pf_mix64(seed + ctr * 0x9E3779B97F4A7C15ULL);
+  double u = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+  uint32_t i = (uint32_t)(u * (double)n);
+  return i < n ? i : n - 1;
+}
+static float pf_distance(const float P[4], const float* p) {
+  float d = P[0] * p[0];
+  float t = P[1] * p[1], u = P[2] * p[2];
+  d = d + t;
+  d = d + u;
+  d = d + P[3];
+  return d;
+}
+static size_t pf_support(const float* xyz, size_t n, const float P[4], float thr) {
+  size_t c = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (fabsf(pf_distance(P, &xyz[3 * i])) <= thr) ++c; /* NaN: false */
+  return c;
+}
+
+/* out_planes (max_iterations x 4) and out_counts (max_iterations) may be NULL.  Returns 0, or 1 if no plane was found. */
+int oracle_plane_fit(const float* xyz, size_t n, float thr, int max_iterations, double probability, uint64_t seed,
+                     int optimize, float out4[4], size_t* out_inliers, int* out_iterations, float* out_planes,
+                     uint32_t* out_counts) {
+  int best = -1, it = 0;
+  size_t best_count = 0;
+  double k = 1.0;
+  const double log_probability = log(1.0 - probability), eps = 2.220446049250313e-16;
+  float bestP[4] = {0, 0, 0, 0};
+  for (int h = 0; h < max_iterations; ++h) {
+    float P[4] = {0.f, 0.f, 0.f, NAN};
+    for (uint32_t attempt = 0; attempt < 16; ++attempt) {
+      const uint64_t base = ((uint64_t)h * 16u + attempt) * 3u;
+      const uint32_t i0 = pf_draw(seed, base, (uint32_t)n), i1 = pf_draw(seed, base + 1, (uint32_t)n), i2 = pf_draw(seed, base + 2, (uint32_t)n);
+      if (i0 == i1 || i0 == i2 || i1 == i2) continue;
+      const float* p0 = &xyz[3 * (size_t)i0];
+      const float ax = xyz[3 * (size_t)i1] - p0[0], ay = xyz[3 * (size_t)i1 + 1] - p0[1], az = xyz[3 * (size_t)i1 + 2] - p0[2];
+      const float bx = xyz[3 * (size_t)i2] - p0[0], by = xyz[3 * (size_t)i2 + 1] - p0[1], bz = xyz[3 * (size_t)i2 + 2] - p0[2];
+      float t, u;
+      t = ay * bz; u = az * by; const float nx = t - u;
+      t = az * bx; u = ax * bz; const float ny = t - u;
+      t = ax * by; u = ay * bx; const float nz = t - u;
+      float l2 = nx * nx;
+      t = ny * ny; l2 = l2 + t;
+      t = nz * nz; l2 = l2 + t;
+      const float len = sqrtf(l2);
+      if (!(len > 0.0f) || !isfinite(len)) continue;
+      const float a = nx / len, b = ny / len, c = nz / len;
+      float d = a * p0[0];
+      t = b * p0[1]; d = d + t;
+      t = c * p0[2]; d = d + t;
+      P[0] = a; P[1] = b; P[2] = c; P[3] = -d;
+      break;
+    }
+    const int valid = !(P[3] != P[3]);
+    const size_t cnt = valid ? pf_support(xyz, n, P, thr) : 0;
+    if (out_planes) memcpy(out_planes + 4 * (size_t)h, P, sizeof(P));
+    if (out_counts) out_counts[h] = (uint32_t)cnt;
+    /* the adaptive loop, in hypothesis order (all hypotheses are evaluated for the record; the choice only looks at a
+     * hypothesis while iterations < k, exactly as a sequential run would) */
+    if (!((double)it < k)) continue;
+    if (!valid) continue;
+    if (best < 0 || cnt > best_count) {
+      best = h;
+      best_count = cnt;
+      memcpy(bestP, P, sizeof(P));
+      const double w = (double)best_count / (double)n;
+      double p_no = 1.0 - w * w * w;
+      p_no = fmax(eps, p_no);
+      p_no = fmin(1.0 - eps, p_no);
+      k = log_probability / log(p_no);
+    }
+    ++it;
+  }
+  if (out_iterations) *out_iterations = it;
+  if (best < 0) return 1;
+  size_t inliers = best_count;
+  if (optimize) {
+    double m[10] = {0};
+    for (size_t i = 0; i < n; ++i) {
+      const float* p = &xyz[3 * i];
+      if (fabsf(pf_distance(bestP, p)) <= thr) {
+        const double X = p[0], Y = p[1], Z = p[2];
+        m[0] += 1.0; m[1] += X; m[2] += Y; m[3] += Z;
+        m[4] += X * X; m[5] += X * Y; m[6] += X * Z; m[7] += Y * Y; m[8] += Y * Z; m[9] += Z * Z;
+      }
+    }
+    if (m[0] >= 3.0) {
+      const double inv = 1.0 / m[0];
+      const double c[3] = {m[1] * inv, m[2] * inv, m[3] * inv};
+      double A[3][3] = {{m[4] * inv - c[0] * c[0], m[5] * inv - c[0] * c[1], m[6] * inv - c[0] * c[2]},
+                        {0, m[7] * inv - c[1] * c[1], m[8] * inv - c[1] * c[2]},
+                        {0, 0, m[9] * inv - c[2] * c[2]}};
+      A[1][0] = A[0][1]; A[2][0] = A[0][2]; A[2][1] = A[1][2];
+      double V[3][3], w[3];
+      jacobi_eig3(A, V, w);
+      int e = 0;
+      if (w[1] < w[e]) e = 1;
+      if (w[2] < w[e]) e = 2;
+      double v[3] = {V[0][e], V[1][e], V[2][e]};
+      const double nrm = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      if (nrm > 0.0) {
+        const double sign = (v[0] * bestP[0] + v[1] * bestP[1] + v[2] * bestP[2]) < 0.0 ? -1.0 : 1.0;
+        for (int q = 0; q < 3; ++q) v[q] = sign * v[q] / nrm;
+        bestP[0] = (float)v[0]; bestP[1] = (float)v[1]; bestP[2] = (float)v[2];
+        bestP[3] = (float)(-(v[0] * c[0] + v[1] * c[1] + v[2] * c[2]));
+        inliers = pf_support(xyz, n, bestP, thr);
+      }
+    }
+  }
+  memcpy(out4, bestP, sizeof(bestP));
+  if (out_inliers) *out_inliers = inliers;
+  return 0;
+}

@@ -82,6 +82,12 @@ class Profile(C.Structure):
     ]
 
 
+class PlaneFitParams(C.Structure):
+    """mi355_plane_fit_params"""
+    _fields_ = [("distance_threshold", C.c_float), ("max_iterations", C.c_int32), ("probability", C.c_double),
+                ("seed", C.c_uint64), ("optimize", C.c_int32), ("reserved", C.c_int32)]
+
+
 class SceneFilter(C.Structure):
     """mi355_scene_filter"""
     _fields_ = [("kind", C.c_int32), ("p", C.c_float * 5)]
@@ -125,6 +131,7 @@ SIGNATURES = {
     "mi355_icp_scene_load": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_size_t]),
     "mi355_icp_scene_filter": (C.c_int, [_ctx, C.c_int, C.c_void_p, _P(C.c_size_t)]),
     "mi355_icp_scene_download": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
+    "mi355_icp_scene_fit_plane": (C.c_int, [_ctx, _P(PlaneFitParams), C.c_void_p, _P(C.c_size_t), _P(C.c_int)]),
     "mi355_icp_scene_normals": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355_icp_scene_commit_target": (C.c_int, [_ctx]),
     "mi355_icp_solve_rigid": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -240,6 +240,89 @@ int solve_point_to_plane(const double* sums, double* x) {
   return MI355_ICP_OK;
 }
 
+// ---- RANSAC plane fit, host half (mi355_icp_scene_fit_plane; reference pose_estimation.cpp:285-297) ----------------
+// PCL's RandomSampleConsensus::computeModel replayed over the support counts the device produced for all hypotheses at
+// once: a hypothesis is looked at only while iterations < k; more support than any before makes it the best and
+// shortens k = log(1 - probability) / log(1 - w^3).  Returns the best hypothesis (-1: none) and the iterations spent.
+int plane_choose(const uint32_t* counts, const float* planes4, uint32_t n_hyp, uint32_t n_points, double probability, int* iterations) {
+  int best = -1, it = 0;
+  uint32_t best_count = 0;
+  double k = 1.0;
+  const double log_probability = std::log(1.0 - probability);
+  const double eps = 2.220446049250313e-16;
+  for (uint32_t h = 0; h < n_hyp; ++h) {
+    if (!(static_cast<double>(it) < k)) break;
+    if (planes4[4 * h + 3] != planes4[4 * h + 3]) continue;  // no valid triple: skipped, not an iteration (as PCL)
+    if (best < 0 || counts[h] > best_count) {
+      best = static_cast<int>(h);
+      best_count = counts[h];
+      const double w = static_cast<double>(best_count) / static_cast<double>(n_points);
+      double p_no_outliers = 1.0 - w * w * w;
+      p_no_outliers = std::fmax(eps, p_no_outliers);
+      p_no_outliers = std::fmin(1.0 - eps, p_no_outliers);
+      k = log_probability / std::log(p_no_outliers);
+    }
+    ++it;
+  }
+  if (iterations) *iterations = it;
+  return best;
+}
+
+// Least-squares plane of the inliers summarised by (n, sum p, sum p p^T upper triangle): normal = eigenvector of the
+// smallest eigenvalue of the covariance (cyclic Jacobi on the symmetric 3x3), pointing the way the hypothesis does.
+int plane_refine(const double* m, const float* hyp, float* out) {
+  for (int k = 0; k < 10; ++k)
+    if (!std::isfinite(m[k])) return MI355_ICP_ERR_NUMERIC;
+  if (m[0] < 3.0) return MI355_ICP_ERR_TOO_FEW_PAIRS;
+  const double inv = 1.0 / m[0];
+  const double c[3] = {m[1] * inv, m[2] * inv, m[3] * inv};
+  double A[3][3] = {{m[4] * inv - c[0] * c[0], m[5] * inv - c[0] * c[1], m[6] * inv - c[0] * c[2]},
+                    {0, m[7] * inv - c[1] * c[1], m[8] * inv - c[1] * c[2]},
+                    {0, 0, m[9] * inv - c[2] * c[2]}};
+  A[1][0] = A[0][1]; A[2][0] = A[0][2]; A[2][1] = A[1][2];
+  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    const double off = std::fabs(A[0][1]) + std::fabs(A[0][2]) + std::fabs(A[1][2]);
+    const double diag = std::fabs(A[0][0]) + std::fabs(A[1][1]) + std::fabs(A[2][2]);
+    if (off <= 1e-300 || off <= 1e-30 * diag) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (A[p][q] == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+        for (int r = 0; r < 3; ++r) {
+          const double a = A[r][p], b = A[r][q];
+          A[r][p] = cs * a - sn * b;
+          A[r][q] = sn * a + cs * b;
+        }
+        for (int r = 0; r < 3; ++r) {
+          const double a = A[p][r], b = A[q][r];
+          A[p][r] = cs * a - sn * b;
+          A[q][r] = sn * a + cs * b;
+        }
+        for (int r = 0; r < 3; ++r) {
+          const double a = V[r][p], b = V[r][q];
+          V[r][p] = cs * a - sn * b;
+          V[r][q] = sn * a + cs * b;
+        }
+      }
+  }
+  int e = 0;
+  if (A[1][1] < A[e][e]) e = 1;
+  if (A[2][2] < A[e][e]) e = 2;
+  double v[3] = {V[0][e], V[1][e], V[2][e]};
+  const double nrm = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  if (!(nrm > 0.0)) return MI355_ICP_ERR_NUMERIC;
+  const double sign = (v[0] * hyp[0] + v[1] * hyp[1] + v[2] * hyp[2]) < 0.0 ? -1.0 : 1.0;
+  for (int k = 0; k < 3; ++k) v[k] = sign * v[k] / nrm;
+  out[0] = static_cast<float>(v[0]);
+  out[1] = static_cast<float>(v[1]);
+  out[2] = static_cast<float>(v[2]);
+  out[3] = static_cast<float>(-(v[0] * c[0] + v[1] * c[1] + v[2] * c[2]));
+  return MI355_ICP_OK;
+}
+
 // R = Rx(x0) * (Ry(x1) * Rz(x2)), t = (x3, x4, x5): upstream's getTransformMat / eulerToDCM convention as recalled.
 void euler_pose(const double* x, double* P) {
   const double c0 = std::cos(x[0]), s0 = std::sin(x[0]), c1 = std::cos(x[1]), s1 = std::sin(x[1]), c2 = std::cos(x[2]),

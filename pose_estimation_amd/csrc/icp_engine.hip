@@ -159,6 +159,7 @@ struct mi355_icp_ctx {
   int32_t* knn_out = nullptr; size_t knn_out_cap = 0;
   bool scene_normals_valid = false; uint32_t scene_normals_padded = 0;
   unsigned long long* scene_state = nullptr; size_t scene_state_cap = 0;
+  float* plane_hyp = nullptr; uint32_t* plane_counts = nullptr; double* plane_partials = nullptr; size_t plane_partials_cap = 0;  // RANSAC plane fit
   uint32_t* scene_counters = nullptr;       // device: ticket, kept total, error bits
   uint32_t* scene_counters_host = nullptr;  // pinned
 
@@ -1193,6 +1194,9 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   (void)hipFree(c->knn_i);
   (void)hipFree(c->knn_out);
   (void)hipFree(c->scene_state);
+  (void)hipFree(c->plane_hyp);
+  (void)hipFree(c->plane_counts);
+  (void)hipFree(c->plane_partials);
   (void)hipFree(c->scene_counters);
   if (c->scene_counters_host) (void)hipHostFree(c->scene_counters_host);
   (void)hipFree(c->xt_scratch);
@@ -1773,6 +1777,67 @@ int mi355_icp_scene_normals(mi355_icp_ctx* c, int k, int flip_viewpoint, const f
   c->scene_normals_padded = padded;
   if (out_normals) HIP_TRY(c, hipMemcpy(out_normals, c->scene_normals_aos, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost));
   if (out_neighbors) HIP_TRY(c, hipMemcpy(out_neighbors, c->knn_out, static_cast<size_t>(n) * k_eff * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return MI355_ICP_OK;
+}
+
+int mi355_icp_scene_fit_plane(mi355_icp_ctx* c, const mi355_plane_fit_params* fp, float out_coefficients[4], size_t* out_inliers,
+                              int* out_iterations) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  c->err.clear();
+  if (!fp || !out_coefficients) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_fit_plane: bad arguments");
+  if (!c->scene_loaded || c->scene_n < 3) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_fit_plane: the scene has fewer than 3 points");
+  if (fp->max_iterations < 1 || fp->max_iterations > kPlaneMaxHypotheses || !(fp->distance_threshold >= 0.0f) ||
+      !(fp->probability > 0.0 && fp->probability < 1.0))
+    return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_fit_plane: 1 <= max_iterations <= 1024, distance_threshold >= 0 and 0 < probability < 1 required");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t n = c->scene_n, n_hyp = static_cast<uint32_t>(fp->max_iterations);
+  const uint32_t blocks = (n + 4 * kBlockThreads - 1) / (4 * kBlockThreads);
+  if (!c->plane_hyp) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->plane_hyp), (kPlaneMaxHypotheses + 1) * 4 * sizeof(float)));
+  if (!c->plane_counts) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->plane_counts), (kPlaneMaxHypotheses + 1) * sizeof(uint32_t)));
+  int st;
+  if ((st = grow(c, c->plane_partials, c->plane_partials_cap, static_cast<size_t>(blocks) * kPlaneMoments)) != MI355_ICP_OK) return st;
+  const float* scene = c->scene[c->scene_cur];
+  std::vector<float> planes(4 * static_cast<size_t>(n_hyp));
+  std::vector<uint32_t> counts(n_hyp);
+  HIP_TRY(c, hipMemsetAsync(c->plane_counts, 0, (kPlaneMaxHypotheses + 1) * sizeof(uint32_t), c->stream));
+  launch_plane_hypotheses(c->stream, scene, n, fp->seed, n_hyp, c->plane_hyp);
+  launch_plane_support(c->stream, scene, n, c->plane_hyp, n_hyp, fp->distance_threshold, c->plane_counts);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(planes.data(), c->plane_hyp, planes.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(counts.data(), c->plane_counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int iterations = 0;
+  const int best = plane_choose(counts.data(), planes.data(), n_hyp, n, fp->probability, &iterations);
+  if (out_iterations) *out_iterations = iterations;
+  if (best < 0) return fail(c, MI355_ICP_ERR_NUMERIC, "scene_fit_plane: no three points of the scene span a plane");
+  float coeff[4] = {planes[4 * best], planes[4 * best + 1], planes[4 * best + 2], planes[4 * best + 3]};
+  size_t inliers = counts[static_cast<size_t>(best)];
+  if (fp->optimize) {
+    launch_plane_moments(c->stream, scene, n, coeff, fp->distance_threshold, c->plane_partials, blocks);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<double> rows(static_cast<size_t>(blocks) * kPlaneMoments);
+    HIP_TRY(c, hipMemcpyAsync(rows.data(), c->plane_partials, rows.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double m[kPlaneMoments] = {0};
+    for (uint32_t b = 0; b < blocks; ++b)  // fixed order: the same scene and plane always give the same bits
+      for (int k = 0; k < kPlaneMoments; ++k) m[k] += rows[static_cast<size_t>(b) * kPlaneMoments + k];
+    float refined[4];
+    if (plane_refine(m, coeff, refined) == MI355_ICP_OK) {  // a degenerate inlier set keeps the hypothesis (PCL: optimisation fails, model kept)
+      std::memcpy(coeff, refined, sizeof(coeff));
+      uint32_t cnt = 0;
+      float* slot = c->plane_hyp + 4 * kPlaneMaxHypotheses;      // the spare hypothesis slot and its counter
+      uint32_t* cslot = c->plane_counts + kPlaneMaxHypotheses;
+      HIP_TRY(c, hipMemcpyAsync(slot, coeff, sizeof(coeff), hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));  // `coeff` is pageable
+      launch_plane_support(c->stream, scene, n, slot, 1, fp->distance_threshold, cslot);
+      HIP_TRY(c, hipGetLastError());
+      HIP_TRY(c, hipMemcpyAsync(&cnt, cslot, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      inliers = cnt;
+    }
+  }
+  std::memcpy(out_coefficients, coeff, sizeof(coeff));
+  if (out_inliers) *out_inliers = inliers;
   return MI355_ICP_OK;
 }
 

@@ -152,6 +152,16 @@ struct SceneFilterSet {
 };
 void launch_scene_compact(void* stream, const float* in, uint32_t n, const SceneFilterSet& filters, float* out,
                           unsigned long long* state, uint32_t* counters, uint32_t n_tiles);
+// RANSAC plane fit (scene_kernels.hip): hypotheses (float4 a, b, c, d; d = NaN marks a hypothesis with no valid triple), their
+// support counts in one pass, and the 10 moments (n, sum p, sum p p^T upper triangle) of one plane's inliers per 1024-point block
+constexpr int kPlaneMaxHypotheses = 1024;
+constexpr int kPlaneMoments = 10;
+void launch_plane_hypotheses(void* stream, const float* scene, uint32_t n, unsigned long long seed, uint32_t n_hyp, float* planes4);
+void launch_plane_support(void* stream, const float* scene, uint32_t n, const float* planes4, uint32_t n_hyp, float threshold, uint32_t* counts);
+void launch_plane_moments(void* stream, const float* scene, uint32_t n, const float* plane4, float threshold, double* partials, uint32_t n_blocks);
+// host side (host_math.cpp): PCL's adaptive choice replayed over the counts; the refined plane from the moments
+int plane_choose(const uint32_t* counts, const float* planes4, uint32_t n_hyp, uint32_t n_points, double probability, int* iterations);
+int plane_refine(const double* moments10, const float* hypothesis4, float* out4);
 void launch_rows_to_planes(void* stream, const float* rows, uint32_t fstride, uint32_t n, float* planes, float* normals, size_t stride,
                            uint32_t off, uint32_t n_padded, float pad, uint32_t* flags, uint32_t cloud);
 void launch_scene_to_planes(void* stream, const float* in, uint32_t n, float* planes, size_t stride, uint32_t off,

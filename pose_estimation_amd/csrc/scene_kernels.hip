@@ -10,7 +10,8 @@
 //                                                  points with |d| <= 0.005 (double compare) are removed
 // Those loops run serialised under `omp critical` and emit indices in thread-arrival order; this kernel emits the
 // kept points in their original order (the order the reference produces when run on one thread).
-// Plane coefficients come from the caller (the RANSAC fit, pose_estimation.cpp:285-297, is PCL's and stays on the host).
+// Plane coefficients come from the caller - or from the RANSAC fit further down (mi355_icp_scene_fit_plane), the
+// replacement of the pcl::SACSegmentation call at pose_estimation.cpp:285-297.
 //
 // One pass over HBM: 12 B read per point, 12 B written per kept point.  Each tile (kSceneTile points) evaluates the
 // predicates, scans its keep flags, and gets its output offset by DECOUPLED LOOK-BACK over 8-byte
@@ -255,6 +256,154 @@ __global__ __launch_bounds__(kBlockThreads) void rows_to_planes_kernel(const flo
     normals[stride + off + i] = b;
     normals[2 * stride + off + i] = c;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RANSAC plane fit (reference pose_estimation.cpp:285-297 calls pcl::SACSegmentation; definition: include/mi355_icp.h,
+// checked against oracle/icp_oracle.c).  Counter-based generator of csrc/synth.c: point index = floor(u01 * n).
+namespace {
+
+__device__ __forceinline__ unsigned long long plane_mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t plane_draw(unsigned long long seed, unsigned long long ctr, uint32_t n) {
+  const unsigned long long x = plane_mix64(seed + ctr * 0x9E3779B97F4A7C15ull);
+  const double u = static_cast<double>(x >> 11) * (1.0 / 9007199254740992.0);
+  const uint32_t i = static_cast<uint32_t>(u * static_cast<double>(n));
+  return i < n ? i : n - 1;
+}
+
+}  // namespace
+
+// one thread per hypothesis
+__global__ void plane_hypotheses_kernel(const float* __restrict__ scene, uint32_t n, unsigned long long seed, uint32_t n_hyp,
+                                        float4* __restrict__ planes) {
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= n_hyp) return;
+  float4 out = make_float4(0.f, 0.f, 0.f, __builtin_nanf(""));
+  for (uint32_t attempt = 0; attempt < 16; ++attempt) {
+    const unsigned long long base = (static_cast<unsigned long long>(h) * 16ull + attempt) * 3ull;
+    const uint32_t i0 = plane_draw(seed, base, n), i1 = plane_draw(seed, base + 1, n), i2 = plane_draw(seed, base + 2, n);
+    if (i0 == i1 || i0 == i2 || i1 == i2) continue;
+    const float p0x = scene[3 * static_cast<size_t>(i0)], p0y = scene[3 * static_cast<size_t>(i0) + 1], p0z = scene[3 * static_cast<size_t>(i0) + 2];
+    const float ax = scene[3 * static_cast<size_t>(i1)] - p0x, ay = scene[3 * static_cast<size_t>(i1) + 1] - p0y, az = scene[3 * static_cast<size_t>(i1) + 2] - p0z;
+    const float bx = scene[3 * static_cast<size_t>(i2)] - p0x, by = scene[3 * static_cast<size_t>(i2) + 1] - p0y, bz = scene[3 * static_cast<size_t>(i2) + 2] - p0z;
+    float t, u;
+    t = ay * bz; u = az * by; const float nx = t - u;
+    t = az * bx; u = ax * bz; const float ny = t - u;
+    t = ax * by; u = ay * bx; const float nz = t - u;
+    float l2 = nx * nx;
+    t = ny * ny; l2 = l2 + t;
+    t = nz * nz; l2 = l2 + t;
+    const float len = __builtin_sqrtf(l2);
+    if (!(len > 0.0f) || !__builtin_isfinite(len)) continue;  // collinear, coincident or non-finite points
+    const float a = nx / len, b = ny / len, c = nz / len;
+    float d = a * p0x;
+    t = b * p0y; d = d + t;
+    t = c * p0z; d = d + t;
+    out = make_float4(a, b, c, -d);
+    break;
+  }
+  planes[h] = out;
+}
+
+// Support of every hypothesis in one pass: a thread takes 4 points; for each plane the wave's inlier ballots are counted
+// and one lane adds them to the workgroup's LDS counters, which go to the global counters at the end.  Integer counts.
+__global__ __launch_bounds__(kBlockThreads) void plane_support_kernel(const float* __restrict__ scene, uint32_t n,
+                                                                       const float4* __restrict__ planes, uint32_t n_hyp, float threshold,
+                                                                       uint32_t* __restrict__ counts) {
+  __shared__ float4 sp[kPlaneMaxHypotheses];
+  __shared__ uint32_t sc[kPlaneMaxHypotheses];
+  for (uint32_t h = threadIdx.x; h < n_hyp; h += kBlockThreads) {
+    sp[h] = planes[h];
+    sc[h] = 0;
+  }
+  __syncthreads();
+  float x[4], y[4], z[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t i = (blockIdx.x * 4 + k) * kBlockThreads + threadIdx.x;
+    const bool in = i < n;
+    x[k] = in ? scene[3 * static_cast<size_t>(i)] : __builtin_nanf("");
+    y[k] = in ? scene[3 * static_cast<size_t>(i) + 1] : 0.f;
+    z[k] = in ? scene[3 * static_cast<size_t>(i) + 2] : 0.f;
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t h = 0; h < n_hyp; ++h) {
+    const float4 P = sp[h];  // wave-uniform: LDS broadcast
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float dist = P.x * x[k];
+      const float t = P.y * y[k], u = P.z * z[k];
+      dist = dist + t;
+      dist = dist + u;
+      dist = dist + P.w;
+      mine += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_fabsf(dist) <= threshold)));  // NaN: false
+    }
+    if (lane == 0 && mine) atomicAdd(&sc[h], mine);
+  }
+  __syncthreads();
+  for (uint32_t h = threadIdx.x; h < n_hyp; h += kBlockThreads)
+    if (sc[h]) atomicAdd(&counts[h], sc[h]);
+}
+
+// n, sum x, y, z, sum xx, xy, xz, yy, yz, zz (double) of one plane's inliers: one partial row per 1024-point block
+__global__ __launch_bounds__(kBlockThreads) void plane_moments_kernel(const float* __restrict__ scene, uint32_t n, float4 P, float threshold,
+                                                                       double* __restrict__ partials) {
+  __shared__ double scratch[kBlockThreads / 64][kPlaneMoments];
+  double acc[kPlaneMoments];
+#pragma unroll
+  for (int k = 0; k < kPlaneMoments; ++k) acc[k] = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t i = (blockIdx.x * 4 + k) * kBlockThreads + threadIdx.x;
+    if (i < n) {
+      const float fx = scene[3 * static_cast<size_t>(i)], fy = scene[3 * static_cast<size_t>(i) + 1], fz = scene[3 * static_cast<size_t>(i) + 2];
+      float dist = P.x * fx;
+      const float t = P.y * fy, u = P.z * fz;
+      dist = dist + t;
+      dist = dist + u;
+      dist = dist + P.w;
+      if (__builtin_fabsf(dist) <= threshold) {
+        const double X = fx, Y = fy, Z = fz;
+        acc[0] += 1.0; acc[1] += X; acc[2] += Y; acc[3] += Z;
+        acc[4] += X * X; acc[5] += X * Y; acc[6] += X * Z; acc[7] += Y * Y; acc[8] += Y * Z; acc[9] += Z * Z;
+      }
+    }
+  }
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kPlaneMoments; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) scratch[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kPlaneMoments) {
+    double r = scratch[0][threadIdx.x];
+    for (int w = 1; w < kBlockThreads / 64; ++w) r += scratch[w][threadIdx.x];
+    partials[static_cast<size_t>(blockIdx.x) * kPlaneMoments + threadIdx.x] = r;
+  }
+}
+
+void launch_plane_hypotheses(void* stream, const float* scene, uint32_t n, unsigned long long seed, uint32_t n_hyp, float* planes4) {
+  hipLaunchKernelGGL(plane_hypotheses_kernel, dim3((n_hyp + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), scene, n, seed, n_hyp,
+                     reinterpret_cast<float4*>(planes4));
+}
+void launch_plane_support(void* stream, const float* scene, uint32_t n, const float* planes4, uint32_t n_hyp, float threshold, uint32_t* counts) {
+  const uint32_t blocks = (n + 4 * kBlockThreads - 1) / (4 * kBlockThreads);
+  if (!blocks) return;
+  hipLaunchKernelGGL(plane_support_kernel, dim3(blocks), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), scene, n,
+                     reinterpret_cast<const float4*>(planes4), n_hyp, threshold, counts);
+}
+void launch_plane_moments(void* stream, const float* scene, uint32_t n, const float* plane4, float threshold, double* partials, uint32_t n_blocks) {
+  if (!n_blocks) return;
+  hipLaunchKernelGGL(plane_moments_kernel, dim3(n_blocks), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), scene, n,
+                     make_float4(plane4[0], plane4[1], plane4[2], plane4[3]), threshold, partials);
 }
 
 void launch_rows_to_planes(void* stream, const float* rows, uint32_t fstride, uint32_t n, float* planes, float* normals, size_t stride,

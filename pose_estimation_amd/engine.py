@@ -314,6 +314,16 @@ class IcpEngine:
         self._check(lib.mi355_icp_scene_download(self._h, out.ctypes.data, n.value, C.byref(n)))
         return out
 
+    def scene_fit_plane(self, distance_threshold: float = 0.0001, max_iterations: int = 100, probability: float = 0.99,
+                        seed: int = 0x5EEDC0DE, optimize: bool = True):
+        """RANSAC plane fit of the current scene with the reference's parameters by default (pose_estimation.cpp:285-297).
+        Returns (coefficients float32[4], inliers, iterations)."""
+        fp = _lib.PlaneFitParams(distance_threshold, max_iterations, probability, seed, int(optimize), 0)
+        coeff = np.empty(4, dtype=np.float32)
+        n, it = C.c_size_t(), C.c_int()
+        self._check(lib.mi355_icp_scene_fit_plane(self._h, C.byref(fp), coeff.ctypes.data, C.byref(n), C.byref(it)))
+        return coeff, n.value, it.value
+
     def scene_normals(self, k: int = 20, flip_viewpoint: bool = True, viewpoint=(0.0, 0.0, 0.0), want_neighbors: bool = False):
         """k-NN PCA normals of the current scene (computeNormalsPC3d semantics). Returns normals [n, 3] (and the
         neighbour indices [n, min(k, n)] when asked); the normals also stay on the device for scene_commit_target."""

@@ -94,12 +94,19 @@ int main(int argc, char** argv) {
       for (int k = 0; k < n_cand; ++k) results[k]->updatePose(rotation_about(0.2, 1, -0.4, 1.0 + k, 0.01, -0.02, 0.015));
       const auto t0 = std::chrono::steady_clock::now();
       eng.scene_load(mi355::CloudView{raw.data(), raw.size() / 3, 12});
+      // create_surface_match_pc's chain (pose_estimation.cpp:248-258): NaN removal, then remove_planes(num_planes = 1):
+      // RANSAC plane fit (:285-297) on the cleaned cloud, then the distance band around the FITTED plane (:310-333)
       mi355_scene_filter fin{};
       fin.kind = MI355_SCENE_FILTER_FINITE;
+      eng.scene_filter({fin});
+      std::size_t plane_inliers = 0;
+      const std::array<float, 4> plane = eng.scene_fit_plane(0.0001f, 100, &plane_inliers);
       mi355_scene_filter band{};
-      band.kind = MI355_SCENE_FILTER_PLANE_BAND_REMOVE;  // plane 0x + 0y + 1z + 1.3 = 0, band 0.005 (pose_estimation.cpp:320)
-      band.p[0] = 0.f; band.p[1] = 0.f; band.p[2] = 1.f; band.p[3] = 1.3f; band.p[4] = 0.005f;
-      const size_t kept = eng.scene_filter({fin, band});
+      band.kind = MI355_SCENE_FILTER_PLANE_BAND_REMOVE;  // band 0.005 (pose_estimation.cpp:320)
+      band.p[0] = plane[0]; band.p[1] = plane[1]; band.p[2] = plane[2]; band.p[3] = plane[3]; band.p[4] = 0.005f;
+      const size_t kept = eng.scene_filter({band});
+      if (rep == 0)
+        std::printf("fitted plane %.7g %.7g %.7g %.7g with %zu inliers (the table was put at z = -1.3)\n", plane[0], plane[1], plane[2], plane[3], plane_inliers);
       const auto t1 = std::chrono::steady_clock::now();
       eng.scene_normals(20, true, {0.f, 0.f, 0.f});  // computeNormalsPC3d(scene, out, 20, true, viewpoint 0)
       const auto t2 = std::chrono::steady_clock::now();
@@ -113,7 +120,7 @@ int main(int argc, char** argv) {
       const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
       };
-      std::printf("pipeline pass %d: %zu raw points -> %zu kept | upload+filters %.3f ms, normals %.3f ms, commit+model upload %.3f ms, "
+      std::printf("pipeline pass %d: %zu raw points -> %zu kept | upload+filters+plane fit %.3f ms, normals %.3f ms, commit+model upload %.3f ms, "
                   "ICP of %zu candidates %.3f ms, total %.3f ms\n",
                   rep, raw.size() / 3, kept, ms(t0, t1), ms(t1, t2), ms(t2, t3), subset.size(), ms(t3, t4), ms(t0, t4));
       }

@@ -13,6 +13,7 @@
 #include <array>
 #include <cmath>
 #include <cstddef>
+#include <cstdint>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -89,6 +90,20 @@ class Engine {
     std::vector<float> out(3 * n);
     check(mi355_icp_scene_download(ctx_, out.data(), n, &n), "mi355_icp_scene_download");
     return out;
+  }
+  // pcl::SACSegmentation as the reference sets it up (pose_estimation.cpp:285-297): plane, RANSAC, optimised coefficients,
+  // distance threshold 0.0001, 100 iterations.  Returns a, b, c, d of ax + by + cz + d = 0.
+  std::array<float, 4> scene_fit_plane(float distance_threshold = 0.0001f, int max_iterations = 100, std::size_t* inliers = nullptr,
+                                       std::uint64_t seed = 0x5EEDC0DEull) {
+    mi355_plane_fit_params fp{};
+    fp.distance_threshold = distance_threshold;
+    fp.max_iterations = max_iterations;
+    fp.probability = 0.99;
+    fp.seed = seed;
+    fp.optimize = 1;
+    std::array<float, 4> coeff{};
+    check(mi355_icp_scene_fit_plane(ctx_, &fp, coeff.data(), inliers, nullptr), "mi355_icp_scene_fit_plane");
+    return coeff;
   }
   void scene_normals(int k, bool flip, const std::array<float, 3>& viewpoint) {
     check(mi355_icp_scene_normals(ctx_, k, flip ? 1 : 0, viewpoint.data(), nullptr, nullptr), "mi355_icp_scene_normals");

@@ -314,3 +314,22 @@ def smallest_eigvec3(Cm):
     v = np.empty(3)
     lib.oracle_smallest_eigvec3(Cm.ctypes.data, v.ctypes.data)
     return v
+
+
+# ---- RANSAC plane fit (reference pose_estimation.cpp:285-297) ----
+lib.oracle_plane_fit.restype = C.c_int
+lib.oracle_plane_fit.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_double, C.c_uint64, C.c_int, C.c_void_p,
+                                 C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+
+
+def plane_fit(xyz, distance_threshold=0.0001, max_iterations=100, probability=0.99, seed=0x5EEDC0DE, optimize=True):
+    """(status, coefficients float32[4], inliers, iterations, hypothesis planes [max_iterations, 4], their support counts)."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    assert xyz.ndim == 2 and xyz.shape[1] == 3
+    out = np.zeros(4, dtype=np.float32)
+    planes = np.zeros((max_iterations, 4), dtype=np.float32)
+    counts = np.zeros(max_iterations, dtype=np.uint32)
+    n, it = C.c_size_t(), C.c_int()
+    st = lib.oracle_plane_fit(xyz.ctypes.data, xyz.shape[0], float(distance_threshold), max_iterations, float(probability), seed,
+                              int(optimize), out.ctypes.data, C.byref(n), C.byref(it), planes.ctypes.data, counts.ctypes.data)
+    return st, out, n.value, it.value, planes, counts
