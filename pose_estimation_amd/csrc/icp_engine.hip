@@ -934,8 +934,14 @@ DevicePlanes level_view(const CloudSet& set, int level) { return level ? set.lev
 
 int ensure_ref_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs, size_t owner_total) {
   int st;
-  if (std::max<size_t>(owner_total, 1) > c->owner_cap) c->owner_epoch = 0;  // a fresh table holds garbage: clear before use
-  if ((st = grow(c, c->owner, c->owner_cap, std::max<size_t>(owner_total, 1))) != MI355_ICP_OK) return st;
+  {
+    // a re-grown table holds garbage: clear it to "never written" right here.  The pass tag is NOT touched: it must be a
+    // function of the call's pass sequence alone, or ranks whose engines grew their tables at different times (different
+    // histories) would tag the same pass differently and the min-reduction of a slab-sharded run would pick by tag.
+    const size_t before = c->owner_cap;
+    if ((st = grow(c, c->owner, c->owner_cap, std::max<size_t>(owner_total, 1))) != MI355_ICP_OK) return st;
+    if (c->owner_cap != before) HIP_TRY(c, hipMemsetAsync(c->owner, 0xFF, c->owner_cap * sizeof(unsigned long long), c->stream));
+  }
   if ((st = grow(c, c->selected, c->selected_cap, std::max<size_t>(plan.out_total, 1))) != MI355_ICP_OK) return st;
   if ((st = grow(c, c->ref_partials, c->ref_partials_cap, static_cast<size_t>(std::max<uint32_t>(plan.partial_total, 1)) * kRefSums)) != MI355_ICP_OK) return st;
   if (n_jobs > c->ref_jobs_cap) {
@@ -1418,6 +1424,7 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
   const bool sharded = c->comm.attached();
   std::vector<uint64_t> shard_begin, shard_total;
   if (sharded) {
+
     const size_t n_clouds = c->sources.clouds.size();
     std::vector<uint32_t> mine(n_clouds + 1), all((n_clouds + 1) * static_cast<size_t>(c->comm.size));
     mine[0] = static_cast<uint32_t>(n_clouds);
@@ -1443,6 +1450,8 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
     return (sharded ? shard_total[static_cast<size_t>(s)] : c->sources.clouds[static_cast<size_t>(s)].n) >> level;
   };
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+  c->owner_epoch = 0;  // the picky pass tags restart with every call (table cleared at its first pass): a function of the
+                       // call's pass sequence only, hence the same on every rank of a slab-sharded run
   c->call_pruned = (rp->flags & MI355_ICP_FLAG_PRUNED_SCAN) != 0;
   const bool profile = c->profile_always || (rp->flags & MI355_ICP_FLAG_PROFILE) != 0;
 
@@ -1583,6 +1592,7 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
   if ((plan.xfilter || plan.pruned) && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
   if ((plan.pruned || plan.sorted_src) && (st = ensure_level_xcopy(c, c->sources, level)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+  c->owner_epoch = 0;
   JobDesc J = plan.jobs[0];
   RefJobDesc R{};
   if (!pose_to_f32(pose_cur, J.pose) || !pose_to_f32(pose_start, R.pose_start)) return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "reference_pass: non-finite pose");

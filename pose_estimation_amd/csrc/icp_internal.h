@@ -127,8 +127,8 @@ static_assert(sizeof(RefJobDesc) == 80, "RefJobDesc layout");
 
 // "Picky" owner key of an accepted pair: atomicMin over these makes the smallest distance win, the lowest source index on
 // ties.  The 6-bit prefix is the pass's tag, DEcreasing from pass to pass, so a key of this pass beats whatever an earlier
-// pass (or another job or level that used the slot) left behind and the table needs no clearing between passes - only once
-// per 63 passes, when the tag wraps (all-ones = "never written" sorts after every tag).  31 bits of distance (finite
+// pass (or another job or level that used the slot) left behind and the table needs no clearing between passes - only at
+// the first pass of a call and when the tag wraps after 63 passes (all-ones = "never written" sorts after every tag).  31 bits of distance (finite
 // non-negative float32 bits are < 2^31), 27 bits of source index: 134M points per model.
 constexpr uint32_t kPickyIndexBits = 27;
 #if defined(__HIPCC__)

@@ -45,6 +45,8 @@ def _ref_worker(rank, world, port, q):
         with pa.IcpEngine(0) as eng:
             eng.set_targets(targets)
             eng.set_sources(slabs)
+            if rank == 0:   # rank 0's engine has a history the others lack (its owner-table pass tags have advanced):
+                eng.align_reference(np.eye(4)[None], 30, 0.005, 2.5, 4)   # the sharded call must not depend on it
             pd.attach_external_comm(eng)
             res = eng.align_reference(np.stack(REF_INITS), 120, 0.005, 2.5, 6, source_ids=REF_IDS, target_ids=REF_IDS)
             eng.comm_detach()
