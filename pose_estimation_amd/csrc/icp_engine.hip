@@ -839,14 +839,17 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
   }
   HIP_TRY(c, hipMemcpyAsync(c->sums_host, c->sums_dev, (n_sums + 2 * n_act) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (const int sst = sync_pass(c); sst != MI355_ICP_OK) return sst;
-  if (defer) {
-    bool settled = true;  // the decision must be the same on every rank: the flags are summed over the ranks
+  if (defer || exchange) {
+    // The decision must be the same on every rank (the flags are summed over the ranks) - including ranks whose own
+    // plan did not defer anything (another scan kernel for their slab size): they repeat the pass with the others, or the
+    // next collective would wait for them for ever.
+    bool settled = true;
     for (size_t k = 0; k < n_act; ++k) settled = settled && c->sums_host[n_sums + k] == 0.0;
     if (!settled) {
       *retry = true;
       return MI355_ICP_OK;
     }
-    book_overflow(c, c->sums_host + n_sums + n_act, n_active);
+    if (defer) book_overflow(c, c->sums_host + n_sums + n_act, n_active);
   }
   c->prof.iterations += 1;
   c->prof.pairs_evaluated += pairs;
@@ -1066,14 +1069,14 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
   HIP_TRY(c, hipMemcpyAsync(c->ref_sums_host, c->ref_sums_dev, (n_sums + 3 * n_act) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (const int sst = sync_pass(c); sst != MI355_ICP_OK) return sst;
   for (size_t k = 0; k < n_act; ++k) c->thr_host[k] = static_cast<float>(c->ref_sums_host[n_sums + n_act + k]);
-  if (defer) {
+  if (defer || sharded) {  // every rank takes the same decision (see run_pass_once)
     bool settled = true;
     for (size_t k = 0; k < n_act; ++k) settled = settled && c->ref_sums_host[n_sums + k] == 0.0;
     if (!settled) {
       *retry = true;
       return MI355_ICP_OK;
     }
-    book_overflow(c, c->ref_sums_host + n_sums + 2 * n_act, n_active);
+    if (defer) book_overflow(c, c->ref_sums_host + n_sums + 2 * n_act, n_active);
   }
   c->prof.iterations += 1;
   c->prof.pairs_evaluated += pairs;
@@ -1493,6 +1496,8 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
       owner_total += level_clouds(c->targets, level)[ptid[a]].padded;
     }
     if ((st = ensure_ref_buffers(c, plan, static_cast<size_t>(np), owner_total)) != MI355_ICP_OK) return st;
+    // the selection histograms are left clear by every completed pass; make that true whatever an earlier call left behind
+    HIP_TRY(c, hipMemsetAsync(c->select_work, 0, c->ref_jobs_cap * (2048 + 4) * sizeof(uint32_t), c->stream));
     if ((plan.xfilter || plan.pruned) && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
     if ((plan.pruned || plan.sorted_src) && (st = ensure_level_xcopy(c, c->sources, level)) != MI355_ICP_OK) return st;
 
