@@ -6,7 +6,7 @@ torch.distributed.run, one rank per GPU; run plainly (no WORLD_SIZE in the envir
 N ranks ITSELF - fresh child processes, started before this process has touched torch or HIP - and relays rank 0's JSON
 line.  `n_gpus` in that line is what the communicator reports (ncclCommCount), and a run whose rank count differs from
 --gpus exits non-zero instead of printing a mislabelled line.  A *step* is one ICP iteration: source transform + exact brute-force NN scan +
-covariance accumulation + (N > 1: one RCCL all-reduce of 17 doubles) + host Kabsch/convergence, all
+covariance accumulation + (N > 1: one RCCL exchange of 17 doubles per rank: all-gather + rank-ordered sum) + host Kabsch/convergence, all
 through `mi355_icp_align`.  Clouds are uploaded before the timed region (inputs resident in HBM).
 
 Workload (BASELINE.json): N = 1 is config[2] "1M<->1M synthetic scene, 1 MI355X"; N > 1 keeps one
@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--exact-leg-steps", type=int, default=3)
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--collective", choices=["native", "torch"], default="native",
-                    help="N > 1: RCCL all-reduce issued inside the engine (native) or by torch.distributed")
+                    help="N > 1: the per-iteration exchange issued inside the engine over RCCL (native) or by torch.distributed")
     ap.add_argument("--force-dist", action="store_true", help="exercise the distributed code path even at N = 1")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --n-source points PER GPU, so N = 8 is BASELINE config[4] 8M<->1M; strong: "

@@ -42,7 +42,7 @@ extern "C" {
  *   [16]     sum d2       float32 squared distance of each accepted pair
  * [4..15] are the "12 covariance/centroid scalars" of the design brief; [0..3]
  * and [16] are the bookkeeping the convergence test and rejection need.  This
- * block is what crosses xGMI in the per-iteration RCCL all-reduce. */
+ * block is what crosses xGMI once per iteration in a slab-sharded run (all-gathered, then added in rank order). */
 #define MI355_ICP_NSUMS 17
 
 typedef enum mi355_icp_status {
@@ -183,7 +183,7 @@ int mi355_icp_level_slab(size_t n_total, size_t begin, size_t count, int level, 
  *   out_converged  n_jobs ints, 1 if criterion A or B fired
  * Returns MI355_ICP_OK unless the call as a whole could not run.
  * With a communicator attached every rank must make the same call (same jobs,
- * same poses); sums are all-reduced so every rank returns identical poses.
+ * same poses); the ranks' sums are exchanged and added in rank order so every rank returns identical poses.
  * Replaces: ICP::registerModelToScene(model, scene, poses). */
 int mi355_icp_align(mi355_icp_ctx* ctx, int n_jobs, const int* source_ids, const int* target_ids,
                     const double* init_poses, const mi355_icp_params* params, double* out_poses,
@@ -194,7 +194,7 @@ int mi355_icp_align(mi355_icp_ctx* ctx, int n_jobs, const int* source_ids, const
  * rounding of poses[16*k..], exact 1-NN, accumulate.
  *   out_index   concatenated over jobs, source-cloud order: int32 target index  (may be NULL)
  *   out_dist2   same shape: float32 squared distance                         (may be NULL)
- *   out_sums    MI355_ICP_NSUMS * n_jobs doubles, LOCAL to this rank (never all-reduced)
+ *   out_sums    MI355_ICP_NSUMS * n_jobs doubles, LOCAL to this rank (never exchanged)
  * max_correspondence_distance as in params (<= 0 keeps all).
  * A source point whose distance to EVERY target is +inf or NaN (coordinates or a pose that overflow float32)
  * gets the oracle's answer for "nothing below +inf": index 0, d2 = +inf; the call still returns MI355_ICP_OK and

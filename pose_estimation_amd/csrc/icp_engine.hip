@@ -1,6 +1,6 @@
 // icp_engine.hip — host side of the engine behind include/mi355_icp.h:
 // device-resident clouds (SoA planes), the per-call planner, the ICP iteration
-// loop (launch scan -> resolve/accumulate -> final reduce -> [RCCL all-reduce]
+// loop (launch scan -> resolve/accumulate -> final reduce -> [cross-rank exchange, comm.hip]
 // -> 17 doubles to the host -> Kabsch + convergence), and the C-ABI glue.
 //
 // Replaces, in the reference, the object constructed at

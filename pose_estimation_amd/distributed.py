@@ -1,6 +1,6 @@
 """Slab-sharded alignment with the collective run by the caller.
 
-Two ways to run the per-iteration all-reduce of the MI355_ICP_NSUMS x n_jobs doubles:
+Three ways to run the per-iteration exchange of the MI355_ICP_NSUMS x n_jobs doubles:
 
 * native (preferred, used by bench.py): ``IcpEngine.comm_attach`` joins the engine to an RCCL
   communicator and ``IcpEngine.align`` exchanges the sums once per iteration on its own stream
