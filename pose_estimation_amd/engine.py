@@ -238,6 +238,10 @@ class IcpEngine:
                                              float(max_correspondence_distance),
                                              idx.ctypes.data if want_pairs else None,
                                              d2.ctypes.data if want_pairs else None, sums.ctypes.data))
+        note = self.last_error()
+        if note:  # status OK with a note: some point had no finite distance and got the oracle's (0, +inf) - see the header
+            import warnings
+            warnings.warn(f"mi355_icp_correspond: {note}", RuntimeWarning, stacklevel=2)
         return idx, d2, sums
 
     def debug_filter_bounds(self, pose: np.ndarray, source_id: int = 0, target_id: int = 0):
