@@ -661,6 +661,18 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint4 bq[kSets];
   float adj[kSets], ee[kSets];
+  // Per-chunk skip test in the RAW domain.  lo() below is monotone in the accumulator value, so there is a smallest value
+  // from which the chunk's lower bound reaches l3 and the chunk cannot enter the point's three best; rawthr[m] holds the bits
+  // of an UPPER bound R of that value, and "minimum >= R" (one unsigned compare: positive floats order like their bits,
+  // +inf and NaN patterns after them) replaces the four float operations of lo() in almost every chunk.
+  //   lo = (raw + adj - ee) * 0.99902 >= l3   <=   raw >= l3 / 0.99902 + ee - adj;   R = (l3 * 1.001 + (ee - adj)) * (1 + 2^-20):
+  // the 2^-20 (16 u) covers the three roundings of lo() on operands of raw's size and R's own two; l3 = +inf gives R = +inf
+  // (only +inf / NaN minima skip, as lo < +inf demands), and ee - adj >= 2 ee > 0 keeps R positive.
+  uint32_t rawthr[kSets];
+  auto raw_threshold = [](float l3v, float adjv, float eev) -> uint32_t {
+    const float x = l3v * 1.001f + (eev - adjv);
+    return __float_as_uint(x + x * 9.5367431640625e-07f);
+  };
   for (uint32_t tile = tile0; tile < tile1; ++tile) {
     const bool more = tile + 1 < tile1;
     // The operand image of kXbCentreGroup consecutive tiles shares one centre and one r^2 (xtarget_kernels.hip): the
@@ -682,6 +694,7 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
       adj[m] = qq - bf16_value(bias);  // s = MFMA + adj
       const uint32_t w0 = hi ? pz : px;
       bq[m] = make_uint4(w0, w0, hi ? 0x3F803F80u : py, hi ? (0x00003F80u | (bias << 16)) : py);
+      rawthr[m] = raw_threshold(l3[m], adj[m], ee[m]);
     }
     }
     const uint4* __restrict__ A = lds + cur * kXbTileVecs + (hi ? kTile : 0) + (lane & 31u);
@@ -742,13 +755,16 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
       const uint32_t run = ((tile * kXbChunksPerTile + c) << 1) | (hi ? 1u : 0u);
 #pragma unroll
       for (int m = 0; m < kSets; ++m) {
-        const float s = __uint_as_float(cmin[m]) + adj[m];
-        const float lo = __builtin_fmaxf((s - ee[m]) * 0.99902f, 0.0f);
+        const uint32_t raw = cmin[m];
         cmin[m] = 0x7F800000u;
+        // once the scan has passed a point's neighbourhood its three best granules rarely change: unless some lane of the
+        // wave holds a minimum below its raw threshold, the chunk is done with one compare
+        if (!kDump && __builtin_amdgcn_ballot_w64(raw < rawthr[m]) == 0) continue;
+        const float s = __uint_as_float(raw) + adj[m];
+        const float lo = __builtin_fmaxf((s - ee[m]) * 0.99902f, 0.0f);
         if constexpr (kDump)  // NaN (a non-finite bound) is reported as 0: "no statement", like the keys of an unsafe point
           dump[static_cast<size_t>(run) * dump_stride + J.out_off + sb * kScanSrcPerBlock + src_local + m * 32] = (unsafe[m] || !(lo == lo)) ? 0.0f : lo;
-        // once the scan has passed a point's neighbourhood its three best granules rarely change: the sorted insert
-        // (12 selects) is skipped unless some lane of the wave needs it (rarely, with the sources in Morton order too)
+        // the sorted insert (12 selects) runs only if some lane needs it (rarely, with the sources in Morton order too)
         if (__builtin_amdgcn_ballot_w64(lo < l3[m]) != 0) {
           const float o1 = l1[m], o2 = l2[m], o3 = l3[m];
           const uint32_t i1 = c1[m], i2 = c2[m], i3 = c3[m];
@@ -761,6 +777,7 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
           c2[m] = d1 ? i1 : keepi2;
           l1[m] = d1 ? lo : o1;
           c1[m] = d1 ? run : i1;
+          rawthr[m] = raw_threshold(l3[m], adj[m], ee[m]);
         }
       }
     }
