@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -141,8 +142,18 @@ struct mi355_icp_ctx {
   uint32_t* select_work = nullptr;  // per job: 2048-bin histogram + selection state of the multi-workgroup rank select
   RefJobDesc* rjobs_dev = nullptr;
   RefJobDesc* rjobs_host = nullptr;    // pinned
-  double* ref_sums_host = nullptr;     // pinned
+  double* ref_sums_host = nullptr;     // pinned, mapped: the last workgroup of a single-GPU pass writes the result here itself
   float* thr_host = nullptr;           // pinned
+  double* ref_sums_mapped = nullptr;   // ref_sums_host as the device addresses it
+  uint32_t* pass_done = nullptr;       // device, [ref_jobs_cap + 1], zero between passes (PassTail::done)
+  uint32_t* ready_host = nullptr;      // pinned, mapped word the pass publishes its sequence number in
+  uint32_t* ready_mapped = nullptr;
+  uint32_t pass_seq = 0;
+  bool error_word_known = false;       // the last pass brought the call's error word along (PassTail::error_flag): no copy needed
+  uint32_t error_word = 0;
+  bool pass_tail = true;               // MI355_ICP_PASS_TAIL=0: final-reduce launch + device-to-host copy instead (A/B)
+  size_t keys_clean = 0;               // leading slots of `keys` known to hold ~0 (merged key rows of reference mode are
+                                       // handed back cleared by the resolve; anything else that writes keys zeroes this)
 
   // scene preparation (packed AoS xyz, ping-pong)
   float* scene[2] = {nullptr, nullptr}; size_t scene_cap = 0;
@@ -225,6 +236,19 @@ int sync_pass(mi355_icp_ctx* c) {
     if (e != hipErrorNotReady) return fail(c, MI355_ICP_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MI355_ICP_OK;
+}
+
+// The same for a pass whose last workgroup publishes `seq` in pinned memory behind its results (PassTail): no copy command
+// to wait for, the word is there as soon as the rows are.
+int wait_pass(mi355_icp_ctx* c, uint32_t seq) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spin = 1;; ++spin) {
+    if (__atomic_load_n(c->ready_host, __ATOMIC_ACQUIRE) == seq) return MI355_ICP_OK;
+    if ((spin & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1500)) break;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // long scans: sleep; a faulted launch: the error comes out here
+  if (__atomic_load_n(c->ready_host, __ATOMIC_ACQUIRE) != seq) return fail(c, MI355_ICP_ERR_INTERNAL, "a reference-mode pass ended without publishing its result");
   return MI355_ICP_OK;
 }
 
@@ -319,7 +343,11 @@ int grow(mi355_icp_ctx* c, T*& ptr, size_t& cap, size_t need) {
 
 int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs) {
   int st;
-  if (!plan.fused && (st = grow(c, c->keys, c->keys_cap, static_cast<size_t>(plan.max_split) * plan.out_total)) != MI355_ICP_OK) return st;
+  {
+    const size_t before = c->keys_cap;
+    if (!plan.fused && (st = grow(c, c->keys, c->keys_cap, static_cast<size_t>(plan.max_split) * plan.out_total)) != MI355_ICP_OK) return st;
+    if (c->keys_cap != before) c->keys_clean = 0;  // a new buffer holds anything
+  }
   if (plan.out_total > c->out_cap) {
     if (c->out_index) { HIP_TRY(c, hipFree(c->out_index)); c->out_index = nullptr; }
     if (c->out_dist2) { HIP_TRY(c, hipFree(c->out_dist2)); c->out_dist2 = nullptr; }
@@ -557,6 +585,7 @@ int run_overflow_fallback(mi355_icp_ctx* c, const Plan& plan, int n_active, cons
     prow += J.src_blocks;
   }
   if ((st = grow(c, c->keys, c->keys_cap, static_cast<size_t>(max_split) * padded_total)) != MI355_ICP_OK) return st;
+  c->keys_clean = 0;
   if ((st = grow(c, c->partials, c->partials_cap, std::max<size_t>(blocks_total, plan.partial_total) * MI355_ICP_NSUMS)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemcpyAsync(c->jobs2_dev, c->jobs2_host, who.size() * sizeof(JobDesc), hipMemcpyHostToDevice, c->stream));
   const DevicePlanes F{c->fb_planes, c->fb_planes + padded_total, c->fb_planes + 2 * padded_total};
@@ -820,6 +849,7 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
     if (sbx) launch_accumulate(c->stream, c->jobs_dev, n_active, sbx, S, T, c->out_index, c->out_dist2, c->partials);
   } else {
     if (plan.merged_keys && plan.out_total) HIP_TRY(c, hipMemsetAsync(c->keys, 0xFF, static_cast<size_t>(plan.out_total) * sizeof(unsigned long long), c->stream));
+    c->keys_clean = 0;
     if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
     if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
@@ -863,6 +893,11 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
 }
 
 int check_error_flag(mi355_icp_ctx* c) {
+  if (c->error_word_known) {  // the last pass was a reference-mode one that ended itself: it read the word for us
+    c->error_word_known = false;
+    if (c->error_word) c->err = "a non-finite distance was met during the scan (overflowing pose or coordinates)";
+    return MI355_ICP_OK;
+  }
   HIP_TRY(c, hipMemcpyAsync(c->flag_host, c->error_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (*c->flag_host) c->err = "a non-finite distance was met during the scan (overflowing pose or coordinates)";
@@ -966,7 +1001,11 @@ int ensure_ref_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs, size_t
     HIP_TRY(c, hipMemsetAsync(c->select_work, 0, want * (2048 + 4) * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->rjobs_dev), want * sizeof(RefJobDesc)));
     HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->rjobs_host), want * sizeof(RefJobDesc), hipHostMallocDefault));
-    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->ref_sums_host), want * (kRefSums + 3) * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->ref_sums_host), want * (kRefSums + 3) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->ref_sums_mapped), c->ref_sums_host, 0));
+    if (c->pass_done) { HIP_TRY(c, hipFree(c->pass_done)); c->pass_done = nullptr; }
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->pass_done), (want + 1) * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->pass_done, 0, (want + 1) * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->thr_host), want * sizeof(float), hipHostMallocDefault));
     c->ref_jobs_cap = want;
   }
@@ -1021,18 +1060,26 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
     const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile, defer);
     if (fst != MI355_ICP_OK) return fst;
   } else {
-    if (plan.merged_keys && plan.out_total) HIP_TRY(c, hipMemsetAsync(c->keys, 0xFF, static_cast<size_t>(plan.out_total) * sizeof(unsigned long long), c->stream));
+    // merged key rows come back cleared from the resolve (which runs whenever the scan does): one memset per plan, not per pass
+    if (plan.merged_keys && plan.out_total && c->keys_clean < plan.out_total) {
+      HIP_TRY(c, hipMemsetAsync(c->keys, 0xFF, static_cast<size_t>(plan.out_total) * sizeof(unsigned long long), c->stream));
+      c->keys_clean = plan.out_total;
+    }
+    if (!plan.merged_keys) c->keys_clean = 0;
     if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-    if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
+    if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, nullptr, c->error_flag);
+    else if (bx) c->keys_clean = 0;
   }
   const bool sharded = c->comm.attached();
   const char* why = nullptr;
+  bool scattered = false;  // the selection launch offered the accepted pairs to the owner table as well
   if (rejection_scale > 0.0f) {
     uint32_t max_n = 0;
     for (int k = 0; k < n_active; ++k) max_n = std::max(max_n, c->jobs_host[k].src_n);
     if (!sharded) {
-      launch_rejection_select(c->stream, c->jobs_dev, n_active, max_n, c->out_dist2, rejection_scale, c->thr_dev, c->select_work, c->select_work + c->ref_jobs_cap * 2048);
+      scattered = launch_rejection_select(c->stream, c->jobs_dev, n_active, max_n, c->out_dist2, rejection_scale, c->thr_dev, c->select_work,
+                                          c->select_work + c->ref_jobs_cap * 2048, c->rjobs_dev, c->out_index, c->owner);
     } else {
       // slab-sharded: the median and the MAD are those of ALL ranks' distances - every rank histograms its slab, the
       // 2048-bin counts are added across ranks (integers: exact in any order), every rank picks the same digit
@@ -1047,18 +1094,32 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
     for (int k = 0; k < n_active; ++k) c->thr_host[k] = std::numeric_limits<float>::infinity();
     HIP_TRY(c, hipMemcpyAsync(c->thr_dev, c->thr_host, static_cast<size_t>(n_active) * sizeof(float), hipMemcpyHostToDevice, c->stream));
   }
+  // single GPU: the accumulate launch ends the pass by itself (PassTail) - every job has a workgroup to be its last one
+  bool tail_on = c->pass_tail && !sharded && sbx > 0;
+  for (int k = 0; k < n_active; ++k) tail_on = tail_on && c->jobs_host[k].src_blocks > 0;
+  PassTail tail;
+  if (tail_on) {
+    tail.done = c->pass_done;
+    tail.sums = c->ref_sums_mapped;
+    tail.overflow_count = plan.fused ? c->overflow_count : nullptr;
+    tail.overflow_cap = defer ? overflow_cap(c, n_active) : 0xFFFFFFFFu;
+    tail.seq = ++c->pass_seq;
+    tail.ready = c->ready_mapped;
+    tail.error_flag = c->error_flag;
+  }
+  c->error_word_known = false;
   if (sbx || sharded) {
-    if (sbx) launch_picky_scatter(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, c->out_index, c->out_dist2, c->thr_dev, c->owner);
+    if (sbx && !scattered) launch_picky_scatter(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, c->out_index, c->out_dist2, c->thr_dev, c->owner);
     if (sharded) {  // targets are replicated: the owner of a target is the smallest key any rank offered
       const int cst = comm_min_u64(c->comm, c->owner, std::max<size_t>(owner_total, 1), c->stream, &why);
       if (cst != MI355_ICP_OK) return fail(c, cst, std::string("cross-rank owner table: ") + (why ? why : "?"));
     }
     if (sbx) launch_ref_accumulate(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, S, T, c->targets.normal_view(), c->out_index,
-                                   c->out_dist2, c->thr_dev, c->owner, c->selected, c->ref_partials);
+                                   c->out_dist2, c->thr_dev, c->owner, c->selected, c->ref_partials, tail);
   }
-  // ref_sums_dev: [n x 29 sums][n overflow-excess flags][n thresholds][n overflow counts]
-  launch_ref_final_reduce(c->stream, c->jobs_dev, n_active, c->ref_partials, c->ref_sums_dev, c->thr_dev, plan.fused ? c->overflow_count : nullptr,
-                          defer ? overflow_cap(c, n_active) : 0xFFFFFFFFu);
+  // the pass result, ref_sums_dev or (PassTail) ref_sums_host directly: [n x 29 sums][n overflow-excess flags][n thresholds][n overflow counts]
+  if (!tail_on) launch_ref_final_reduce(c->stream, c->jobs_dev, n_active, c->ref_partials, c->ref_sums_dev, c->thr_dev, plan.fused ? c->overflow_count : nullptr,
+                                        defer ? overflow_cap(c, n_active) : 0xFFFFFFFFu);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   HIP_TRY(c, hipGetLastError());
   const size_t n_sums = static_cast<size_t>(n_active) * kRefSums, n_act = static_cast<size_t>(n_active);
@@ -1066,8 +1127,15 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
     const int cst = comm_sum_f64_rank_order(c->comm, c->ref_sums_dev, n_sums + n_act, c->stream, &why);
     if (cst != MI355_ICP_OK) return fail(c, cst == MI355_ICP_ERR_HIP ? MI355_ICP_ERR_HIP : MI355_ICP_ERR_COMM, std::string("cross-rank exchange: ") + (why ? why : "?"));
   }
-  HIP_TRY(c, hipMemcpyAsync(c->ref_sums_host, c->ref_sums_dev, (n_sums + 3 * n_act) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  if (const int sst = sync_pass(c); sst != MI355_ICP_OK) return sst;
+  if (tail_on) {
+    if (const int sst = wait_pass(c, tail.seq); sst != MI355_ICP_OK) return sst;
+    c->error_word = c->ref_sums_host[static_cast<size_t>(n_active) * (kRefSums + 3)] != 0.0 ? 1u : 0u;
+    c->error_word_known = true;
+    if (profile) HIP_TRY(c, hipStreamSynchronize(c->stream));  // the events are read below
+  } else {
+    HIP_TRY(c, hipMemcpyAsync(c->ref_sums_host, c->ref_sums_dev, (n_sums + 3 * n_act) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (const int sst = sync_pass(c); sst != MI355_ICP_OK) return sst;
+  }
   for (size_t k = 0; k < n_act; ++k) c->thr_host[k] = static_cast<float>(c->ref_sums_host[n_sums + n_act + k]);
   if (defer || sharded) {  // every rank takes the same decision (see run_pass_once)
     bool settled = true;
@@ -1168,6 +1236,10 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   if ((e = hipMalloc(reinterpret_cast<void**>(&c->error_flag), sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(c->error_flag, 0, sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->flag_host), sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->ready_host), 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
+  if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->ready_mapped), c->ready_host, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
+  *c->ready_host = 0;
+  if (const char* v = std::getenv("MI355_ICP_PASS_TAIL")) c->pass_tail = std::atoi(v) != 0;
   *out = c;
   return MI355_ICP_OK;
 }
@@ -1229,6 +1301,8 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   (void)hipFree(c->rjobs_dev);
   if (c->rjobs_host) (void)hipHostFree(c->rjobs_host);
   if (c->ref_sums_host) (void)hipHostFree(c->ref_sums_host);
+  if (c->pass_done) (void)hipFree(c->pass_done);
+  if (c->ready_host) (void)hipHostFree(c->ready_host);
   if (c->thr_host) (void)hipHostFree(c->thr_host);
   (void)hipFree(c->keys);
   (void)hipFree(c->out_index);
@@ -1272,6 +1346,7 @@ int mi355_icp_align(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const i
   if ((plan.xfilter || plan.pruned) && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;
   if ((plan.pruned || plan.sorted_src) && (st = ensure_xtarget(c, c->sources)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+  c->error_word_known = false;
 
   struct JobState { double pose[16]; double prev_mse = 0.0; double residual = 0.0; int iters = 0; int status = MI355_ICP_OK; int converged = 0; };
   std::vector<JobState> js(static_cast<size_t>(n_jobs));
@@ -1332,6 +1407,7 @@ int mi355_icp_correspond(mi355_icp_ctx* c, int n_jobs, const int* source_ids, co
   if ((plan.xfilter || plan.pruned) && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;
   if ((plan.pruned || plan.sorted_src) && (st = ensure_xtarget(c, c->sources)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+  c->error_word_known = false;
   for (int k = 0; k < n_jobs; ++k) {
     JobDesc J = plan.jobs[static_cast<size_t>(k)];
     if (!pose_to_f32(poses + 16 * static_cast<size_t>(k), J.pose)) return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "correspond: non-finite pose");
@@ -1453,6 +1529,7 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
     return (sharded ? shard_total[static_cast<size_t>(s)] : c->sources.clouds[static_cast<size_t>(s)].n) >> level;
   };
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+  c->error_word_known = false;
   c->owner_epoch = 0;  // the picky pass tags restart with every call (table cleared at its first pass): a function of the
                        // call's pass sequence only, hence the same on every rank of a slab-sharded run
   c->call_pruned = (rp->flags & MI355_ICP_FLAG_PRUNED_SCAN) != 0;
@@ -1497,7 +1574,8 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
     }
     if ((st = ensure_ref_buffers(c, plan, static_cast<size_t>(np), owner_total)) != MI355_ICP_OK) return st;
     // the selection histograms are left clear by every completed pass; make that true whatever an earlier call left behind
-    HIP_TRY(c, hipMemsetAsync(c->select_work, 0, c->ref_jobs_cap * (2048 + 4) * sizeof(uint32_t), c->stream));
+    // (sharded passes only: the single-GPU selection of jobs below 64k points keeps its histograms in LDS)
+    if (sharded || plan.out_total >= 65536u) HIP_TRY(c, hipMemsetAsync(c->select_work, 0, c->ref_jobs_cap * (2048 + 4) * sizeof(uint32_t), c->stream));
     if ((plan.xfilter || plan.pruned) && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
     if ((plan.pruned || plan.sorted_src) && (st = ensure_level_xcopy(c, c->sources, level)) != MI355_ICP_OK) return st;
 
@@ -1597,6 +1675,7 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
   if ((plan.xfilter || plan.pruned) && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
   if ((plan.pruned || plan.sorted_src) && (st = ensure_level_xcopy(c, c->sources, level)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+  c->error_word_known = false;
   c->owner_epoch = 0;
   JobDesc J = plan.jobs[0];
   RefJobDesc R{};

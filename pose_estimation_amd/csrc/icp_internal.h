@@ -113,6 +113,18 @@ struct JobDesc {
 static_assert(sizeof(JobDesc) == 112, "JobDesc layout");
 
 // ---- reference mode (point-to-plane / rejection / picky / pyramid): icp_ref_kernels.hip ----
+// How ref_accumulate_kernel ends a single-GPU reference-mode pass by itself (done == nullptr: it does not, and
+// ref_final_reduce_kernel plus a device-to-host copy follow).
+struct PassTail {
+  uint32_t* done = nullptr;            // [n_jobs + 1], zero between passes: workgroups finished per job, then jobs finished
+  double* sums = nullptr;              // the pass result block in pinned host memory, as the device addresses it
+  uint32_t* overflow_count = nullptr;  // matrix-core scan: points sent to the overflow list per job (nullptr otherwise)
+  uint32_t overflow_cap = 0xFFFFFFFFu;
+  uint32_t seq = 0;                    // what *ready becomes once every job's rows are written
+  uint32_t* ready = nullptr;           // pinned host word
+  const uint32_t* error_flag = nullptr;  // the call's "non-finite distance met" word; its value rides behind the tail
+};
+
 constexpr int kRefSums = 29;  // 21 upper-triangle A^T A + 6 A^T b + sum |p-q|^2 + count
 struct RefJobDesc {
   uint32_t owner_off;    // first slot of this job's target in the picky owner table
@@ -226,15 +238,16 @@ void launch_gather_points(void* stream, DevicePlanes src, uint32_t src_off, cons
 void launch_scatter_results(void* stream, const uint32_t* list, uint32_t n, const int32_t* idx_tmp, const float* d2_tmp,
                             int32_t* out_index, float* out_dist2, uint32_t out_off);
 void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
-                    DevicePlanes tgt, const unsigned long long* keys, uint32_t key_stride, int32_t* out_index,
+                    DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride, int32_t* out_index,
                     float* out_dist2, double* partials, uint32_t* error_flag);
 void launch_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums,
                          uint32_t* overflow_count, uint32_t overflow_cap);
 
 void launch_subsample(void* stream, const float* in, size_t in_stride, uint32_t in_off, float* out, size_t out_stride,
                       uint32_t out_off, uint32_t n_level, uint32_t n_padded, uint32_t step, float pad);
-void launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_n, const float* dist2, float scale,
-                             float* thr, uint32_t* hists, uint32_t* states);
+bool launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_n, const float* dist2, float scale,
+                             float* thr, uint32_t* hists, uint32_t* states, const RefJobDesc* rjobs_dev = nullptr,
+                             const int32_t* index = nullptr, unsigned long long* owner = nullptr);
 void launch_select_hist(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_n, const float* dist2, uint32_t* hists,
                         uint32_t* states, int pass);
 void launch_select_pick(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t* hists, uint32_t* states, int pass, float scale,
@@ -245,7 +258,7 @@ void launch_picky_scatter(void* stream, const JobDesc* jobs_dev, const RefJobDes
 void launch_ref_accumulate(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
                            uint32_t max_src_blocks, DevicePlanes src, DevicePlanes tgt, DevicePlanes normals,
                            const int32_t* index, const float* dist2, const float* thr, const unsigned long long* owner,
-                           uint8_t* selected, double* partials);
+                           uint8_t* selected, double* partials, const PassTail& tail);
 void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums, const float* thr,
                              uint32_t* overflow_count, uint32_t overflow_cap);
 

@@ -31,9 +31,11 @@
 //     whose unsigned minimum is the lowest distance, then the lowest chunk.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "icp_internal.h"
 
@@ -323,16 +325,21 @@ __device__ __forceinline__ double block_sum(double (&v)[NV], double (*scratch)[N
 // ---------------------------------------------------------------------------------------------
 // N1 (index recovery) + N2 (accumulation).  grid = (max_j src_blocks_j, n_jobs), block = 256.
 // Same (block, lane, p) -> source point mapping as the scan.
+// kSums = false (reference mode: its sums are the point-to-plane ones of ref_accumulate_kernel) recovers the indices only,
+// on a grid of (kResolvePointsPerLane * max_j src_blocks_j, n_jobs) with ONE point per lane - the passes of the coarse
+// pyramid levels are a chain of latency-bound launches, and four dependent points per lane is four times the latency -
+// and, where the scan merged its workgroups into one key row (sub_split), hands the row back cleared for the next pass.
+template <bool kSums>
 __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
     const JobDesc* __restrict__ jobs, const float* __restrict__ sx, const float* __restrict__ sy,
     const float* __restrict__ sz, const float* __restrict__ tx, const float* __restrict__ ty,
-    const float* __restrict__ tz, const unsigned long long* __restrict__ keys, uint32_t key_stride,
+    const float* __restrict__ tz, unsigned long long* __restrict__ keys, uint32_t key_stride,
     int32_t* __restrict__ out_index, float* __restrict__ out_dist2, double* __restrict__ partials,
     uint32_t* __restrict__ error_flag) {
-  __shared__ double scratch[kBlockThreads / 64][MI355_ICP_NSUMS];
+  __shared__ double scratch[kSums ? kBlockThreads / 64 : 1][MI355_ICP_NSUMS];
 
   const JobDesc& J = jobs[blockIdx.y];
-  const uint32_t sb = blockIdx.x;
+  const uint32_t sb = kSums ? blockIdx.x : blockIdx.x / kResolvePointsPerLane;
   if (sb >= J.src_blocks) return;
   const uint32_t tid = threadIdx.x;
   float pose[12];
@@ -345,15 +352,21 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
 #pragma unroll
   for (int k = 0; k < MI355_ICP_NSUMS; ++k) acc[k] = 0.0;
 
+  const int p_first = kSums ? 0 : static_cast<int>(blockIdx.x % kResolvePointsPerLane);
+  const int p_end = kSums ? kResolvePointsPerLane : p_first + 1;
 #pragma unroll 1
-  for (int p = 0; p < kResolvePointsPerLane; ++p) {
+  for (int p = p_first; p < p_end; ++p) {
     const uint32_t local = sb * kSrcPerBlock + p * kBlockThreads + tid;
+    // the scan's padding lanes merge keys as well: the whole span of this workgroup goes back cleared (a job's slots are
+    // padded to kSrcPad, a multiple of this kernel's span and of the scan's)
+    if (!kSums && J.sub_split > 1 && local >= J.src_n) keys[J.out_off + local] = ~0ull;
     if (local < J.src_n) {
       unsigned long long key = ~0ull;
       for (uint32_t sp = 0; sp < n_split; ++sp) {
         const unsigned long long k = keys[sp * key_stride + J.out_off + local];
         key = k < key ? k : key;
       }
+      if (!kSums && J.sub_split > 1) keys[J.out_off + local] = ~0ull;
       const uint32_t best_bits = static_cast<uint32_t>(key >> 32);
       const uint32_t chunk = static_cast<uint32_t>(key);
       const uint32_t i = J.src_off + local;
@@ -398,7 +411,7 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
       const uint32_t o = J.out_off + local;
       out_index[o] = static_cast<int32_t>(chunk * kChunk + static_cast<uint32_t>(found));
       out_dist2[o] = best;
-      if (best <= max_d2) {
+      if (kSums && best <= max_d2) {
         const double a0 = s0x, a1 = s0y, a2 = s0z, b0 = mx, b1 = my, b2 = mz;
         acc[0] += 1.0;
         acc[1] += a0; acc[2] += a1; acc[3] += a2;
@@ -411,8 +424,10 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
     }
   }
 
-  const double r = block_sum<MI355_ICP_NSUMS>(acc, scratch);
-  if (tid < MI355_ICP_NSUMS) partials[static_cast<size_t>(J.partial_off + sb) * MI355_ICP_NSUMS + tid] = r;
+  if (kSums) {
+    const double r = block_sum<MI355_ICP_NSUMS>(acc, scratch);
+    if (tid < MI355_ICP_NSUMS) partials[static_cast<size_t>(J.partial_off + sb) * MI355_ICP_NSUMS + tid] = r;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -613,6 +628,8 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
     // memory round trips: 0.15 ms at any size).  A step with fewer than kStep points left repeats its first one.
     // kStep = 8 for the 128-target granule of the matrix-core filter: 8 x 2 x 4 loads in flight per lane, 8 round trips
     // per wave (6 x 20k points against 100k targets: 48 -> ~30 us; the 64-target granule keeps 4 x 1 x 4).
+    // (Tried in round 2 for the small launches of reference mode, where this kernel lasts ~28 us whatever the point count:
+    // 16 points per step, and 16 or 32 points per wave on more waves - neither moved the request latency.)
     constexpr int kStep = kRun >= 128 ? 8 : 4;
     unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
     while (todo) {
@@ -745,11 +762,14 @@ __global__ __launch_bounds__(kBlockThreads) void overflow_tiles_kernel(
   __shared__ unsigned long long smask[kBlockThreads / 64];
   __shared__ uint32_t sd[kBlockThreads / 64], sj[kBlockThreads / 64];
   const JobDesc& J = jobs[blockIdx.y];
-  if (blockIdx.x >= overflow_count[blockIdx.y]) return;
-  const uint32_t local = overflow_list[J.out_off + blockIdx.x];
+  const uint32_t n_listed = overflow_count[blockIdx.y];
+  if (blockIdx.x >= n_listed) return;
   float pose[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
+  // grid.x workgroups share the job's list (mostly empty: a launch of one workgroup per POSSIBLE entry spent 11 us finding that out)
+  for (uint32_t slot = blockIdx.x; slot < n_listed; slot += gridDim.x) {
+  const uint32_t local = overflow_list[J.out_off + slot];
   const uint32_t i = J.src_off + local;
   float qx, qy, qz;
   transform_point(pose, sx[i], sy[i], sz[i], qx, qy, qz);
@@ -809,6 +829,8 @@ __global__ __launch_bounds__(kBlockThreads) void overflow_tiles_kernel(
     }
     out_index[J.out_off + local] = static_cast<int32_t>(j);
     out_dist2[J.out_off + local] = __uint_as_float(d);
+  }
+  __syncthreads();  // sd / sj are rewritten by the next listed point
   }
 }
 
@@ -1190,13 +1212,21 @@ void launch_nn_scan(void* stream, int points_per_lane, const JobDesc* jobs_dev, 
   }
 }
 
+// partials == nullptr: indices and distances only (reference mode), and merged key rows are handed back cleared
 void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
-                    DevicePlanes tgt, const unsigned long long* keys, uint32_t key_stride, int32_t* out_index,
+                    DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride, int32_t* out_index,
                     float* out_dist2, double* partials, uint32_t* error_flag) {
-  dim3 grid(max_src_blocks, static_cast<uint32_t>(n_jobs));
-  hipLaunchKernelGGL(resolve_accumulate_kernel, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
-                     jobs_dev, src.x, src.y, src.z, tgt.x, tgt.y, tgt.z, keys, key_stride, out_index, out_dist2,
-                     partials, error_flag);
+  if (partials) {
+    dim3 grid(max_src_blocks, static_cast<uint32_t>(n_jobs));
+    hipLaunchKernelGGL(resolve_accumulate_kernel<true>, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
+                       jobs_dev, src.x, src.y, src.z, tgt.x, tgt.y, tgt.z, keys, key_stride, out_index, out_dist2,
+                       partials, error_flag);
+  } else {
+    dim3 grid(max_src_blocks * kResolvePointsPerLane, static_cast<uint32_t>(n_jobs));
+    hipLaunchKernelGGL(resolve_accumulate_kernel<false>, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
+                       jobs_dev, src.x, src.y, src.z, tgt.x, tgt.y, tgt.z, keys, key_stride, out_index, out_dist2,
+                       partials, error_flag);
+  }
 }
 
 #ifdef MI355_ICP_DIAG
@@ -1253,7 +1283,9 @@ void launch_overflow_exact(void* stream, const JobDesc* jobs_dev, int n_jobs, ui
 void launch_overflow_tiles(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t cap, DevicePlanes src, DevicePlanes sorted_tgt,
                            const uint32_t* tgt_perm, const void* tgt_table, const uint32_t* overflow_list, const uint32_t* overflow_count,
                            int32_t* out_index, float* out_dist2, uint32_t* error_flag) {
-  hipLaunchKernelGGL(overflow_tiles_kernel, dim3(cap, static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
+  // `cap` listed points per job are settled on the device (more: the host path); the job's workgroups stride over its list
+  const uint32_t per_job = std::min<uint32_t>(cap, std::max<uint32_t>(16u, std::min<uint32_t>(256u, 2048u / static_cast<uint32_t>(std::max(n_jobs, 1)))));
+  hipLaunchKernelGGL(overflow_tiles_kernel, dim3(per_job, static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
                      jobs_dev, src.x, src.y, src.z, sorted_tgt.x, sorted_tgt.y, sorted_tgt.z, tgt_perm, static_cast<const float4*>(tgt_table),
                      overflow_list, overflow_count, out_index, out_dist2, error_flag);
 }

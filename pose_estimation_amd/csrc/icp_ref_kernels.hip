@@ -129,13 +129,20 @@ __device__ uint32_t radix_select(uint32_t n, uint32_t k, uint32_t* hist /* 2048 
 // grid = n_jobs, block = kSelThreads.  thr[job] = scale * (1.48257968f * median|d2 - med|) + med, float32 ops as the oracle.
 // The six radix passes re-read the job's distances; the first `cache_n` of them are kept in LDS (dynamic, up to 128 KiB of
 // the CU's 160) so that global memory is walked once instead of six times (20k points: 31 -> ~15 us).
+// With `owner` given the workgroup goes on to offer the job's accepted pairs to the picky owner table (what
+// picky_scatter_kernel does in a launch of its own): the distances are still in LDS, and a pass of the coarse pyramid
+// levels is a chain of dependent launches whose number is what it costs.
 __global__ __launch_bounds__(kSelThreads) void rejection_select_kernel(const JobDesc* __restrict__ jobs,
                                                                         const float* __restrict__ dist2, float scale,
-                                                                        float* __restrict__ thr_out, uint32_t cache_n) {
+                                                                        float* __restrict__ thr_out, uint32_t cache_n,
+                                                                        const RefJobDesc* __restrict__ rjobs,
+                                                                        const int32_t* __restrict__ index,
+                                                                        unsigned long long* __restrict__ owner) {
   extern __shared__ float cache[];
   __shared__ uint32_t hist[2048];
   __shared__ uint32_t bcast[2];
   __shared__ uint32_t wave_tot[kSelThreads / 64];
+  __shared__ float thr_shared;
   const JobDesc& J = jobs[blockIdx.x];
   const uint32_t n = J.src_n;
   if (n == 0) {
@@ -156,6 +163,16 @@ __global__ __launch_bounds__(kSelThreads) void rejection_select_kernel(const Job
     const float s = 1.48257968f * mad;
     const float t = scale * s;
     thr_out[blockIdx.x] = t + med;
+    thr_shared = t + med;
+  }
+  if (!owner) return;
+  __syncthreads();
+  const float t = thr_shared;
+  const RefJobDesc& RJ = rjobs[blockIdx.x];
+  const int32_t* __restrict__ idx = index + J.out_off;
+  for (uint32_t i = threadIdx.x; i < n; i += kSelThreads) {
+    const float v = i < cached ? cache[i] : d[i];
+    if (v < t) atomicMin(&owner[RJ.owner_off + static_cast<uint32_t>(idx[i])], picky_key(RJ.owner_prefix, v, RJ.src_index_base + i));
   }
 }
 
@@ -287,15 +304,33 @@ __global__ __launch_bounds__(kBlockThreads) void picky_scatter_kernel(const JobD
 }
 
 // ---------------------------------------------------------------------------------------------
+// Rows of the pass result: [n x 29 sums][n overflow-excess flags][n thresholds][n overflow counts], n = jobs of the pass
+// (+ one more value behind them when ref_accumulate_kernel ends the pass: the call's error word).
+__device__ __forceinline__ void write_pass_tail(double* sums, uint32_t n_jobs, uint32_t job, const float* thr,
+                                                uint32_t* overflow_count, uint32_t overflow_cap) {
+  double* tail = sums + static_cast<size_t>(n_jobs) * kRefSums;
+  const uint32_t n = overflow_count ? overflow_count[job] : 0u;
+  tail[job] = n > overflow_cap ? 1.0 : 0.0;
+  tail[n_jobs + job] = static_cast<double>(thr[job]);  // float -> double is exact
+  tail[2 * n_jobs + job] = static_cast<double>(n);
+  if (overflow_count) overflow_count[job] = 0u;
+}
+
 // grid = (max src_blocks, n_jobs).  src/tgt are the LEVEL planes; normals are the level-0 normal planes.
+// With tail.done set the launch also ENDS the pass (single-GPU reference mode): the last workgroup of a job to finish adds
+// the job's partial rows up - in row order, so the sums are those of ref_final_reduce_kernel bit for bit - and writes them
+// with the tail straight into the host's (pinned, mapped) result block; the last job to finish publishes tail.seq in
+// *tail.ready behind a system-scope release, which is what the host polls.  One launch and no copy instead of two
+// launches and a device-to-host copy, on a chain of dependent launches that is most of a coarse level's pass.
 __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
     const JobDesc* __restrict__ jobs, const RefJobDesc* __restrict__ rjobs, const float* __restrict__ sx,
     const float* __restrict__ sy, const float* __restrict__ sz, const float* __restrict__ tx,
     const float* __restrict__ ty, const float* __restrict__ tz, const float* __restrict__ nx,
     const float* __restrict__ ny, const float* __restrict__ nz, const int32_t* __restrict__ index,
     const float* __restrict__ dist2, const float* __restrict__ thr, const unsigned long long* __restrict__ owner,
-    uint8_t* __restrict__ selected, double* __restrict__ partials) {
+    uint8_t* __restrict__ selected, double* partials, PassTail tail) {
   __shared__ double scratch[kBlockThreads / 64][kRefSums];
+  __shared__ uint32_t last_flag;
   const JobDesc& J = jobs[blockIdx.y];
   const uint32_t sb = blockIdx.x;
   if (sb >= J.src_blocks) return;
@@ -339,7 +374,52 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
     }
   }
   const double r = block_sum<kRefSums>(acc, scratch);
-  if (threadIdx.x < kRefSums) partials[static_cast<size_t>(J.partial_off + sb) * kRefSums + threadIdx.x] = r;
+  double* my_row = partials + static_cast<size_t>(J.partial_off + sb) * kRefSums;
+  if (!tail.done) {
+    if (threadIdx.x < kRefSums) my_row[threadIdx.x] = r;
+    return;
+  }
+  // The classic last-block reduction, without its device-wide fences (a __threadfence() is a write-back of the whole L2 on
+  // this chip, per workgroup: +15 us on a 14 us launch).  Everything one workgroup hands to another goes through
+  // agent-scope atomic accesses instead - they are performed at memory, past the per-XCD L2s - and a writer waits for its
+  // own stores to be acknowledged (s_waitcnt) before it raises the count the reader takes its cue from.
+  if (threadIdx.x < kRefSums) __hip_atomic_store(my_row + threadIdx.x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the row is at memory
+  __syncthreads();
+  if (threadIdx.x == 0)
+    last_flag = __hip_atomic_fetch_add(&tail.done[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == J.src_blocks ? 1u : 0u;
+  __syncthreads();
+  if (!last_flag) return;
+#pragma unroll
+  for (int k = 0; k < kRefSums; ++k) acc[k] = 0.0;
+  for (uint32_t b = threadIdx.x; b < J.src_blocks; b += kBlockThreads) {  // row order: ref_final_reduce_kernel's sums, bit for bit
+    double* row = partials + static_cast<size_t>(J.partial_off + b) * kRefSums;
+#pragma unroll
+    for (int k = 0; k < kRefSums; ++k) acc[k] += __hip_atomic_load(row + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();  // scratch is reused
+  const double total = block_sum<kRefSums>(acc, scratch);
+  if (threadIdx.x < kRefSums)
+    __hip_atomic_store(tail.sums + static_cast<size_t>(blockIdx.y) * kRefSums + threadIdx.x, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) {
+    double* t = tail.sums + static_cast<size_t>(gridDim.y) * kRefSums;
+    const uint32_t n = tail.overflow_count ? __hip_atomic_load(&tail.overflow_count[blockIdx.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    __hip_atomic_store(t + blockIdx.y, n > tail.overflow_cap ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(t + gridDim.y + blockIdx.y, static_cast<double>(thr[blockIdx.y]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(t + 2 * gridDim.y + blockIdx.y, static_cast<double>(n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tail.overflow_count) tail.overflow_count[blockIdx.y] = 0u;
+    __hip_atomic_store(&tail.done[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next pass
+  }
+  __builtin_amdgcn_s_waitcnt(0);  // this job's rows have reached the host's memory
+  __syncthreads();
+  if (threadIdx.x == 0 &&
+      __hip_atomic_fetch_add(&tail.done[gridDim.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.y) {
+    __hip_atomic_store(&tail.done[gridDim.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t raised = __hip_atomic_load(tail.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(tail.sums + static_cast<size_t>(gridDim.y) * (kRefSums + 3), static_cast<double>(raised), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_s_waitcnt(0);
+    __hip_atomic_store(tail.ready, tail.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // every job's rows were acknowledged before its count
+  }
 }
 
 // Tail of `sums` behind the n = gridDim.x rows: [n flags][n thresholds][n counts] - see final_reduce_kernel; the rejection
@@ -360,14 +440,7 @@ __global__ __launch_bounds__(kBlockThreads) void ref_final_reduce_kernel(const J
   }
   const double r = block_sum<kRefSums>(acc, scratch);
   if (threadIdx.x < kRefSums) sums[static_cast<size_t>(blockIdx.x) * kRefSums + threadIdx.x] = r;
-  if (threadIdx.x == 0) {
-    double* tail = sums + static_cast<size_t>(gridDim.x) * kRefSums;
-    const uint32_t n = overflow_count ? overflow_count[blockIdx.x] : 0u;
-    tail[blockIdx.x] = n > overflow_cap ? 1.0 : 0.0;
-    tail[gridDim.x + blockIdx.x] = static_cast<double>(thr[blockIdx.x]);  // float -> double is exact
-    tail[2 * gridDim.x + blockIdx.x] = static_cast<double>(n);
-    if (overflow_count) overflow_count[blockIdx.x] = 0u;
-  }
+  if (threadIdx.x == 0) write_pass_tail(sums, gridDim.x, blockIdx.x, thr, overflow_count, overflow_cap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -381,21 +454,27 @@ void launch_subsample(void* stream, const float* in, size_t in_stride, uint32_t 
 
 // max_n: largest job of the launch.  hists / states: scratch zeroed once at allocation (the pick kernel leaves the
 // histograms clear); small launches keep the one-workgroup kernel (a dozen launches cost more).
-void launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_n, const float* dist2, float scale,
-                             float* thr, uint32_t* hists, uint32_t* states) {
+// Returns true when the launch also offered the accepted pairs to `owner` (the one-workgroup kernel does when asked to:
+// rjobs_dev, index and owner given); false = the caller still has to launch picky_scatter_kernel.
+bool launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_n, const float* dist2, float scale,
+                             float* thr, uint32_t* hists, uint32_t* states, const RefJobDesc* rjobs_dev, const int32_t* index,
+                             unsigned long long* owner) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (max_n < 65536u || !hists) {
     static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(rejection_select_kernel),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
     const uint32_t cache_n = std::min<uint32_t>(max_n, big_lds ? 32768u : 12288u);
+    // one workgroup offering 20k pairs takes longer than the launch it saves (26 + 7 -> 58 us); a few thousand do not
+    const bool scatter = rjobs_dev && index && owner && max_n <= 4096u;
     hipLaunchKernelGGL(rejection_select_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kSelThreads), cache_n * sizeof(float), st, jobs_dev,
-                       dist2, scale, thr, cache_n);
-    return;
+                       dist2, scale, thr, cache_n, rjobs_dev, index, scatter ? owner : nullptr);
+    return scatter;
   }
   for (int pass = 0; pass < 6; ++pass) {
     launch_select_hist(stream, jobs_dev, n_jobs, max_n, dist2, hists, states, pass);
     launch_select_pick(stream, jobs_dev, n_jobs, hists, states, pass, scale, thr);
   }
+  return false;
 }
 
 // the two halves of one radix pass of the many-workgroup selection, separately: a slab-sharded pass adds the histograms
@@ -422,10 +501,10 @@ void launch_picky_scatter(void* stream, const JobDesc* jobs_dev, const RefJobDes
 void launch_ref_accumulate(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
                            uint32_t max_src_blocks, DevicePlanes src, DevicePlanes tgt, DevicePlanes normals,
                            const int32_t* index, const float* dist2, const float* thr, const unsigned long long* owner,
-                           uint8_t* selected, double* partials) {
+                           uint8_t* selected, double* partials, const PassTail& tail) {
   hipLaunchKernelGGL(ref_accumulate_kernel, dim3(max_src_blocks, static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0,
                      static_cast<hipStream_t>(stream), jobs_dev, rjobs_dev, src.x, src.y, src.z, tgt.x, tgt.y, tgt.z,
-                     normals.x, normals.y, normals.z, index, dist2, thr, owner, selected, partials);
+                     normals.x, normals.y, normals.z, index, dist2, thr, owner, selected, partials, tail);
 }
 
 void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums, const float* thr,
