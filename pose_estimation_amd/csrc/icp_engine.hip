@@ -15,7 +15,9 @@
 #include <chrono>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "icp_internal.h"
@@ -32,6 +34,54 @@ struct CloudEntry {
   uint32_t padded;  // slots occupied
 };
 
+// Device buffers of the cloud copies (planes, pyramid levels, sorted copies) come from a size-classed cache.  A service
+// commits a new scene per request, a few per cent larger or smaller than the last one, and every hipMalloc / hipFree pair
+// costs ~0.1 ms plus a device-wide synchronisation - a request at the reference's shape went through ~40 of them.
+// Everything that touches these buffers is ordered on the engine's one stream, so a buffer given back while launches that
+// use it are still queued may be handed out again at once: the next user is queued behind them.
+struct BufferPool {
+  std::multimap<size_t, void*> idle;            // size class -> buffer
+  std::unordered_map<void*, size_t> class_of;   // every buffer the pool ever handed out and still owns
+  size_t idle_bytes = 0;
+  static size_t size_class(size_t bytes) {      // steps of 64 KiB up to 1 MiB, of one eighth of the power of two above
+    if (bytes <= (1u << 20)) return (std::max<size_t>(bytes, 1) + 0xFFFFu) & ~static_cast<size_t>(0xFFFFu);
+    size_t p = 1;
+    while ((p << 1) <= bytes) p <<= 1;
+    const size_t step = p >> 3;
+    return (bytes + step - 1) / step * step;
+  }
+  hipError_t take(void** out, size_t bytes) {
+    const size_t cls = size_class(bytes);
+    auto it = idle.find(cls);
+    if (it != idle.end()) {
+      *out = it->second;
+      idle.erase(it);
+      idle_bytes -= cls;
+      return hipSuccess;
+    }
+    const hipError_t e = hipMalloc(out, cls);
+    if (e == hipSuccess) class_of[*out] = cls;
+    return e;
+  }
+  void give(void* ptr) {
+    if (!ptr) return;
+    auto it = class_of.find(ptr);
+    if (it == class_of.end()) { (void)hipFree(ptr); return; }  // not ours (never happens)
+    if (idle_bytes + it->second > (static_cast<size_t>(8) << 30)) {  // keep at most 8 GiB idle
+      (void)hipDeviceSynchronize();
+      (void)hipFree(ptr);
+      class_of.erase(it);
+      return;
+    }
+    idle.emplace(it->second, ptr);
+    idle_bytes += it->second;
+  }
+  void release_all() {  // the caller has drained the device; buffers still held by their users are freed through give() later
+    for (auto& kv : idle) { (void)hipFree(kv.second); class_of.erase(kv.second); }
+    idle.clear();
+    idle_bytes = 0;
+  }
+};
 // Expansion-filter copy of a group of target clouds (built on demand, xtarget_kernels.hip): Morton-sorted, centred per
 // 1024-point tile.  planes: tcx | tcy | tcz | tt | sox | soy | soz, each `stride` floats; perm: sorted position ->
 // original index; table: per tile (centre x, y, z, r^2); bf: bf16 operand image of the matrix-core filter
@@ -89,14 +139,15 @@ struct Plan {
   uint32_t key_ranks() const { return xfilter && xkind != 3 ? 4u : 3u; }       // the VALU expansion kernels also publish U
 };
 
-void free_xcopy(XCopy& x) {  // the caller has drained the stream
-  (void)hipFree(x.planes);
-  (void)hipFree(x.perm);
-  (void)hipFree(x.table);
-  (void)hipFree(x.bf);
-  (void)hipFree(x.bf_table);
-  (void)hipFree(x.sub);
-  (void)hipFree(x.super);
+void free_xcopy(BufferPool& pool_ref, XCopy& x) {  // back to the pool (stream-ordered: no drain needed)
+  BufferPool* pool = &pool_ref;
+  pool->give(x.planes);
+  pool->give(x.perm);
+  pool->give(x.table);
+  pool->give(x.bf);
+  pool->give(x.bf_table);
+  pool->give(x.sub);
+  pool->give(x.super);
   x = XCopy{};
 }
 
@@ -115,6 +166,7 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
 using namespace mi355;
 
 struct mi355_icp_ctx {
+  BufferPool pool;
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
@@ -183,6 +235,7 @@ struct mi355_icp_ctx {
   int scan_ppl = 0;                  // scan points-per-lane override (2, 4, 8); 0 = planner decides per call
   bool scan_sgpr = false;            // experimental scalar-load scan (MI355_ICP_SCAN_MODE=sgpr)
   uint32_t* xt_scratch = nullptr; size_t xt_scratch_cap = 0;  // Morton codes / indices while building the sorted target copy
+  uint32_t* xt_meta_host = nullptr; size_t xt_meta_cap = 0; hipEvent_t xt_meta_event = nullptr; bool xt_meta_pending = false;  // pinned (offset, count) table of ensure_xcopy
   uint32_t* xt_box = nullptr;     size_t xt_box_cap = 0;  // per cloud: bounding box as order-preserving keys
   unsigned char* xt_temp = nullptr; size_t xt_temp_cap = 0;   // rocPRIM sort scratch
   uint32_t mfma_share_pct = 65;      // hybrid: per cent of the scan workgroups that run on the matrix cores
@@ -252,6 +305,21 @@ int wait_pass(mi355_icp_ctx* c, uint32_t seq) {
   return MI355_ICP_OK;
 }
 
+// Hands every device buffer of a cloud set (planes, normals, pyramid levels, sorted copies) back to the pool.
+void release_cloud_buffers(mi355_icp_ctx* c, CloudSet& set) {
+  c->pool.give(set.planes);
+  c->pool.give(set.normals);
+  set.planes = set.normals = nullptr;
+  for (auto& lv : set.levels) {
+    c->pool.give(lv.planes);
+    free_xcopy(c->pool, lv.xt);
+  }
+  set.levels.clear();
+  set.shard_begin.clear();
+  set.shard_total.clear();
+  free_xcopy(c->pool, set.xt);
+}
+
 int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* const* xyz, const size_t* n_points,
                   size_t stride_bytes, uint32_t pad_multiple, float pad_value, bool allow_empty, const char* what) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
@@ -283,12 +351,12 @@ int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* co
   if ((st = grow(c, c->upload_raw, c->upload_raw_cap, raw_floats)) != MI355_ICP_OK) return st;
   if ((st = grow(c, c->upload_flags, c->upload_flags_cap, static_cast<size_t>(n_clouds))) != MI355_ICP_OK) return st;
   float *planes = nullptr, *normals = nullptr;
-  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&planes), 3 * stride * sizeof(float)));
-  if (with_normals && hipMalloc(reinterpret_cast<void**>(&normals), 3 * stride * sizeof(float)) != hipSuccess) {
-    (void)hipFree(planes);
+  HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&planes), 3 * stride * sizeof(float)));
+  if (with_normals && c->pool.take(reinterpret_cast<void**>(&normals), 3 * stride * sizeof(float)) != hipSuccess) {
+    c->pool.give(planes);
     return fail(c, MI355_ICP_ERR_HIP, "hipMalloc (normal planes) failed");
   }
-  auto drop_new = [&]() { (void)hipFree(planes); (void)hipFree(normals); };
+  auto drop_new = [&]() { c->pool.give(planes); c->pool.give(normals); };
   bool ok = hipMemsetAsync(c->upload_flags, 0, static_cast<size_t>(n_clouds) * sizeof(uint32_t), c->stream) == hipSuccess;
   if (total == 0) {  // only empty clouds: planes of padding
     ok = ok && hipMemsetAsync(planes, 0, 3 * stride * sizeof(float), c->stream) == hipSuccess;
@@ -314,16 +382,7 @@ int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* co
       return fail(c, MI355_ICP_ERR_NONFINITE_INPUT,
                   std::string(what) + ": cloud " + std::to_string(k) + " holds NaN/Inf (strip them first, as the reference does at pose_estimation.cpp:248)");
     }
-  if (set.planes) { HIP_TRY(c, hipFree(set.planes)); set.planes = nullptr; }
-  if (set.normals) { HIP_TRY(c, hipFree(set.normals)); set.normals = nullptr; }
-  for (auto& lv : set.levels) {
-    if (lv.planes) HIP_TRY(c, hipFree(lv.planes));
-    free_xcopy(lv.xt);
-  }
-  set.levels.clear();
-  set.shard_begin.clear();
-  set.shard_total.clear();
-  free_xcopy(set.xt);
+  release_cloud_buffers(c, set);
   set.planes = planes;
   set.normals = normals;
   set.stride = stride;
@@ -611,7 +670,16 @@ int ensure_xcopy(mi355_icp_ctx* c, DevicePlanes view, size_t stride, const std::
   if (x.valid) return MI355_ICP_OK;
   const int n_clouds = static_cast<int>(clouds.size());
   uint32_t max_n = 1;
-  std::vector<uint32_t> meta(2 * static_cast<size_t>(n_clouds));
+  // the (offset, count) table goes up from a pinned buffer of the engine's, without a synchronisation of its own: the buffer
+  // is rewritten only after the previous build's copy has left it (an event, long since signalled in practice)
+  if (c->xt_meta_pending) { HIP_TRY(c, hipEventSynchronize(c->xt_meta_event)); c->xt_meta_pending = false; }
+  if (2 * static_cast<size_t>(n_clouds) > c->xt_meta_cap) {
+    if (c->xt_meta_host) { HIP_TRY(c, hipHostFree(c->xt_meta_host)); c->xt_meta_host = nullptr; c->xt_meta_cap = 0; }
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->xt_meta_host), 4 * static_cast<size_t>(n_clouds) * sizeof(uint32_t), hipHostMallocDefault));
+    c->xt_meta_cap = 4 * static_cast<size_t>(n_clouds);
+  }
+  if (!c->xt_meta_event) HIP_TRY(c, hipEventCreateWithFlags(&c->xt_meta_event, hipEventDisableTiming));
+  uint32_t* meta = c->xt_meta_host;
   for (int k = 0; k < n_clouds; ++k) {
     meta[k] = clouds[k].off;
     meta[n_clouds + k] = clouds[k].n;
@@ -623,20 +691,21 @@ int ensure_xcopy(mi355_icp_ctx* c, DevicePlanes view, size_t stride, const std::
   if ((st = grow(c, c->xt_scratch, c->xt_scratch_cap, 4 * static_cast<size_t>(max_n) + 2 * static_cast<size_t>(n_clouds))) != MI355_ICP_OK) return st;
   if ((st = grow(c, c->xt_box, c->xt_box_cap, 6 * static_cast<size_t>(n_clouds))) != MI355_ICP_OK) return st;
   if ((st = grow(c, c->xt_temp, c->xt_temp_cap, temp_bytes + 16)) != MI355_ICP_OK) return st;
-  if (!x.planes) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.planes), 7 * stride * sizeof(float)));
-  if (!x.perm) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.perm), stride * sizeof(uint32_t)));
-  if (!x.table) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.table), 4 * (stride / kTile) * sizeof(float)));
-  if (!x.bf) HIP_TRY(c, hipMalloc(&x.bf, (stride / kTile) * static_cast<size_t>(kXbTileVecs) * 16));
-  if (!x.bf_table) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.bf_table), 4 * (stride / kTile) * sizeof(float)));
-  if (!x.sub) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.sub), (stride / 64) * 4 * sizeof(float)));
-  if (!x.super) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&x.super), (stride / kTile / kSuperTiles + 1) * 4 * sizeof(float)));
+  if (!x.planes) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.planes), 7 * stride * sizeof(float)));
+  if (!x.perm) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.perm), stride * sizeof(uint32_t)));
+  if (!x.table) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.table), 4 * (stride / kTile) * sizeof(float)));
+  if (!x.bf) HIP_TRY(c, c->pool.take(&x.bf, (stride / kTile) * static_cast<size_t>(kXbTileVecs) * 16));
+  if (!x.bf_table) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.bf_table), 4 * (stride / kTile) * sizeof(float)));
+  if (!x.sub) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.sub), (stride / 64) * 4 * sizeof(float)));
+  if (!x.super) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.super), (stride / kTile / kSuperTiles + 1) * 4 * sizeof(float)));
   uint32_t* code = c->xt_scratch;
   uint32_t* index = code + max_n;
   uint32_t* code2 = index + max_n;
   uint32_t* order = code2 + max_n;
   uint32_t* meta_dev = order + max_n;
-  HIP_TRY(c, hipMemcpyAsync(meta_dev, meta.data(), meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));  // `meta` is a pageable temporary
+  HIP_TRY(c, hipMemcpyAsync(meta_dev, meta, 2 * static_cast<size_t>(n_clouds) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipEventRecord(c->xt_meta_event, c->stream));
+  c->xt_meta_pending = true;
   launch_xt_fill(c->stream, x.planes, stride, x.perm, x.bf);
   HIP_TRY(c, hipMemsetAsync(x.table, 0, 4 * (stride / kTile) * sizeof(float), c->stream));
   HIP_TRY(c, hipMemsetAsync(x.bf_table, 0, 4 * (stride / kTile) * sizeof(float), c->stream));
@@ -916,10 +985,9 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
   const std::vector<uint64_t>& want_begin = shard_begin ? *shard_begin : none;
   const std::vector<uint64_t>& want_total = shard_total ? *shard_total : none;
   if (want_begin != set.shard_begin || want_total != set.shard_total) {  // levels built for another slab geometry: drop them
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (auto& lv : set.levels) {
-      if (lv.planes) HIP_TRY(c, hipFree(lv.planes));
-      free_xcopy(lv.xt);
+      c->pool.give(lv.planes);
+      free_xcopy(c->pool, lv.xt);
     }
     set.levels.clear();
     set.shard_begin = want_begin;
@@ -943,7 +1011,7 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
       total += padded;
     }
     lv.stride = static_cast<size_t>(std::max<uint64_t>(total, pad_multiple));
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&lv.planes), 3 * lv.stride * sizeof(float)));
+    HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&lv.planes), 3 * lv.stride * sizeof(float)));
     hipError_t e = hipSuccess;
     if (total == 0) e = hipMemsetAsync(lv.planes, 0, 3 * lv.stride * sizeof(float), c->stream);
     for (size_t k = 0; k < set.clouds.size() && e == hipSuccess; ++k)
@@ -951,8 +1019,7 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
                        lv.clouds[k].n, lv.clouds[k].padded, step, pad_value);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) {  // the level is not adopted: give its planes back
-      (void)hipStreamSynchronize(c->stream);
-      (void)hipFree(lv.planes);
+      c->pool.give(lv.planes);
       return fail(c, MI355_ICP_ERR_HIP, std::string("building pyramid level: ") + hipGetErrorString(e));
     }
     set.levels.push_back(lv);
@@ -1254,21 +1321,16 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
-  for (CloudSet* set : {&c->targets, &c->sources}) {
-    (void)hipFree(set->planes);
-    (void)hipFree(set->normals);
-    for (auto& lv : set->levels) {
-      (void)hipFree(lv.planes);
-      free_xcopy(lv.xt);
-    }
-    free_xcopy(set->xt);
-  }
+  for (CloudSet* set : {&c->targets, &c->sources}) release_cloud_buffers(c, *set);
   (void)hipFree(c->scene[0]);
   (void)hipFree(c->scene[1]);
   (void)hipFree(c->scene_planes);
   (void)hipFree(c->upload_raw);
   (void)hipFree(c->upload_flags);
-  free_xcopy(c->scene_xt);
+  free_xcopy(c->pool, c->scene_xt);
+  c->pool.release_all();  // the stream was drained above
+  if (c->xt_meta_host) (void)hipHostFree(c->xt_meta_host);
+  if (c->xt_meta_event) (void)hipEventDestroy(c->xt_meta_event);
   (void)hipFree(c->scene_normal_planes);
   (void)hipFree(c->scene_normals_aos);
   (void)hipFree(c->knn_d);
@@ -1843,9 +1905,8 @@ int mi355_icp_scene_normals(mi355_icp_ctx* c, int k, int flip_viewpoint, const f
   } else {
     // Morton-sorted copy of the scene with per-tile bounding spheres (the same builder the ICP targets use), then the
     // pruned exact scan on it (normals_kernels.hip)
-    if (c->scene_xt_stride != padded) {
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
-      free_xcopy(c->scene_xt);
+    if (c->scene_xt_stride != padded) {  // another size: buffers of the right class come from the pool
+      free_xcopy(c->pool, c->scene_xt);
       c->scene_xt_stride = padded;
     }
     c->scene_xt.valid = false;
@@ -1940,36 +2001,48 @@ int mi355_icp_scene_commit_target(mi355_icp_ctx* c) {
   c->err.clear();
   if (!c->scene_loaded || c->scene_n == 0) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_commit_target: the scene is empty");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
   CloudSet& set = c->targets;
   const uint32_t n = c->scene_n;
   const uint32_t padded = (n + kTile - 1) / kTile * kTile;
+  const size_t plane_bytes = 3 * static_cast<size_t>(padded) * sizeof(float);
+  // scene_normals left, for exactly this scene: its padded SoA planes (checked finite), the normal planes and - pruned
+  // k-NN - the Morton-sorted copy with the tile tables and the operand image of the matrix-core scan
+  const bool fresh = c->scene_normals_valid && c->scene_normals_padded == padded;
   float* planes = nullptr;
-  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&planes), 3 * static_cast<size_t>(padded) * sizeof(float)));
-  HIP_TRY(c, hipMemsetAsync(c->scene_counters, 0, 4 * sizeof(uint32_t), c->stream));
-  launch_scene_to_planes(c->stream, c->scene[c->scene_cur], n, planes, padded, 0, padded, kTargetPad, c->scene_counters);
-  HIP_TRY(c, hipMemcpyAsync(c->scene_counters_host, c->scene_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->scene_counters_host[2] & 2u) {
-    (void)hipFree(planes);
-    return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "scene_commit_target: the scene still holds NaN/Inf (apply MI355_SCENE_FILTER_FINITE)");
+  HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&planes), plane_bytes));
+  if (fresh) {
+    if (hipMemcpyAsync(planes, c->scene_planes, plane_bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) {
+      c->pool.give(planes);
+      return fail(c, MI355_ICP_ERR_HIP, "scene_commit_target: copying the scene planes failed");
+    }
+  } else {
+    bool ok = hipMemsetAsync(c->scene_counters, 0, 4 * sizeof(uint32_t), c->stream) == hipSuccess;
+    launch_scene_to_planes(c->stream, c->scene[c->scene_cur], n, planes, padded, 0, padded, kTargetPad, c->scene_counters);
+    ok = ok && hipMemcpyAsync(c->scene_counters_host, c->scene_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+         hipStreamSynchronize(c->stream) == hipSuccess;
+    if (!ok) {
+      c->pool.give(planes);
+      return fail(c, MI355_ICP_ERR_HIP, "scene_commit_target: laying the scene out failed");
+    }
+    if (c->scene_counters_host[2] & 2u) {
+      c->pool.give(planes);
+      return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "scene_commit_target: the scene still holds NaN/Inf (apply MI355_SCENE_FILTER_FINITE)");
+    }
   }
-  if (set.planes) HIP_TRY(c, hipFree(set.planes));
-  if (set.normals) { HIP_TRY(c, hipFree(set.normals)); set.normals = nullptr; }
-  for (auto& lv : set.levels) {
-    if (lv.planes) HIP_TRY(c, hipFree(lv.planes));
-    free_xcopy(lv.xt);
-  }
-  set.levels.clear();
-  set.shard_begin.clear();
-  set.shard_total.clear();
-  free_xcopy(set.xt);
+  release_cloud_buffers(c, set);
   set.planes = planes;
   set.stride = padded;
   set.clouds.assign(1, CloudEntry{0, n, padded});
-  if (c->scene_normals_valid && c->scene_normals_padded == padded) {  // normals of exactly this scene: copy them over
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&set.normals), 3 * static_cast<size_t>(padded) * sizeof(float)));
-    HIP_TRY(c, hipMemcpy(set.normals, c->scene_normal_planes, 3 * static_cast<size_t>(padded) * sizeof(float), hipMemcpyDeviceToDevice));
+  if (fresh) {  // normals of exactly this scene: they go along
+    HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&set.normals), plane_bytes));
+    HIP_TRY(c, hipMemcpyAsync(set.normals, c->scene_normal_planes, plane_bytes, hipMemcpyDeviceToDevice, c->stream));
+    // ... and so does the sorted copy (the builder, its input and its layout are the target's own: ensure_xcopy) - the
+    // scene is not sorted a second time.  A second commit of the same scene builds its own.
+    if (c->scene_xt.valid && c->scene_xt_stride == padded) {
+      set.xt = c->scene_xt;
+      c->scene_xt = XCopy{};
+      c->scene_xt_stride = 0;
+    }
   }
   return MI355_ICP_OK;
 }
