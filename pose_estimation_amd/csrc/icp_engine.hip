@@ -1884,7 +1884,7 @@ int mi355_icp_scene_normals(mi355_icp_ctx* c, int k, int flip_viewpoint, const f
   if (split >= 8) split -= split % 8;
   else if (split >= 4) split = 4;
   else if (split >= 2) split = 2;
-  const bool knn_brute = c->knn_brute || n_tiles > kPrunedMaxTiles;  // the pruned scan's tile bitmap lives in LDS
+  const bool knn_brute = c->knn_brute;  // MI355_ICP_KNN_MODE=brute; the pruned scan (knn_wave_kernel) has no size limit of its own
   if (!knn_brute) split = 1;  // the pruned scan keeps one list per point
   const uint32_t q_stride = qblocks * kBlockThreads;
   const size_t list_len = static_cast<size_t>(split) * kk * q_stride;

@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t bf16_bits(float x) {
 }
 __device__ __forceinline__ float bf16_value(uint32_t bits) { return __uint_as_float(bits << 16); }
 
-// ---- sphere bounds of the pruned scans (nn_pruned_kernel, knn_pruned_kernel) ----
+// ---- sphere bounds of the pruned scans (nn_pruned_kernel, knn_wave_kernel) ----
 // Lower bound of the contract squared distance from any point of the sphere (o, orad) to any point of the sphere c =
 // (centre, r^2), with every
 // rounding pushed DOWN: relative margins of 2^-18 against float32 errors of a few 2^-24 (v_sqrt_f32 directly: its 1 ulp

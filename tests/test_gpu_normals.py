@@ -136,3 +136,15 @@ def test_pruned_knn_on_geometry_that_stresses_the_tile_bounds(engine):
     _, nb = engine.scene_normals(20, False, (0, 0, 0), want_neighbors=True)
     idx, _ = ora.knn_self(big, 20, use_kdtree=True, nthreads=ora.max_threads())
     assert np.array_equal(nb, idx)
+
+
+def test_pruned_knn_when_every_sphere_is_reachable(engine):
+    """135k copies of one point: every run, tile and super-tile ties with every query, so the k-NN kernel's LDS queues
+    (192 runs, 128 tiles per wave) overflow and are drained many times per query.  The answer is known without an oracle:
+    all distances are 0 and the (d2, index) order picks the k lowest indices for every query."""
+    n = 135_000
+    xyz = np.tile(np.float32([1.5, -2.0, 0.25]), (n, 1))
+    engine.scene_load(xyz)
+    _, nb = engine.scene_normals(20, False, (0, 0, 0), want_neighbors=True)
+    assert nb.shape == (n, 20)
+    assert np.array_equal(nb, np.broadcast_to(np.arange(20, dtype=nb.dtype), (n, 20)))
