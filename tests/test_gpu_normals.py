@@ -148,3 +148,26 @@ def test_pruned_knn_when_every_sphere_is_reachable(engine):
     _, nb = engine.scene_normals(20, False, (0, 0, 0), want_neighbors=True)
     assert nb.shape == (n, 20)
     assert np.array_equal(nb, np.broadcast_to(np.arange(20, dtype=nb.dtype), (n, 20)))
+
+
+def test_a_service_of_requests_with_scenes_of_changing_size(engine):
+    """Five requests in a row through one engine, the scene a little larger or smaller every time (what a camera delivers):
+    device buffers come back from the engine's pool, the committed target takes over the sorted copy the k-NN built, and
+    every request must still give the oracle's normals (bit for bit) and the oracle's reference-mode result.  The last scene
+    is committed twice: the second commit has no sorted copy to inherit and builds its own."""
+    T = st.perturbation(-1)
+    model = st.synth_cloud_np(st.SOURCE_SEED, 3000, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T)
+    engine.set_sources([model])
+    sizes = (9000, 9500, 8100, 20000, 9001)
+    for rep, n in enumerate(sizes):
+        scene = st.synth_cloud_np(st.TARGET_SEED + rep, n)
+        engine.scene_load(scene)
+        normals = engine.scene_normals(20, True, (0.0, 0.0, 0.0))
+        want = ora.normals(scene, 20, True, (0, 0, 0), nthreads=ora.max_threads())
+        assert np.array_equal(normals.view(np.uint32), want.view(np.uint32)), rep
+        for commit in range(2 if rep == len(sizes) - 1 else 1):
+            engine.scene_commit_target()
+            res = engine.align_reference(np.eye(4)[None], 60, 0.005, 2.5, 5)
+            o = ora.icp_reference(model, np.concatenate([scene, want], axis=1), np.eye(4), 60, 0.005, 2.5, 5)
+            assert res.passes[0] == o["passes"], (rep, commit)
+            assert np.linalg.norm(res.poses[0] - o["pose"]) <= 1e-5, (rep, commit)
