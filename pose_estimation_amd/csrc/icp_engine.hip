@@ -101,6 +101,7 @@ struct LevelPlanes {  // compacted copy of every cloud of a set at pyramid level
   float* planes = nullptr;
   size_t stride = 0;
   std::vector<CloudEntry> clouds;
+  std::vector<uint32_t> first;       // per cloud: the level-0 row (of this rank's slab) the level's first point is; then every step-th
   std::vector<uint32_t> index_base;  // per cloud: index, in the WHOLE level cloud, of this rank's first level point (0 unless sharded)
   std::vector<uint32_t> n_total;     // per cloud: points of the whole level cloud over all ranks (= clouds[k].n unless sharded)
   XCopy xt;  // targets only
@@ -165,6 +166,8 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
 
 using namespace mi355;
 
+constexpr size_t kReadyWords = 1024;  // jobs of one pass that can publish for themselves (PassTail::ready); more take the copy path
+
 struct mi355_icp_ctx {
   BufferPool pool;
   int device = 0;
@@ -197,8 +200,8 @@ struct mi355_icp_ctx {
   double* ref_sums_host = nullptr;     // pinned, mapped: the last workgroup of a single-GPU pass writes the result here itself
   float* thr_host = nullptr;           // pinned
   double* ref_sums_mapped = nullptr;   // ref_sums_host as the device addresses it
-  uint32_t* pass_done = nullptr;       // device, [ref_jobs_cap + 1], zero between passes (PassTail::done)
-  uint32_t* ready_host = nullptr;      // pinned, mapped word the pass publishes its sequence number in
+  uint32_t* pass_done = nullptr;       // device, [ref_jobs_cap], zero between passes (PassTail::done)
+  uint32_t* ready_host = nullptr;      // pinned, mapped: one word per job, where a pass publishes (sequence number << 1 | error bit)
   uint32_t* ready_mapped = nullptr;
   uint32_t pass_seq = 0;
   bool error_word_known = false;       // the last pass brought the call's error word along (PassTail::error_flag): no copy needed
@@ -259,6 +262,7 @@ struct mi355_icp_ctx {
   bool call_pruned = false;          // this call asked for the pruned scan (MI355_ICP_FLAG_PRUNED_SCAN)
   int xbf16_shape = 0;               // 0: <4 sets, 256 threads> workgroups, 1: <2 sets, 512 threads> (MI355_ICP_XBF16_SHAPE)
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
+  bool level_sort = false;           // MI355_ICP_LEVEL_SORT=1: every pyramid level's sorted copy from a radix sort of its own (A/B)
   bool sort_sources = true;          // matrix-core scan: walk the sources in Morton order (MI355_ICP_SORT_SOURCES=0 turns it off: A/B)
 };
 
@@ -294,14 +298,25 @@ int sync_pass(mi355_icp_ctx* c) {
 
 // The same for a pass whose last workgroup publishes `seq` in pinned memory behind its results (PassTail): no copy command
 // to wait for, the word is there as soon as the rows are.
-int wait_pass(mi355_icp_ctx* c, uint32_t seq) {
+// Every job publishes (seq << 1 | error bit) in its own word.
+int wait_pass(mi355_icp_ctx* c, uint32_t seq, int n_jobs, uint32_t* error_bit) {
   const auto t0 = std::chrono::steady_clock::now();
+  auto all_there = [&]() {
+    uint32_t err = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+      const uint32_t w = __atomic_load_n(c->ready_host + k, __ATOMIC_ACQUIRE);
+      if ((w >> 1) != (seq & 0x7FFFFFFFu)) return false;
+      err |= w & 1u;
+    }
+    *error_bit = err;
+    return true;
+  };
   for (uint32_t spin = 1;; ++spin) {
-    if (__atomic_load_n(c->ready_host, __ATOMIC_ACQUIRE) == seq) return MI355_ICP_OK;
+    if (all_there()) return MI355_ICP_OK;
     if ((spin & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1500)) break;
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // long scans: sleep; a faulted launch: the error comes out here
-  if (__atomic_load_n(c->ready_host, __ATOMIC_ACQUIRE) != seq) return fail(c, MI355_ICP_ERR_INTERNAL, "a reference-mode pass ended without publishing its result");
+  if (!all_there()) return fail(c, MI355_ICP_ERR_INTERNAL, "a reference-mode pass ended without publishing its result");
   return MI355_ICP_OK;
 }
 
@@ -666,6 +681,21 @@ int run_overflow_fallback(mi355_icp_ctx* c, const Plan& plan, int n_active, cons
 
 // Builds, on the device, the expansion-filter copy of a group of target clouds (XCopy, xtarget_kernels.hip).
 // Everything is enqueued on the engine's stream; the scan that follows on the same stream sees it complete.
+// the buffers of a sorted copy of `stride` slots, padding written (a copy keeps its buffers while its stride stays the same)
+int alloc_xcopy(mi355_icp_ctx* c, XCopy& x, size_t stride) {
+  if (!x.planes) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.planes), 7 * stride * sizeof(float)));
+  if (!x.perm) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.perm), stride * sizeof(uint32_t)));
+  if (!x.table) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.table), 4 * (stride / kTile) * sizeof(float)));
+  if (!x.bf) HIP_TRY(c, c->pool.take(&x.bf, (stride / kTile) * static_cast<size_t>(kXbTileVecs) * 16));
+  if (!x.bf_table) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.bf_table), 4 * (stride / kTile) * sizeof(float)));
+  if (!x.sub) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.sub), (stride / 64) * 4 * sizeof(float)));
+  if (!x.super) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.super), (stride / kTile / kSuperTiles + 1) * 4 * sizeof(float)));
+  launch_xt_fill(c->stream, x.planes, stride, x.perm, x.bf);
+  HIP_TRY(c, hipMemsetAsync(x.table, 0, 4 * (stride / kTile) * sizeof(float), c->stream));
+  HIP_TRY(c, hipMemsetAsync(x.bf_table, 0, 4 * (stride / kTile) * sizeof(float), c->stream));
+  return MI355_ICP_OK;
+}
+
 int ensure_xcopy(mi355_icp_ctx* c, DevicePlanes view, size_t stride, const std::vector<CloudEntry>& clouds, XCopy& x) {
   if (x.valid) return MI355_ICP_OK;
   const int n_clouds = static_cast<int>(clouds.size());
@@ -691,13 +721,7 @@ int ensure_xcopy(mi355_icp_ctx* c, DevicePlanes view, size_t stride, const std::
   if ((st = grow(c, c->xt_scratch, c->xt_scratch_cap, 4 * static_cast<size_t>(max_n) + 2 * static_cast<size_t>(n_clouds))) != MI355_ICP_OK) return st;
   if ((st = grow(c, c->xt_box, c->xt_box_cap, 6 * static_cast<size_t>(n_clouds))) != MI355_ICP_OK) return st;
   if ((st = grow(c, c->xt_temp, c->xt_temp_cap, temp_bytes + 16)) != MI355_ICP_OK) return st;
-  if (!x.planes) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.planes), 7 * stride * sizeof(float)));
-  if (!x.perm) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.perm), stride * sizeof(uint32_t)));
-  if (!x.table) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.table), 4 * (stride / kTile) * sizeof(float)));
-  if (!x.bf) HIP_TRY(c, c->pool.take(&x.bf, (stride / kTile) * static_cast<size_t>(kXbTileVecs) * 16));
-  if (!x.bf_table) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.bf_table), 4 * (stride / kTile) * sizeof(float)));
-  if (!x.sub) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.sub), (stride / 64) * 4 * sizeof(float)));
-  if (!x.super) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.super), (stride / kTile / kSuperTiles + 1) * 4 * sizeof(float)));
+  if ((st = alloc_xcopy(c, x, stride)) != MI355_ICP_OK) return st;
   uint32_t* code = c->xt_scratch;
   uint32_t* index = code + max_n;
   uint32_t* code2 = index + max_n;
@@ -706,9 +730,6 @@ int ensure_xcopy(mi355_icp_ctx* c, DevicePlanes view, size_t stride, const std::
   HIP_TRY(c, hipMemcpyAsync(meta_dev, meta, 2 * static_cast<size_t>(n_clouds) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipEventRecord(c->xt_meta_event, c->stream));
   c->xt_meta_pending = true;
-  launch_xt_fill(c->stream, x.planes, stride, x.perm, x.bf);
-  HIP_TRY(c, hipMemsetAsync(x.table, 0, 4 * (stride / kTile) * sizeof(float), c->stream));
-  HIP_TRY(c, hipMemsetAsync(x.bf_table, 0, 4 * (stride / kTile) * sizeof(float), c->stream));
   launch_bbox(c->stream, view, meta_dev, meta_dev + n_clouds, n_clouds, max_n, c->xt_box);
   for (int k = 0; k < n_clouds; ++k)
     if (xtarget_build_cloud(c->stream, view, clouds[k].off, clouds[k].n, c->xt_box + 6 * k, code, index, code2, order, c->xt_temp,
@@ -1022,16 +1043,38 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
       c->pool.give(lv.planes);
       return fail(c, MI355_ICP_ERR_HIP, std::string("building pyramid level: ") + hipGetErrorString(e));
     }
+    lv.first = first;
     set.levels.push_back(lv);
   }
   return MI355_ICP_OK;
 }
 
 // the expansion-filter copy of pyramid level `level` of the targets (level 0: the uploaded clouds), built once per upload
+// The sorted copy of a pyramid level is DERIVED from the level-0 copy (xtarget_build_cloud_from_parent: the level's points in
+// the parent's Morton order, an order-preserving compaction instead of a radix sort) - MI355_ICP_LEVEL_SORT=1 sorts each
+// level by itself as rounds 1-2 did (A/B; same results either way, the order of a sorted copy never reaches an output).
 int ensure_level_xcopy(mi355_icp_ctx* c, CloudSet& set, int level) {
   if (level == 0) return ensure_xtarget(c, set);
   LevelPlanes& lv = set.levels[static_cast<size_t>(level) - 1];
-  return ensure_xcopy(c, lv.view(), lv.stride, lv.clouds, lv.xt);
+  if (lv.xt.valid) return MI355_ICP_OK;
+  if (c->level_sort) return ensure_xcopy(c, lv.view(), lv.stride, lv.clouds, lv.xt);
+  int st = ensure_xtarget(c, set);
+  if (st != MI355_ICP_OK) return st;
+  size_t scratch = 1;
+  for (size_t k = 0; k < lv.clouds.size(); ++k)
+    scratch = std::max(scratch, static_cast<size_t>(lv.clouds[k].n) + set.clouds[k].n / 4096 + 2);
+  if ((st = grow(c, c->xt_scratch, c->xt_scratch_cap, scratch)) != MI355_ICP_OK) return st;
+  if ((st = alloc_xcopy(c, lv.xt, lv.stride)) != MI355_ICP_OK) return st;
+  const DevicePlanes view = lv.view();
+  for (size_t k = 0; k < lv.clouds.size(); ++k)
+    if (xtarget_build_cloud_from_parent(c->stream, view, lv.clouds[k].off, lv.clouds[k].n, set.xt.perm + set.clouds[k].off, set.clouds[k].n,
+                                        lv.first[k], 1u << level, c->xt_scratch, lv.xt.planes, lv.stride, lv.xt.perm, lv.xt.table, lv.xt.bf,
+                                        lv.xt.sub, lv.xt.bf_table) != 0)
+      return fail(c, MI355_ICP_ERR_HIP, "deriving a pyramid level's sorted copy failed");
+  launch_super_tiles(c->stream, lv.xt.table, static_cast<uint32_t>(lv.stride / kTile), lv.xt.super);
+  HIP_TRY(c, hipGetLastError());
+  lv.xt.valid = true;
+  return MI355_ICP_OK;
 }
 
 const std::vector<CloudEntry>& level_clouds(const CloudSet& set, int level) { return level ? set.levels[level - 1].clouds : set.clouds; }
@@ -1071,8 +1114,8 @@ int ensure_ref_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs, size_t
     HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->ref_sums_host), want * (kRefSums + 3) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->ref_sums_mapped), c->ref_sums_host, 0));
     if (c->pass_done) { HIP_TRY(c, hipFree(c->pass_done)); c->pass_done = nullptr; }
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->pass_done), (want + 1) * sizeof(uint32_t)));
-    HIP_TRY(c, hipMemsetAsync(c->pass_done, 0, (want + 1) * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->pass_done), want * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->pass_done, 0, want * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->thr_host), want * sizeof(float), hipHostMallocDefault));
     c->ref_jobs_cap = want;
   }
@@ -1162,7 +1205,7 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
     HIP_TRY(c, hipMemcpyAsync(c->thr_dev, c->thr_host, static_cast<size_t>(n_active) * sizeof(float), hipMemcpyHostToDevice, c->stream));
   }
   // single GPU: the accumulate launch ends the pass by itself (PassTail) - every job has a workgroup to be its last one
-  bool tail_on = c->pass_tail && !sharded && sbx > 0;
+  bool tail_on = c->pass_tail && !sharded && sbx > 0 && static_cast<size_t>(n_active) <= kReadyWords;
   for (int k = 0; k < n_active; ++k) tail_on = tail_on && c->jobs_host[k].src_blocks > 0;
   PassTail tail;
   if (tail_on) {
@@ -1170,7 +1213,8 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
     tail.sums = c->ref_sums_mapped;
     tail.overflow_count = plan.fused ? c->overflow_count : nullptr;
     tail.overflow_cap = defer ? overflow_cap(c, n_active) : 0xFFFFFFFFu;
-    tail.seq = ++c->pass_seq;
+    c->pass_seq = (c->pass_seq + 1) & 0x7FFFFFFFu;
+    tail.seq = c->pass_seq;
     tail.ready = c->ready_mapped;
     tail.error_flag = c->error_flag;
   }
@@ -1195,8 +1239,7 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
     if (cst != MI355_ICP_OK) return fail(c, cst == MI355_ICP_ERR_HIP ? MI355_ICP_ERR_HIP : MI355_ICP_ERR_COMM, std::string("cross-rank exchange: ") + (why ? why : "?"));
   }
   if (tail_on) {
-    if (const int sst = wait_pass(c, tail.seq); sst != MI355_ICP_OK) return sst;
-    c->error_word = c->ref_sums_host[static_cast<size_t>(n_active) * (kRefSums + 3)] != 0.0 ? 1u : 0u;
+    if (const int sst = wait_pass(c, tail.seq, n_active, &c->error_word); sst != MI355_ICP_OK) return sst;
     c->error_word_known = true;
     if (profile) HIP_TRY(c, hipStreamSynchronize(c->stream));  // the events are read below
   } else {
@@ -1303,10 +1346,11 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   if ((e = hipMalloc(reinterpret_cast<void**>(&c->error_flag), sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(c->error_flag, 0, sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->flag_host), sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
-  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->ready_host), 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->ready_host), kReadyWords * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
   if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->ready_mapped), c->ready_host, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
-  *c->ready_host = 0;
+  std::memset(c->ready_host, 0, kReadyWords * sizeof(uint32_t));
   if (const char* v = std::getenv("MI355_ICP_PASS_TAIL")) c->pass_tail = std::atoi(v) != 0;
+  if (const char* v = std::getenv("MI355_ICP_LEVEL_SORT")) c->level_sort = std::atoi(v) != 0;
   *out = c;
   return MI355_ICP_OK;
 }

@@ -116,13 +116,13 @@ static_assert(sizeof(JobDesc) == 112, "JobDesc layout");
 // How ref_accumulate_kernel ends a single-GPU reference-mode pass by itself (done == nullptr: it does not, and
 // ref_final_reduce_kernel plus a device-to-host copy follow).
 struct PassTail {
-  uint32_t* done = nullptr;            // [n_jobs + 1], zero between passes: workgroups finished per job, then jobs finished
+  uint32_t* done = nullptr;            // [n_jobs], zero between passes: workgroups of the job that have finished
   double* sums = nullptr;              // the pass result block in pinned host memory, as the device addresses it
   uint32_t* overflow_count = nullptr;  // matrix-core scan: points sent to the overflow list per job (nullptr otherwise)
   uint32_t overflow_cap = 0xFFFFFFFFu;
-  uint32_t seq = 0;                    // what *ready becomes once every job's rows are written
-  uint32_t* ready = nullptr;           // pinned host word
-  const uint32_t* error_flag = nullptr;  // the call's "non-finite distance met" word; its value rides behind the tail
+  uint32_t seq = 0;                    // ready[job] becomes (seq << 1 | error bit) once the job's rows are written
+  uint32_t* ready = nullptr;           // [n_jobs] pinned host words
+  const uint32_t* error_flag = nullptr;  // the call's "non-finite distance met" word
 };
 
 constexpr int kRefSums = 29;  // 21 upper-triangle A^T A + 6 A^T b + sum |p-q|^2 + count
@@ -264,6 +264,9 @@ void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, 
 
 // ---- sorted / tile-centred target copy for the expansion filter (xtarget_kernels.hip) ----
 int xtarget_sort_temp_bytes(uint32_t n, size_t* bytes);
+int xtarget_build_cloud_from_parent(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const uint32_t* parent_perm,
+                                    uint32_t n_parent, uint32_t first, uint32_t step, uint32_t* scratch, float* xt, size_t stride,
+                                    uint32_t* perm, float* table, void* bf_image, void* sub_table, float* bf_table);
 int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const uint32_t* box, uint32_t* code,
                         uint32_t* index, uint32_t* code2, uint32_t* order, void* temp, size_t temp_bytes, float* xt,
                         size_t stride, uint32_t* perm, float* table, void* bf_image, void* sub_table, float* bf_table);

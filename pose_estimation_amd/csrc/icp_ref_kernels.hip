@@ -304,8 +304,7 @@ __global__ __launch_bounds__(kBlockThreads) void picky_scatter_kernel(const JobD
 }
 
 // ---------------------------------------------------------------------------------------------
-// Rows of the pass result: [n x 29 sums][n overflow-excess flags][n thresholds][n overflow counts], n = jobs of the pass
-// (+ one more value behind them when ref_accumulate_kernel ends the pass: the call's error word).
+// Rows of the pass result: [n x 29 sums][n overflow-excess flags][n thresholds][n overflow counts], n = jobs of the pass.
 __device__ __forceinline__ void write_pass_tail(double* sums, uint32_t n_jobs, uint32_t job, const float* thr,
                                                 uint32_t* overflow_count, uint32_t overflow_cap) {
   double* tail = sums + static_cast<size_t>(n_jobs) * kRefSums;
@@ -319,8 +318,8 @@ __device__ __forceinline__ void write_pass_tail(double* sums, uint32_t n_jobs, u
 // grid = (max src_blocks, n_jobs).  src/tgt are the LEVEL planes; normals are the level-0 normal planes.
 // With tail.done set the launch also ENDS the pass (single-GPU reference mode): the last workgroup of a job to finish adds
 // the job's partial rows up - in row order, so the sums are those of ref_final_reduce_kernel bit for bit - and writes them
-// with the tail straight into the host's (pinned, mapped) result block; the last job to finish publishes tail.seq in
-// *tail.ready behind a system-scope release, which is what the host polls.  One launch and no copy instead of two
+// with the tail straight into the host's (pinned, mapped) result block, then publishes (tail.seq << 1 | error bit) in
+// tail.ready[job], which is what the host polls.  One launch and no copy instead of two
 // launches and a device-to-host copy, on a chain of dependent launches that is most of a coarse level's pass.
 __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
     const JobDesc* __restrict__ jobs, const RefJobDesc* __restrict__ rjobs, const float* __restrict__ sx,
@@ -334,6 +333,8 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
   const JobDesc& J = jobs[blockIdx.y];
   const uint32_t sb = blockIdx.x;
   if (sb >= J.src_blocks) return;
+  // raised by earlier launches of the call only: read now, needed at the very end
+  const uint32_t raised = tail.done ? __hip_atomic_load(tail.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   const RefJobDesc& RJ = rjobs[blockIdx.y];
   float pose[12];
 #pragma unroll
@@ -342,35 +343,56 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
   double acc[kRefSums];
 #pragma unroll
   for (int k = 0; k < kRefSums; ++k) acc[k] = 0.0;
-#pragma unroll 1
-  for (int p = 0; p < kResolvePointsPerLane; ++p) {
-    const uint32_t local = sb * kSrcPerBlock + p * kBlockThreads + threadIdx.x;
-    if (local < J.src_n) {
-      const float d = dist2[J.out_off + local];
-      const uint32_t j = static_cast<uint32_t>(index[J.out_off + local]);
-      const bool sel = (d < t) && owner[RJ.owner_off + j] == picky_key(RJ.owner_prefix, d, RJ.src_index_base + local);
-      selected[J.out_off + local] = sel ? 1 : 0;
-      if (sel) {
-        const uint32_t i = J.src_off + local;
-        float px, py, pz;
-        transform_point(pose, sx[i], sy[i], sz[i], px, py, pz);  // the level-start point
-        const uint32_t tj = J.tgt_off + j;
-        const size_t nj = static_cast<size_t>(RJ.normal_off) + static_cast<size_t>(j) * RJ.step;
-        const double P0 = px, P1 = py, P2 = pz, Q0 = tx[tj], Q1 = ty[tj], Q2 = tz[tj];
-        const double N0 = nx[nj], N1 = ny[nj], N2 = nz[nj];
-        const double a[6] = {P1 * N2 - P2 * N1, P2 * N0 - P0 * N2, P0 * N1 - P1 * N0, N0, N1, N2};
-        const double dx = Q0 - P0, dy = Q1 - P1, dz = Q2 - P2;
-        const double b = dx * N0 + dy * N1 + dz * N2;
-        int k = 0;
+  // A point is a chain of dependent gathers (distance and index -> owner slot -> source, target and normal rows).  The
+  // lane's four points walk it side by side - every load of a stage is issued before the first one is used - so the
+  // launch waits for three round trips, not twelve: on the coarse pyramid levels that IS the launch.
+  constexpr int kP = kResolvePointsPerLane;
+  uint32_t local[kP], jt[kP];
+  float dd[kP];
+  bool live[kP];
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+  for (int p = 0; p < kP; ++p) {
+    local[p] = sb * kSrcPerBlock + p * kBlockThreads + threadIdx.x;
+    live[p] = local[p] < J.src_n;
+    const uint32_t at = J.out_off + (live[p] ? local[p] : 0u);
+    dd[p] = dist2[at];
+    jt[p] = static_cast<uint32_t>(index[at]);
+  }
+  unsigned long long own[kP];
 #pragma unroll
-          for (int c = r; c < 6; ++c) acc[k++] += a[r] * a[c];
+  for (int p = 0; p < kP; ++p) own[p] = owner[RJ.owner_off + jt[p]];
+  bool sel[kP];
+  float S0[kP], S1[kP], S2[kP], Qx[kP], Qy[kP], Qz[kP], Nx[kP], Ny[kP], Nz[kP];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) acc[21 + r] += a[r] * b;
-        acc[27] += dx * dx + dy * dy + dz * dz;
-        acc[28] += 1.0;
-      }
+  for (int p = 0; p < kP; ++p) {
+    sel[p] = live[p] && (dd[p] < t) && own[p] == picky_key(RJ.owner_prefix, dd[p], RJ.src_index_base + local[p]);
+    const uint32_t i = J.src_off + (live[p] ? local[p] : 0u);
+    const uint32_t tj = J.tgt_off + jt[p];
+    const size_t nj = static_cast<size_t>(RJ.normal_off) + static_cast<size_t>(jt[p]) * RJ.step;
+    S0[p] = sx[i]; S1[p] = sy[i]; S2[p] = sz[i];
+    Qx[p] = tx[tj]; Qy[p] = ty[tj]; Qz[p] = tz[tj];
+    Nx[p] = nx[nj]; Ny[p] = ny[nj]; Nz[p] = nz[nj];
+  }
+#pragma unroll
+  for (int p = 0; p < kP; ++p) {
+    if (live[p]) selected[J.out_off + local[p]] = sel[p] ? 1 : 0;
+    if (sel[p]) {
+      float px, py, pz;
+      transform_point(pose, S0[p], S1[p], S2[p], px, py, pz);  // the level-start point
+      const double P0 = px, P1 = py, P2 = pz, Q0 = Qx[p], Q1 = Qy[p], Q2 = Qz[p];
+      const double N0 = Nx[p], N1 = Ny[p], N2 = Nz[p];
+      const double a[6] = {P1 * N2 - P2 * N1, P2 * N0 - P0 * N2, P0 * N1 - P1 * N0, N0, N1, N2};
+      const double dx = Q0 - P0, dy = Q1 - P1, dz = Q2 - P2;
+      const double b = dx * N0 + dy * N1 + dz * N2;
+      int k = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) acc[k++] += a[r] * a[c];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) acc[21 + r] += a[r] * b;
+      acc[27] += dx * dx + dy * dy + dz * dz;
+      acc[28] += 1.0;
     }
   }
   const double r = block_sum<kRefSums>(acc, scratch);
@@ -382,23 +404,28 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
   // The classic last-block reduction, without its device-wide fences (a __threadfence() is a write-back of the whole L2 on
   // this chip, per workgroup: +15 us on a 14 us launch).  Everything one workgroup hands to another goes through
   // agent-scope atomic accesses instead - they are performed at memory, past the per-XCD L2s - and a writer waits for its
-  // own stores to be acknowledged (s_waitcnt) before it raises the count the reader takes its cue from.
-  if (threadIdx.x < kRefSums) __hip_atomic_store(my_row + threadIdx.x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the row is at memory
-  __syncthreads();
-  if (threadIdx.x == 0)
-    last_flag = __hip_atomic_fetch_add(&tail.done[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == J.src_blocks ? 1u : 0u;
-  __syncthreads();
-  if (!last_flag) return;
+  // own stores to be acknowledged (s_waitcnt) before it raises the count the reader takes its cue from.  What is left is a
+  // chain of memory round trips, so every link that can go does: a job of one workgroup (the coarsest levels) has nobody to
+  // wait for, every job publishes for itself (no count of finished jobs), and the call's error word was read at the start.
+  double total = r;
+  if (J.src_blocks > 1) {
+    if (threadIdx.x < kRefSums) __hip_atomic_store(my_row + threadIdx.x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the row is at memory
+    __syncthreads();
+    if (threadIdx.x == 0)
+      last_flag = __hip_atomic_fetch_add(&tail.done[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == J.src_blocks ? 1u : 0u;
+    __syncthreads();
+    if (!last_flag) return;
 #pragma unroll
-  for (int k = 0; k < kRefSums; ++k) acc[k] = 0.0;
-  for (uint32_t b = threadIdx.x; b < J.src_blocks; b += kBlockThreads) {  // row order: ref_final_reduce_kernel's sums, bit for bit
-    double* row = partials + static_cast<size_t>(J.partial_off + b) * kRefSums;
+    for (int k = 0; k < kRefSums; ++k) acc[k] = 0.0;
+    for (uint32_t b = threadIdx.x; b < J.src_blocks; b += kBlockThreads) {  // row order: ref_final_reduce_kernel's sums, bit for bit
+      double* row = partials + static_cast<size_t>(J.partial_off + b) * kRefSums;
 #pragma unroll
-    for (int k = 0; k < kRefSums; ++k) acc[k] += __hip_atomic_load(row + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int k = 0; k < kRefSums; ++k) acc[k] += __hip_atomic_load(row + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();  // scratch is reused
+    total = block_sum<kRefSums>(acc, scratch);
   }
-  __syncthreads();  // scratch is reused
-  const double total = block_sum<kRefSums>(acc, scratch);
   if (threadIdx.x < kRefSums)
     __hip_atomic_store(tail.sums + static_cast<size_t>(blockIdx.y) * kRefSums + threadIdx.x, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (threadIdx.x == 0) {
@@ -408,18 +435,12 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
     __hip_atomic_store(t + gridDim.y + blockIdx.y, static_cast<double>(thr[blockIdx.y]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(t + 2 * gridDim.y + blockIdx.y, static_cast<double>(n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (tail.overflow_count) tail.overflow_count[blockIdx.y] = 0u;
-    __hip_atomic_store(&tail.done[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next pass
+    if (J.src_blocks > 1) __hip_atomic_store(&tail.done[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next pass
   }
-  __builtin_amdgcn_s_waitcnt(0);  // this job's rows have reached the host's memory
+  __builtin_amdgcn_s_waitcnt(0);  // this job's rows have reached the host's memory ...
   __syncthreads();
-  if (threadIdx.x == 0 &&
-      __hip_atomic_fetch_add(&tail.done[gridDim.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.y) {
-    __hip_atomic_store(&tail.done[gridDim.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t raised = __hip_atomic_load(tail.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(tail.sums + static_cast<size_t>(gridDim.y) * (kRefSums + 3), static_cast<double>(raised), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __builtin_amdgcn_s_waitcnt(0);
-    __hip_atomic_store(tail.ready, tail.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // every job's rows were acknowledged before its count
-  }
+  // ... and only then its word: (sequence number of the pass << 1) | the call's error bit
+  if (threadIdx.x == 0) __hip_atomic_store(tail.ready + blockIdx.y, (tail.seq << 1) | (raised ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Tail of `sums` behind the n = gridDim.x rows: [n flags][n thresholds][n counts] - see final_reduce_kernel; the rejection

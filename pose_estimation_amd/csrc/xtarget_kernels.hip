@@ -383,6 +383,106 @@ int xtarget_sort_temp_bytes(uint32_t n, size_t* bytes) {
 }
 
 // Enqueues the whole build for one cloud on `stream`.  code/index/code2/order: n entries each; temp: sort scratch.
+// ---- sorted copy of a PYRAMID LEVEL without a sort of its own ------------------------------------------------------------
+// Level l of a cloud is rows first, first + step, first + 2 step, ... of level 0, so its points in the Morton order of the
+// level-0 sorted copy are that copy's order with everything else left out: an order-preserving compaction of one uint32
+// array (level-0 sorted position -> index) into (level sorted position -> level index).  Any spatially coherent order
+// serves the filter and the pruned scans equally - results never depend on it, the tile spheres are computed from the points
+// actually in the tile - so the level needs neither bounding box nor codes nor the eight launches of a radix sort; a new
+// scene pays for those once per request instead of once per matrix-core level.
+constexpr uint32_t kOrderItems = 16;  // consecutive parent positions per thread
+__device__ __forceinline__ bool level_member(uint32_t parent_index, uint32_t first, uint32_t step, uint32_t n_level, uint32_t* level_index) {
+  if (parent_index < first) return false;
+  const uint32_t rel = parent_index - first;
+  *level_index = rel / step;
+  return rel % step == 0 && *level_index < n_level;
+}
+// grid = ceil(n_parent / (256 * kOrderItems))
+__global__ __launch_bounds__(kBlockThreads) void level_order_count_kernel(const uint32_t* __restrict__ parent_perm, uint32_t n_parent,
+                                                                           uint32_t first, uint32_t step, uint32_t n_level,
+                                                                           uint32_t* __restrict__ block_counts) {
+  __shared__ uint32_t wave_tot[kBlockThreads / 64];
+  const uint32_t base = (blockIdx.x * kBlockThreads + threadIdx.x) * kOrderItems;
+  uint32_t mine = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kOrderItems; ++k) {
+    uint32_t li;
+    if (base + k < n_parent && level_member(parent_perm[base + k], first, step, n_level, &li)) ++mine;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+  if ((threadIdx.x & 63u) == 0) wave_tot[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < kBlockThreads / 64; ++w) t += wave_tot[w];
+    block_counts[blockIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(kBlockThreads) void level_order_write_kernel(const uint32_t* __restrict__ parent_perm, uint32_t n_parent,
+                                                                           uint32_t first, uint32_t step, uint32_t n_level,
+                                                                           const uint32_t* __restrict__ block_counts,
+                                                                           uint32_t* __restrict__ order) {
+  __shared__ uint32_t wave_tot[kBlockThreads / 64];
+  __shared__ uint32_t block_base;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  // members in the workgroups before this one
+  uint32_t before = 0;
+  for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kBlockThreads) before += block_counts[b];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) before += __shfl_xor(before, off, 64);
+  if (lane == 0) wave_tot[wave] = before;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < kBlockThreads / 64; ++w) t += wave_tot[w];
+    block_base = t;
+  }
+  __syncthreads();
+  const uint32_t base = (blockIdx.x * kBlockThreads + threadIdx.x) * kOrderItems;
+  uint32_t li[kOrderItems];
+  uint32_t flags = 0, mine = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kOrderItems; ++k) {
+    li[k] = 0;
+    if (base + k < n_parent && level_member(parent_perm[base + k], first, step, n_level, &li[k])) {
+      flags |= 1u << k;
+      ++mine;
+    }
+  }
+  uint32_t incl = mine;  // exclusive scan of `mine` over the workgroup, in thread order
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off, 64);
+    if (lane >= static_cast<uint32_t>(off)) incl += up;
+  }
+  __syncthreads();  // wave_tot is reused
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t at = block_base + incl - mine;
+  for (uint32_t w = 0; w < wave; ++w) at += wave_tot[w];
+#pragma unroll
+  for (uint32_t k = 0; k < kOrderItems; ++k)
+    if (flags & (1u << k)) order[at++] = li[k];
+}
+
+// The level's copy from its parent's order: `parent_perm` = the level-0 sorted copy's table for this cloud (n_parent
+// entries), `first`/`step` = which level-0 rows the level holds.  scratch: n + ceil(n_parent / 4096) words.
+int xtarget_build_cloud_from_parent(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const uint32_t* parent_perm,
+                                    uint32_t n_parent, uint32_t first, uint32_t step, uint32_t* scratch, float* xt, size_t stride,
+                                    uint32_t* perm, float* table, void* bf_image, void* sub_table, float* bf_table) {
+  if (!n) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const uint32_t blocks = (n_parent + kBlockThreads * kOrderItems - 1) / (kBlockThreads * kOrderItems);
+  uint32_t* order = scratch;
+  uint32_t* counts = scratch + n;
+  hipLaunchKernelGGL(level_order_count_kernel, dim3(blocks), dim3(kBlockThreads), 0, st, parent_perm, n_parent, first, step, n, counts);
+  hipLaunchKernelGGL(level_order_write_kernel, dim3(blocks), dim3(kBlockThreads), 0, st, parent_perm, n_parent, first, step, n, counts, order);
+  hipLaunchKernelGGL(centre_kernel, dim3((n + kTile - 1) / kTile), dim3(kBlockThreads), 0, st, planes.x, planes.y, planes.z, off, n,
+                     order, xt, stride, perm, table, static_cast<uint4*>(bf_image), static_cast<float4*>(sub_table), bf_table);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const uint32_t* box, uint32_t* code,
                         uint32_t* index, uint32_t* code2, uint32_t* order, void* temp, size_t temp_bytes, float* xt,
                         size_t stride, uint32_t* perm, float* table, void* bf_image, void* sub_table, float* bf_table) {

@@ -14,9 +14,11 @@ def nm(r):
     return r["Kernel_Name"].split("(")[0].replace("void mi355::", "").replace("mi355::", "")[:48] or "(blit)"
 
 
-# a request starts where the gap to the previous command is the largest (host-side frame synthesis / printing)
-gaps = [(int(rows[i]["Start_Timestamp"]) - int(rows[i - 1]["End_Timestamp"]), i) for i in range(1, len(rows))]
-first = max(gaps[len(gaps) // 4:])[1]
+# the last request: every request fits one plane (plane_hypotheses_kernel) and ends with an accumulate launch of the ICP
+hyp = [i for i, r in enumerate(rows) if "plane_hypotheses_kernel" in r["Kernel_Name"]]
+last_hyp = hyp[-1]
+prev_end = max(i for i in range(last_hyp) if "ref_accumulate_kernel" in rows[i]["Kernel_Name"]) if len(hyp) > 1 else -1
+first = prev_end + 1
 body = rows[first:]
 t0 = int(body[0]["Start_Timestamp"])
 prev = t0
