@@ -255,6 +255,10 @@ int mi355_icp_reference_pass(mi355_icp_ctx* ctx, int source_id, int target_id, i
 /* Minimum-norm least-squares solution x = (rx, ry, rz, tx, ty, tz) of the 6x6 normal equations packed in
  * sums (symmetric eigen-decomposition in double).  [host] */
 int mi355_icp_solve_point_to_plane(const double* sums29, double out_x[6]);
+/* The same for n systems (sums29: n x MI355_ICP_NREFSUMS, out_x: n x 6, out_status: n x MI355_ICP_OK or
+ * MI355_ICP_ERR_NUMERIC), eight per SIMD pass - what a reference-mode pass uses for its candidates.  Every system gets
+ * the bits mi355_icp_solve_point_to_plane would give it.  [host] */
+int mi355_icp_solve_point_to_plane_batch(const double* sums29, int n, double* out_x, int* out_status);
 
 /* ---- scene preparation: the reference's point filters as one-pass stream compaction ---- */
 

@@ -128,6 +128,7 @@ SIGNATURES = {
     "mi355_icp_reference_pass": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                            C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_float), C.c_void_p]),
     "mi355_icp_solve_point_to_plane": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi355_icp_solve_point_to_plane_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mi355_icp_scene_load": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_size_t]),
     "mi355_icp_scene_filter": (C.c_int, [_ctx, C.c_int, C.c_void_p, _P(C.c_size_t)]),
     "mi355_icp_scene_download": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),

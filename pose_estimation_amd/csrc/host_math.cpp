@@ -6,6 +6,8 @@
 // (pose_estimation/src/opencv_surface_match.cpp:94); the only in-repo
 // centroid+SVD is plane_fit (chessboard_pose_estimator.cpp:82-124).
 #include <cmath>
+#include <cstdlib>
+#include <string>
 #include <cstring>
 
 #include "../../include/mi355_icp.h"
@@ -238,6 +240,139 @@ int solve_point_to_plane(const double* sums, double* x) {
   for (int i = 0; i < n; ++i)
     if (!std::isfinite(x[i])) return MI355_ICP_ERR_NUMERIC;
   return MI355_ICP_OK;
+}
+
+// The same solve for up to 8 systems AT ONCE, one per SIMD lane (GCC vector extensions, compiled for AVX-512; other CPUs take
+// the scalar loop).  A reference-mode pass ends with one 6x6 solve per candidate pose while the device
+// has nothing to do; 6 of them in sequence were 14 us of every ~65 us coarse-level pass.  Every lane performs EXACTLY the
+// operations of solve_point_to_plane in the same order (+, -, *, /, sqrt are correctly rounded in every instruction set,
+// contraction is off): the scalar version's branches become masks - a skipped rotation or a lane that has already
+// converged keeps its values through a blend, never through an "identity rotation" - so results are bit-identical lane
+// for lane (tests/test_reference_mode_cpu.py compares the two on well-conditioned, rank-deficient and non-finite input).
+#pragma GCC diagnostic ignored "-Wpsabi"  // the vector helpers below are always inlined: no 64-byte value crosses a call
+namespace {
+typedef double vd8 __attribute__((vector_size(64)));
+typedef long long vm8 __attribute__((vector_size(64)));  // comparison results: -1 / 0 per lane
+
+__attribute__((always_inline)) inline vd8 splat(double v) { return vd8{v, v, v, v, v, v, v, v}; }
+__attribute__((always_inline)) inline vd8 vabs(vd8 v) { return v < splat(0.0) ? -v : v; }  // fabs for everything but the sign of zero, which is never looked at
+__attribute__((always_inline)) inline vd8 vsqrt(vd8 v) {
+  vd8 r;
+  for (int l = 0; l < 8; ++l) r[l] = std::sqrt(v[l]);
+  return r;
+}
+__attribute__((always_inline)) inline bool any(vm8 m) {
+  long long acc = 0;
+  for (int l = 0; l < 8; ++l) acc |= m[l];
+  return acc != 0;
+}
+}  // namespace
+
+namespace {
+__attribute__((always_inline)) inline void solve_batch_body(const double* sums, int n, double* x, int* status) {
+  constexpr int N = 6;
+  for (int base = 0; base < n; base += 8) {
+    const int lanes = n - base < 8 ? n - base : 8;
+    vd8 M[N][N], E[N][N], g[N];
+    vm8 bad = vm8{0, 0, 0, 0, 0, 0, 0, 0};
+    {
+      double in[kRefSums][8];
+      for (int k = 0; k < kRefSums; ++k)
+        for (int l = 0; l < 8; ++l) in[k][l] = l < lanes ? sums[static_cast<size_t>(base + l) * kRefSums + k] : (k == 0 || k == 6 || k == 11 || k == 15 || k == 18 || k == 20 ? 1.0 : 0.0);
+      for (int k = 0; k < kRefSums; ++k)
+        for (int l = 0; l < 8; ++l)
+          if (!std::isfinite(in[k][l])) bad[l] = -1;
+      int k = 0;
+      for (int i = 0; i < N; ++i)
+        for (int j = i; j < N; ++j) {
+          vd8 v;
+          for (int l = 0; l < 8; ++l) v[l] = in[k][l];
+          M[i][j] = M[j][i] = v;
+          ++k;
+        }
+      for (int i = 0; i < N; ++i) {
+        for (int l = 0; l < 8; ++l) g[i][l] = in[21 + i][l];
+        for (int j = 0; j < N; ++j) E[i][j] = splat(i == j ? 1.0 : 0.0);
+      }
+    }
+    vm8 act = ~bad;  // lanes still sweeping
+    for (int sweep = 0; sweep < 100; ++sweep) {
+      vd8 off = splat(0.0), diag = splat(0.0);
+      for (int i = 0; i < N; ++i) {
+        diag += vabs(M[i][i]);
+        for (int j = i + 1; j < N; ++j) off += vabs(M[i][j]);
+      }
+      act &= ~((off <= splat(1e-300)) | (off <= splat(1e-30) * diag));
+      if (!any(act)) break;
+      for (int p = 0; p < N - 1; ++p)
+        for (int q = p + 1; q < N; ++q) {
+          const vm8 go = act & (M[p][q] != splat(0.0));
+          if (!any(go)) continue;
+          const vd8 theta = (M[q][q] - M[p][p]) / (splat(2.0) * M[p][q]);
+          const vd8 t = (theta >= splat(0.0) ? splat(1.0) : splat(-1.0)) / (vabs(theta) + vsqrt(theta * theta + splat(1.0)));
+          const vd8 c = splat(1.0) / vsqrt(t * t + splat(1.0)), sn = t * c;
+          for (int r = 0; r < N; ++r) {
+            const vd8 a = M[r][p], b = M[r][q];
+            M[r][p] = go ? c * a - sn * b : a;
+            M[r][q] = go ? sn * a + c * b : b;
+          }
+          for (int r = 0; r < N; ++r) {
+            const vd8 a = M[p][r], b = M[q][r];
+            M[p][r] = go ? c * a - sn * b : a;
+            M[q][r] = go ? sn * a + c * b : b;
+          }
+          for (int r = 0; r < N; ++r) {
+            const vd8 a = E[r][p], b = E[r][q];
+            E[r][p] = go ? c * a - sn * b : a;
+            E[r][q] = go ? sn * a + c * b : b;
+          }
+        }
+    }
+    vd8 wmax = splat(0.0);
+    for (int i = 0; i < N; ++i) {
+      const vd8 w = vabs(M[i][i]);
+      wmax = (wmax < w || wmax != wmax) ? w : wmax;  // std::fmax(wmax, w) with wmax never NaN in a live lane
+    }
+    vd8 xs[N];
+    for (int i = 0; i < N; ++i) xs[i] = splat(0.0);
+    for (int e = 0; e < N; ++e) {
+      const vd8 w = M[e][e];
+      const vm8 use = w > splat(1e-12) * wmax;  // rank-deficient direction: left out (minimum-norm solution)
+      vd8 proj = splat(0.0);
+      for (int i = 0; i < N; ++i) proj += E[i][e] * g[i];
+      for (int i = 0; i < N; ++i) xs[i] = use ? xs[i] + E[i][e] * proj / w : xs[i];
+    }
+    for (int l = 0; l < lanes; ++l) {
+      int st = bad[l] ? MI355_ICP_ERR_NUMERIC : MI355_ICP_OK;
+      for (int i = 0; i < N; ++i) {
+        x[static_cast<size_t>(base + l) * N + i] = xs[i][l];
+        if (!std::isfinite(xs[i][l])) st = MI355_ICP_ERR_NUMERIC;
+      }
+      status[base + l] = st;
+    }
+  }
+}
+// The body is worth having with 512-bit registers only: GCC lowers its 64-byte vector compares and blends to scalar code on
+// AVX2 and below (measured: 3-8 x SLOWER than six scalar solves), so without AVX-512 the batch is the scalar loop.
+__attribute__((target("avx512f,avx512dq,avx512vl,avx512bw"))) void solve_batch_avx512(const double* sums, int n, double* x, int* status) {
+  solve_batch_body(sums, n, x, status);
+}
+void solve_batch_scalar(const double* sums, int n, double* x, int* status) {
+  for (int k = 0; k < n; ++k) status[k] = solve_point_to_plane(sums + static_cast<size_t>(k) * kRefSums, x + static_cast<size_t>(k) * 6);
+}
+}  // namespace
+
+void solve_point_to_plane_batch(const double* sums, int n, double* x, int* status) {
+  static void (*const impl)(const double*, int, double*, int*) = [] {
+    __builtin_cpu_init();
+    const char* want = std::getenv("MI355_ICP_SOLVE_ISA");  // "scalar": one system at a time whatever the CPU has (A/B, tests)
+    if (want && std::string(want) == "scalar") return &solve_batch_scalar;
+    if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl") &&
+        __builtin_cpu_supports("avx512bw"))
+      return &solve_batch_avx512;
+    return &solve_batch_scalar;
+  }();
+  impl(sums, n, x, status);
 }
 
 // ---- RANSAC plane fit, host half (mi355_icp_scene_fit_plane; reference pose_estimation.cpp:285-297) ----------------

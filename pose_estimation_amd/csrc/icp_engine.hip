@@ -1641,6 +1641,8 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
   c->call_pruned = (rp->flags & MI355_ICP_FLAG_PRUNED_SCAN) != 0;
   const bool profile = c->profile_always || (rp->flags & MI355_ICP_FLAG_PROFILE) != 0;
 
+  std::vector<double> solve_x;
+  std::vector<int> solve_st;
   struct JobState { double pose[16]; double residual = 0.0; int passes = 0; int status = MI355_ICP_OK; };
   struct LevelState { double posex[16]; double start[16]; double fval_old, fval_perc, fval_min; int i; bool done; };
   std::vector<JobState> js(static_cast<size_t>(n_jobs));
@@ -1725,13 +1727,17 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
         c->rjobs_host[q] = R;
       }
       if ((st = run_ref_pass(c, plan, level, static_cast<int>(active.size()), rp->rejection_scale, owner_total, profile)) != MI355_ICP_OK) return st;
+      // the candidates' 6x6 systems in one SIMD pass (lane for lane the scalar solve's bits): the device idles meanwhile
+      solve_x.resize(6 * active.size());
+      solve_st.resize(active.size());
+      solve_point_to_plane_batch(c->ref_sums_host, static_cast<int>(active.size()), solve_x.data(), solve_st.data());
       for (size_t q = 0; q < active.size(); ++q) {
         const int a = active[q];
         LevelState& L = ls[a];
         const double* sums = c->ref_sums_host + q * kRefSums;
         js[part[a]].passes += 1;
-        double x[6];
-        if (sums[28] < 6.0 || solve_point_to_plane(sums, x) != MI355_ICP_OK) {  // upstream: fewer than 6 pairs or a NaN solve leaves the level
+        const double* x = solve_x.data() + 6 * q;
+        if (sums[28] < 6.0 || solve_st[q] != MI355_ICP_OK) {  // upstream: fewer than 6 pairs or a NaN solve leaves the level
           L.done = true;
           continue;
         }
@@ -1800,6 +1806,12 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
     if (out_selected) HIP_TRY(c, hipMemcpy(out_selected, c->selected + J.out_off, J.src_n * sizeof(uint8_t), hipMemcpyDeviceToHost));
   }
   return check_error_flag(c);
+}
+
+int mi355_icp_solve_point_to_plane_batch(const double* sums29, int n, double* out_x, int* out_status) {
+  if (!sums29 || n < 0 || !out_x || !out_status) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  solve_point_to_plane_batch(sums29, n, out_x, out_status);
+  return MI355_ICP_OK;
 }
 
 int mi355_icp_solve_point_to_plane(const double* sums29, double out_x[6]) {

@@ -150,6 +150,8 @@ __device__ __forceinline__ unsigned long long picky_key(uint32_t prefix, float d
 #endif
 
 int solve_point_to_plane(const double* sums29, double* x6);
+// n systems at once, 8 per SIMD pass; x: n x 6, status: n (MI355_ICP_OK / MI355_ICP_ERR_NUMERIC).  Lane for lane the bits of solve_point_to_plane.
+void solve_point_to_plane_batch(const double* sums29, int n, double* x6, int* status);
 void euler_pose(const double* x6, double* pose16);
 void mat4_mul(const double* a, const double* b, double* c);
 

@@ -90,6 +90,19 @@ def solve_point_to_plane(sums: np.ndarray) -> np.ndarray:
     return x
 
 
+def solve_point_to_plane_batch(sums: np.ndarray):
+    """n systems at once (n x NREFSUMS) -> (x [n, 6], status [n]); every row gets the bits solve_point_to_plane gives it."""
+    sums = np.ascontiguousarray(sums, dtype=np.float64)
+    assert sums.ndim == 2 and sums.shape[1] == NREFSUMS
+    n = sums.shape[0]
+    x = np.zeros((n, 6), dtype=np.float64)
+    status = np.zeros(n, dtype=np.int32)
+    st = lib.mi355_icp_solve_point_to_plane_batch(sums.ctypes.data, n, x.ctypes.data, status.ctypes.data)
+    if st != _lib.OK:
+        raise IcpError(st, "solve_point_to_plane_batch")
+    return x, status
+
+
 def pose_to_pose7(pose: np.ndarray, reference_packing: bool = False) -> np.ndarray:
     p = np.ascontiguousarray(pose, dtype=np.float64).reshape(16)
     out = np.zeros(7, dtype=np.float32)

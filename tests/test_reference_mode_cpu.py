@@ -112,3 +112,51 @@ def test_golden_reference_mode_fixture_reproduced():
     n, sums, idx, d2, sel, thr = ora.ref_pass(g["src"][::2][:1000], g["tgt6"][::2][:1250], g["start"], g["cur"], scale)
     assert n == meta["pass_selected"] and np.array_equal(idx, g["pass_idx"]) and np.array_equal(d2, g["pass_d2"])
     assert np.array_equal(sel, g["pass_sel"]) and np.float32(thr) == g["pass_thr"] and np.array_equal(sums, g["pass_sums"])
+
+
+def _random_normal_equations(rng, n_rows, rank_deficient=False, scale=1.0):
+    p = rng.uniform(-1, 1, (n_rows, 3)) * scale
+    nn = rng.standard_normal((n_rows, 3))
+    nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+    if rank_deficient:
+        p[:, 2] = 0.0
+        nn[:] = [0.0, 0.0, 1.0]
+    q = p + rng.standard_normal((n_rows, 3)) * 1e-2 * scale
+    A = np.concatenate([np.cross(p, nn), nn], axis=1)
+    b = ((q - p) * nn).sum(1)
+    N = A.T @ A
+    return np.concatenate([N[np.triu_indices(6)], A.T @ b, [((p - q) ** 2).sum(), float(n_rows)]])
+
+
+def test_batched_solve_gives_every_system_the_bits_of_the_single_solve():
+    """The SIMD batch (8 systems per pass; what a reference-mode pass runs for its candidates) against the scalar solve, bit for
+    bit: well-conditioned, rank-deficient (masked eigen-directions), badly scaled, all-zero and non-finite systems, in batches
+    whose lanes converge after different numbers of sweeps, and batch sizes around the SIMD width."""
+    rng = np.random.default_rng(20261004)
+    rows = []
+    for k in range(45):
+        kind = k % 5
+        if kind == 0:
+            rows.append(_random_normal_equations(rng, 200))
+        elif kind == 1:
+            rows.append(_random_normal_equations(rng, 50, rank_deficient=True))
+        elif kind == 2:
+            rows.append(_random_normal_equations(rng, 30, scale=10.0 ** rng.integers(-6, 7)))
+        elif kind == 3:
+            rows.append(np.zeros(29))
+        else:
+            bad = _random_normal_equations(rng, 100)
+            bad[rng.integers(0, 29)] = [np.nan, np.inf, -np.inf][k % 3]
+            rows.append(bad)
+    sums = np.stack(rows)
+    for n in (1, 2, 6, 7, 8, 9, 16, 17, 45):
+        x, status = pa.solve_point_to_plane_batch(sums[:n])
+        for k in range(n):
+            try:
+                want = pa.solve_point_to_plane(sums[k])
+                assert status[k] == 0, (n, k)
+                assert np.array_equal(x[k].view(np.uint64), want.view(np.uint64)), (n, k, x[k], want)
+            except pa.IcpError:
+                assert status[k] != 0, (n, k)
+    x, status = pa.solve_point_to_plane_batch(np.zeros((0, 29)))
+    assert x.shape == (0, 6) and status.shape == (0,)
