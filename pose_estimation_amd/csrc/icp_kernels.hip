@@ -569,16 +569,30 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
     unsigned long long k1 = ~0ull, k2 = ~0ull, k3 = ~0ull;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (valid) {
-      for (uint32_t row = 0; row < n_rows; ++row) {
-        const size_t base = static_cast<size_t>(row) * key_stride + J.out_off + local;
+      // four key rows (twelve loads) in flight at a time: one row per trip made this loop a chain of n_rows memory round
+      // trips - with the 16-32 rows of a mid-size launch that chain WAS the launch (~28 us whatever the point count)
+      for (uint32_t row0 = 0; row0 < n_rows; row0 += 4) {
+        unsigned long long kk[4][3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const unsigned long long k = keys4[static_cast<size_t>(r) * rank_stride + base];
-          const bool l1 = k < k1, l2 = k < k2, l3 = k < k3;
-          k3 = l2 ? k2 : (l3 ? k : k3);
-          k2 = l1 ? k1 : (l2 ? k : k2);
-          k1 = l1 ? k : k1;
+        for (int j = 0; j < 4; ++j) {
+          const bool there = row0 + j < n_rows;
+          const size_t base = static_cast<size_t>(there ? row0 + j : row0) * key_stride + J.out_off + local;
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const unsigned long long k = keys4[static_cast<size_t>(r) * rank_stride + base];
+            kk[j][r] = there ? k : ~0ull;  // a row past the end must not enter twice
+          }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const unsigned long long k = kk[j][r];
+            const bool l1 = k < k1, l2 = k < k2, l3 = k < k3;
+            k3 = l2 ? k2 : (l3 ? k : k3);
+            k2 = l1 ? k1 : (l2 ? k : k2);
+            k1 = l1 ? k : k1;
+          }
       }
       const uint32_t i = J.src_off + local;
       transform_point(pose, sx[i], sy[i], sz[i], qx, qy, qz);
