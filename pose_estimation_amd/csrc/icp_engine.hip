@@ -184,7 +184,9 @@ struct mi355_icp_ctx {
   JobDesc* jobs_dev = nullptr;
   uint32_t* error_flag = nullptr;
   JobDesc* jobs_host = nullptr;  // pinned
-  double* sums_host = nullptr;   // pinned
+  double* sums_host = nullptr;   // pinned, mapped: the last workgroup of a single-GPU pass writes the result here itself (PassTail)
+  double* sums_mapped = nullptr; // sums_host as the device addresses it
+  uint32_t* p2p_done = nullptr;  // device, [jobs_cap], zero between passes (PassTail::done of the point-to-point pass)
   uint32_t* flag_host = nullptr; // pinned
 
   // reference-mode work buffers
@@ -456,7 +458,11 @@ int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs) {
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sums_dev), want * (MI355_ICP_NSUMS + 2) * sizeof(double)));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->jobs_dev), want * sizeof(JobDesc)));
     HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->jobs_host), want * sizeof(JobDesc), hipHostMallocDefault));
-    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->sums_host), want * (MI355_ICP_NSUMS + 2) * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->sums_host), want * (MI355_ICP_NSUMS + 2) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->sums_mapped), c->sums_host, 0));
+    if (c->p2p_done) { HIP_TRY(c, hipFree(c->p2p_done)); c->p2p_done = nullptr; }
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->p2p_done), want * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->p2p_done, 0, want * sizeof(uint32_t), c->stream));
     c->jobs_cap = want;
   }
   // the per-job overflow counters are zero between passes (the final-reduce kernels reset them); make that true at the
@@ -893,22 +899,23 @@ bool defer_pays(const mi355_icp_ctx* c, const Plan& plan, int n_active) {
   return tiles <= 256;
 }
 
-int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only, bool defer, bool* retry);
+int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only, bool defer, bool* retry, bool tail_allowed);
 
 // Enqueues one correspondence pass for the first n_active descriptors of jobs_host and leaves
 // their sums in sums_host (synchronises the stream).  `local_only` skips the collective.
-int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only) {
+// tail_allowed: the accumulation launch may end the pass by itself (PassTail) - the align loop; a correspondence query reads
+// its outputs with blocking copies afterwards and keeps the copy + synchronisation.
+int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only, bool tail_allowed = false) {
   // Slab-sharded: the exchange sits between the kernels and the synchronisation, so a rank cannot decide on its own to
   // repeat a pass.  The per-job "my device-side overflow pass was too small" flags therefore travel WITH the sums;
   // every rank sees their total and all of them repeat the pass through the host path together.
-  const bool defer = plan.fused && defer_pays(c, plan, n_active);
   bool retry = false;
-  int st = run_pass_once(c, plan, n_active, profile, local_only, defer, &retry);
-  if (st == MI355_ICP_OK && retry) st = run_pass_once(c, plan, n_active, profile, local_only, false, &retry);
+  int st = run_pass_once(c, plan, n_active, profile, local_only, plan.fused && defer_pays(c, plan, n_active), &retry, tail_allowed);
+  if (st == MI355_ICP_OK && retry) st = run_pass_once(c, plan, n_active, profile, local_only, false, &retry, tail_allowed);
   return st;
 }
 
-int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only, bool defer, bool* retry) {
+int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only, bool defer, bool* retry, bool tail_allowed) {
   *retry = false;
   if (stage_jobs(c->stream, c->jobs_host, nullptr, n_active, c->jobs_dev, nullptr) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
   uint32_t bx = 0, sbx = 0;
@@ -925,40 +932,61 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
   if (plan.out_total > c->out_cap || static_cast<size_t>(plan.partial_total) * MI355_ICP_NSUMS > c->partials_cap ||
       (plan.pruned ? false : plan.fused ? (plan.key_ranks() * key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : key_need > c->keys_cap))
     return fail(c, MI355_ICP_ERR_INTERNAL, "work buffers are smaller than the plan (ensure_buffers not run for this plan)");
+  // single GPU, align loop: the accumulation launch ends the pass by itself (PassTail) - every job has a workgroup to be its last one
+  const bool exchange = c->comm.attached() && !local_only;
+  bool tail_on = tail_allowed && c->pass_tail && !exchange && sbx > 0 && static_cast<size_t>(n_active) <= kReadyWords;
+  for (int k = 0; k < n_active; ++k) tail_on = tail_on && c->jobs_host[k].src_blocks > 0;
+  PassTail tail;
+  if (tail_on) {
+    tail.done = c->p2p_done;
+    tail.sums = c->sums_mapped;
+    tail.overflow_count = plan.fused ? c->overflow_count : nullptr;
+    tail.overflow_cap = defer ? overflow_cap(c, n_active) : 0xFFFFFFFFu;
+    c->pass_seq = (c->pass_seq + 1) & 0x7FFFFFFFu;
+    tail.seq = c->pass_seq;
+    tail.ready = c->ready_mapped;
+    tail.error_flag = c->error_flag;
+  }
+  c->error_word_known = false;
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (plan.pruned) {
     const int fst = run_pruned_index_phase(c, n_active, sbx, S, T);
     if (fst != MI355_ICP_OK) return fst;
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
-    if (sbx) launch_accumulate(c->stream, c->jobs_dev, n_active, sbx, S, T, c->out_index, c->out_dist2, c->partials);
+    if (sbx) launch_accumulate(c->stream, c->jobs_dev, n_active, sbx, S, T, c->out_index, c->out_dist2, c->partials, tail);
   } else if (plan.fused) {
     const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile, defer);
     if (fst != MI355_ICP_OK) return fst;
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
-    if (sbx) launch_accumulate(c->stream, c->jobs_dev, n_active, sbx, S, T, c->out_index, c->out_dist2, c->partials);
+    if (sbx) launch_accumulate(c->stream, c->jobs_dev, n_active, sbx, S, T, c->out_index, c->out_dist2, c->partials, tail);
   } else {
     if (plan.merged_keys && plan.out_total) HIP_TRY(c, hipMemsetAsync(c->keys, 0xFF, static_cast<size_t>(plan.out_total) * sizeof(unsigned long long), c->stream));
     c->keys_clean = 0;
     if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-    if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag);
+    if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag, tail);
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   }
-  // sums_dev: [n x 17 sums][n overflow-excess flags][n overflow counts]
-  launch_final_reduce(c->stream, c->jobs_dev, n_active, c->partials, c->sums_dev, plan.fused ? c->overflow_count : nullptr,
-                      defer ? overflow_cap(c, n_active) : 0xFFFFFFFFu);
+  // the pass result, sums_dev or (PassTail) sums_host directly: [n x 17 sums][n overflow-excess flags][n overflow counts]
+  if (!tail_on) launch_final_reduce(c->stream, c->jobs_dev, n_active, c->partials, c->sums_dev, plan.fused ? c->overflow_count : nullptr,
+                                    defer ? overflow_cap(c, n_active) : 0xFFFFFFFFu);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
   HIP_TRY(c, hipGetLastError());
-  const bool exchange = c->comm.attached() && !local_only;
   const size_t n_sums = static_cast<size_t>(n_active) * MI355_ICP_NSUMS, n_act = static_cast<size_t>(n_active);
   if (exchange) {  // the rows and the flags: every rank learns whether ANY rank's device-side overflow pass was too small
     const char* why = nullptr;
     const int cst = comm_sum_f64_rank_order(c->comm, c->sums_dev, n_sums + n_act, c->stream, &why);
     if (cst != MI355_ICP_OK) return fail(c, cst == MI355_ICP_ERR_HIP ? MI355_ICP_ERR_HIP : MI355_ICP_ERR_COMM, std::string("cross-rank exchange: ") + (why ? why : "?"));
   }
-  HIP_TRY(c, hipMemcpyAsync(c->sums_host, c->sums_dev, (n_sums + 2 * n_act) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  if (const int sst = sync_pass(c); sst != MI355_ICP_OK) return sst;
+  if (tail_on) {
+    if (const int sst = wait_pass(c, tail.seq, n_active, &c->error_word); sst != MI355_ICP_OK) return sst;
+    c->error_word_known = true;
+    if (profile) HIP_TRY(c, hipStreamSynchronize(c->stream));  // the events are read below
+  } else {
+    HIP_TRY(c, hipMemcpyAsync(c->sums_host, c->sums_dev, (n_sums + 2 * n_act) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (const int sst = sync_pass(c); sst != MI355_ICP_OK) return sst;
+  }
   if (defer || exchange) {
     // The decision must be the same on every rank (the flags are summed over the ranks) - including ranks whose own
     // plan did not defer anything (another scan kernel for their slab size): they repeat the pass with the others, or the
@@ -1408,6 +1436,7 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   if (c->rjobs_host) (void)hipHostFree(c->rjobs_host);
   if (c->ref_sums_host) (void)hipHostFree(c->ref_sums_host);
   if (c->pass_done) (void)hipFree(c->pass_done);
+  if (c->p2p_done) (void)hipFree(c->p2p_done);
   if (c->ready_host) (void)hipHostFree(c->ready_host);
   if (c->thr_host) (void)hipHostFree(c->thr_host);
   (void)hipFree(c->keys);
@@ -1471,7 +1500,7 @@ int mi355_icp_align(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const i
       if (!pose_to_f32(js[active[a]].pose, J.pose)) return fail(c, MI355_ICP_ERR_NUMERIC, "align: pose overflowed float32");
       c->jobs_host[a] = J;
     }
-    if ((st = run_pass(c, plan, static_cast<int>(active.size()), profile, false)) != MI355_ICP_OK) return st;
+    if ((st = run_pass(c, plan, static_cast<int>(active.size()), profile, false, true)) != MI355_ICP_OK) return st;
     std::vector<int> next;
     for (size_t a = 0; a < active.size(); ++a) {
       JobState& s = js[active[a]];

@@ -125,6 +125,96 @@ struct PassTail {
   const uint32_t* error_flag = nullptr;  // the call's "non-finite distance met" word
 };
 
+#if defined(__HIPCC__)
+// Sum of NV doubles per thread over a 256-thread workgroup: shuffle tree inside each wave, wave results through LDS, added in
+// wave order.  Threads 0..NV-1 return the total of value [threadIdx.x].
+template <int NV>
+__device__ __forceinline__ double pass_block_sum(double (&v)[NV], double (*scratch)[NV]) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double x = v[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    v[k] = x;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) scratch[wave][k] = v[k];
+  }
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x < NV) {
+    r = scratch[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kBlockThreads / 64; ++w) r += scratch[w][threadIdx.x];
+  }
+  return r;
+}
+
+// How an accumulation launch (grid = (workgroups of the largest job, jobs), 256 threads) ENDS the pass by itself: the last
+// workgroup of a job to finish adds the job's partial rows up - in row order, so the sums are those of the separate
+// final-reduce kernels bit for bit - and writes them, with whatever `extras` appends behind the n x NV rows, straight into
+// the host's (pinned, mapped) result block; then it publishes (tail.seq << 1 | error bit) in tail.ready[job], which is what
+// the host polls.  One launch and no copy command instead of two launches and a device-to-host copy, on a chain of
+// dependent launches that is most of a small pass.
+// This is the classic last-block reduction WITHOUT its device-wide fences (a __threadfence() is a write-back of the whole L2
+// on this chip, per workgroup: +15 us on a 14 us launch).  Everything one workgroup hands to another goes through
+// agent-scope atomic accesses instead - they are performed at memory, past the per-XCD L2s - and a writer waits for its
+// own stores to be acknowledged (s_waitcnt) before it raises the count the reader takes its cue from.  What is left is a
+// chain of memory round trips, so every link that can go does: a job of one workgroup has nobody to wait for, every job
+// publishes for itself (no count of finished jobs), and the caller reads the error word (`raised`) at kernel start.
+//   r: pass_block_sum's result of this workgroup (threads < NV); row / n_rows: this workgroup's partial row of the job
+//   extras(block_behind_the_rows, job, n_jobs): thread 0 only; system-scope atomic stores
+template <int NV, typename Extras>
+__device__ __forceinline__ void finish_pass(double r, double (&acc)[NV], double (*scratch)[NV], uint32_t* last_flag /* LDS word */,
+                                            double* job_rows, uint32_t row, uint32_t n_rows, const PassTail& tail, uint32_t raised,
+                                            Extras extras, bool reread_error = false) {
+  const uint32_t job = blockIdx.y, n_jobs = gridDim.y;
+  double total = r;
+  if (n_rows > 1) {
+    if (threadIdx.x < NV) __hip_atomic_store(job_rows + static_cast<size_t>(row) * NV + threadIdx.x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the row is at memory
+    __syncthreads();
+    if (threadIdx.x == 0)
+      *last_flag = __hip_atomic_fetch_add(&tail.done[job], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == n_rows ? 1u : 0u;
+    __syncthreads();
+    if (!*last_flag) return;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    for (uint32_t b = threadIdx.x; b < n_rows; b += kBlockThreads) {  // row order: the final-reduce kernels' sums, bit for bit
+      double* src = job_rows + static_cast<size_t>(b) * NV;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) acc[k] += __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();  // scratch is reused
+    total = pass_block_sum<NV>(acc, scratch);
+  }
+  if (threadIdx.x < NV) __hip_atomic_store(tail.sums + static_cast<size_t>(job) * NV + threadIdx.x, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) {
+    extras(tail.sums + static_cast<size_t>(n_jobs) * NV, job, n_jobs);
+    if (n_rows > 1) __hip_atomic_store(&tail.done[job], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next pass
+  }
+  __builtin_amdgcn_s_waitcnt(0);  // this job's rows have reached the host's memory ...
+  __syncthreads();
+  // ... and only then its word.  A launch that can raise the error word ITSELF (reread_error) looks at it again now: every
+  // workgroup of this job has waited for its own memory operations before it counted in, so whatever the job raised is there
+  // (what another job raises travels with that job's word; the host ORs them)
+  if (threadIdx.x == 0) {
+    if (reread_error) raised |= __hip_atomic_load(tail.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(tail.ready + job, (tail.seq << 1) | (raised ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// the overflow bookkeeping both result layouts end with: [n excess flags] ... [n counts] at flag_at / count_at
+__device__ __forceinline__ uint32_t publish_overflow(const PassTail& tail, uint32_t job, double* flag_at, double* count_at) {
+  const uint32_t n = tail.overflow_count ? __hip_atomic_load(&tail.overflow_count[job], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  __hip_atomic_store(flag_at, n > tail.overflow_cap ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(count_at, static_cast<double>(n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tail.overflow_count) tail.overflow_count[job] = 0u;
+  return n;
+}
+#endif
+
 constexpr int kRefSums = 29;  // 21 upper-triangle A^T A + 6 A^T b + sum |p-q|^2 + count
 struct RefJobDesc {
   uint32_t owner_off;    // first slot of this job's target in the picky owner table
@@ -234,14 +324,14 @@ void launch_overflow_tiles(void* stream, const JobDesc* jobs_dev, int n_jobs, ui
                            const uint32_t* tgt_perm, const void* tgt_table, const uint32_t* overflow_list, const uint32_t* overflow_count,
                            int32_t* out_index, float* out_dist2, uint32_t* error_flag);
 void launch_accumulate(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
-                       DevicePlanes tgt, const int32_t* index, const float* dist2, double* partials);
+                       DevicePlanes tgt, const int32_t* index, const float* dist2, double* partials, const PassTail& tail = PassTail{});
 void launch_gather_points(void* stream, DevicePlanes src, uint32_t src_off, const uint32_t* list, uint32_t n, float* out_planes,
                           size_t out_stride, uint32_t n_padded);
 void launch_scatter_results(void* stream, const uint32_t* list, uint32_t n, const int32_t* idx_tmp, const float* d2_tmp,
                             int32_t* out_index, float* out_dist2, uint32_t out_off);
 void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
                     DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride, int32_t* out_index,
-                    float* out_dist2, double* partials, uint32_t* error_flag);
+                    float* out_dist2, double* partials, uint32_t* error_flag, const PassTail& tail = PassTail{});
 void launch_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums,
                          uint32_t* overflow_count, uint32_t overflow_cap);
 

@@ -334,9 +334,10 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
     const JobDesc* __restrict__ jobs, const float* __restrict__ sx, const float* __restrict__ sy,
     const float* __restrict__ sz, const float* __restrict__ tx, const float* __restrict__ ty,
     const float* __restrict__ tz, unsigned long long* __restrict__ keys, uint32_t key_stride,
-    int32_t* __restrict__ out_index, float* __restrict__ out_dist2, double* __restrict__ partials,
-    uint32_t* __restrict__ error_flag) {
+    int32_t* __restrict__ out_index, float* __restrict__ out_dist2, double* partials,
+    uint32_t* __restrict__ error_flag, PassTail tail) {
   __shared__ double scratch[kSums ? kBlockThreads / 64 : 1][MI355_ICP_NSUMS];
+  __shared__ uint32_t last_flag;
 
   const JobDesc& J = jobs[blockIdx.y];
   const uint32_t sb = kSums ? blockIdx.x : blockIdx.x / kResolvePointsPerLane;
@@ -426,7 +427,16 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
 
   if (kSums) {
     const double r = block_sum<MI355_ICP_NSUMS>(acc, scratch);
-    if (tid < MI355_ICP_NSUMS) partials[static_cast<size_t>(J.partial_off + sb) * MI355_ICP_NSUMS + tid] = r;
+    double* job_rows = partials + static_cast<size_t>(J.partial_off) * MI355_ICP_NSUMS;
+    if (!tail.done) {
+      if (tid < MI355_ICP_NSUMS) job_rows[static_cast<size_t>(sb) * MI355_ICP_NSUMS + tid] = r;
+      return;
+    }
+    // single-GPU align loop: this launch ends the pass (finish_pass, icp_internal.h).  This kernel can raise the error
+    // word itself, so the job's last workgroup looks at it again right before it publishes (reread_error)
+    const uint32_t raised = 0u;
+    finish_pass<MI355_ICP_NSUMS>(r, acc, scratch, &last_flag, job_rows, sb, J.src_blocks, tail, raised,
+                                 [&](double* t, uint32_t job, uint32_t n_jobs) { publish_overflow(tail, job, t + job, t + n_jobs + job); }, true);
   }
 }
 
@@ -1100,11 +1110,14 @@ __global__ __launch_bounds__(kBlockThreads) void accumulate_kernel(const JobDesc
                                                                     const float* __restrict__ ty, const float* __restrict__ tz,
                                                                     const int32_t* __restrict__ index,
                                                                     const float* __restrict__ dist2,
-                                                                    double* __restrict__ partials) {
+                                                                    double* partials, PassTail tail) {
   __shared__ double scratch[kBlockThreads / 64][MI355_ICP_NSUMS];
+  __shared__ uint32_t last_flag;
   const JobDesc& J = jobs[blockIdx.y];
   const uint32_t sb = blockIdx.x;
   if (sb >= J.src_blocks) return;
+  // raised by earlier launches of the pass only (the resolve and overflow kernels): read now, needed at the very end
+  const uint32_t raised = tail.done ? __hip_atomic_load(tail.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   const float max_d2 = J.max_d2;
   double acc[MI355_ICP_NSUMS];
 #pragma unroll
@@ -1128,7 +1141,13 @@ __global__ __launch_bounds__(kBlockThreads) void accumulate_kernel(const JobDesc
     }
   }
   const double r = block_sum<MI355_ICP_NSUMS>(acc, scratch);
-  if (threadIdx.x < MI355_ICP_NSUMS) partials[static_cast<size_t>(J.partial_off + sb) * MI355_ICP_NSUMS + threadIdx.x] = r;
+  double* job_rows = partials + static_cast<size_t>(J.partial_off) * MI355_ICP_NSUMS;
+  if (!tail.done) {
+    if (threadIdx.x < MI355_ICP_NSUMS) job_rows[static_cast<size_t>(sb) * MI355_ICP_NSUMS + threadIdx.x] = r;
+    return;
+  }
+  finish_pass<MI355_ICP_NSUMS>(r, acc, scratch, &last_flag, job_rows, sb, J.src_blocks, tail, raised,
+                               [&](double* t, uint32_t job, uint32_t n_jobs) { publish_overflow(tail, job, t + job, t + n_jobs + job); });
 }
 
 // overflow handling: gather the listed source points into scratch planes / scatter their exact answers back
@@ -1229,17 +1248,17 @@ void launch_nn_scan(void* stream, int points_per_lane, const JobDesc* jobs_dev, 
 // partials == nullptr: indices and distances only (reference mode), and merged key rows are handed back cleared
 void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
                     DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride, int32_t* out_index,
-                    float* out_dist2, double* partials, uint32_t* error_flag) {
+                    float* out_dist2, double* partials, uint32_t* error_flag, const PassTail& tail) {
   if (partials) {
     dim3 grid(max_src_blocks, static_cast<uint32_t>(n_jobs));
     hipLaunchKernelGGL(resolve_accumulate_kernel<true>, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
                        jobs_dev, src.x, src.y, src.z, tgt.x, tgt.y, tgt.z, keys, key_stride, out_index, out_dist2,
-                       partials, error_flag);
+                       partials, error_flag, tail);
   } else {
     dim3 grid(max_src_blocks * kResolvePointsPerLane, static_cast<uint32_t>(n_jobs));
     hipLaunchKernelGGL(resolve_accumulate_kernel<false>, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
                        jobs_dev, src.x, src.y, src.z, tgt.x, tgt.y, tgt.z, keys, key_stride, out_index, out_dist2,
-                       partials, error_flag);
+                       partials, error_flag, PassTail{});
   }
 }
 
@@ -1316,10 +1335,10 @@ void launch_nn_pruned(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_
 }
 
 void launch_accumulate(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,
-                       DevicePlanes tgt, const int32_t* index, const float* dist2, double* partials) {
+                       DevicePlanes tgt, const int32_t* index, const float* dist2, double* partials, const PassTail& tail) {
   dim3 grid(max_src_blocks, static_cast<uint32_t>(n_jobs));
   hipLaunchKernelGGL(accumulate_kernel, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x, src.y,
-                     src.z, tgt.x, tgt.y, tgt.z, index, dist2, partials);
+                     src.z, tgt.x, tgt.y, tgt.z, index, dist2, partials, tail);
 }
 
 void launch_gather_points(void* stream, DevicePlanes src, uint32_t src_off, const uint32_t* list, uint32_t n, float* out_planes,

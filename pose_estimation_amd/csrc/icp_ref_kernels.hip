@@ -316,11 +316,7 @@ __device__ __forceinline__ void write_pass_tail(double* sums, uint32_t n_jobs, u
 }
 
 // grid = (max src_blocks, n_jobs).  src/tgt are the LEVEL planes; normals are the level-0 normal planes.
-// With tail.done set the launch also ENDS the pass (single-GPU reference mode): the last workgroup of a job to finish adds
-// the job's partial rows up - in row order, so the sums are those of ref_final_reduce_kernel bit for bit - and writes them
-// with the tail straight into the host's (pinned, mapped) result block, then publishes (tail.seq << 1 | error bit) in
-// tail.ready[job], which is what the host polls.  One launch and no copy instead of two
-// launches and a device-to-host copy, on a chain of dependent launches that is most of a coarse level's pass.
+// With tail.done set the launch also ENDS the pass (single-GPU reference mode): finish_pass, icp_internal.h.
 __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
     const JobDesc* __restrict__ jobs, const RefJobDesc* __restrict__ rjobs, const float* __restrict__ sx,
     const float* __restrict__ sy, const float* __restrict__ sz, const float* __restrict__ tx,
@@ -396,51 +392,16 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
     }
   }
   const double r = block_sum<kRefSums>(acc, scratch);
-  double* my_row = partials + static_cast<size_t>(J.partial_off + sb) * kRefSums;
+  double* job_rows = partials + static_cast<size_t>(J.partial_off) * kRefSums;
   if (!tail.done) {
-    if (threadIdx.x < kRefSums) my_row[threadIdx.x] = r;
+    if (threadIdx.x < kRefSums) job_rows[static_cast<size_t>(sb) * kRefSums + threadIdx.x] = r;
     return;
   }
-  // The classic last-block reduction, without its device-wide fences (a __threadfence() is a write-back of the whole L2 on
-  // this chip, per workgroup: +15 us on a 14 us launch).  Everything one workgroup hands to another goes through
-  // agent-scope atomic accesses instead - they are performed at memory, past the per-XCD L2s - and a writer waits for its
-  // own stores to be acknowledged (s_waitcnt) before it raises the count the reader takes its cue from.  What is left is a
-  // chain of memory round trips, so every link that can go does: a job of one workgroup (the coarsest levels) has nobody to
-  // wait for, every job publishes for itself (no count of finished jobs), and the call's error word was read at the start.
-  double total = r;
-  if (J.src_blocks > 1) {
-    if (threadIdx.x < kRefSums) __hip_atomic_store(my_row + threadIdx.x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the row is at memory
-    __syncthreads();
-    if (threadIdx.x == 0)
-      last_flag = __hip_atomic_fetch_add(&tail.done[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == J.src_blocks ? 1u : 0u;
-    __syncthreads();
-    if (!last_flag) return;
-#pragma unroll
-    for (int k = 0; k < kRefSums; ++k) acc[k] = 0.0;
-    for (uint32_t b = threadIdx.x; b < J.src_blocks; b += kBlockThreads) {  // row order: ref_final_reduce_kernel's sums, bit for bit
-      double* row = partials + static_cast<size_t>(J.partial_off + b) * kRefSums;
-#pragma unroll
-      for (int k = 0; k < kRefSums; ++k) acc[k] += __hip_atomic_load(row + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();  // scratch is reused
-    total = block_sum<kRefSums>(acc, scratch);
-  }
-  if (threadIdx.x < kRefSums)
-    __hip_atomic_store(tail.sums + static_cast<size_t>(blockIdx.y) * kRefSums + threadIdx.x, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (threadIdx.x == 0) {
-    double* t = tail.sums + static_cast<size_t>(gridDim.y) * kRefSums;
-    const uint32_t n = tail.overflow_count ? __hip_atomic_load(&tail.overflow_count[blockIdx.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    __hip_atomic_store(t + blockIdx.y, n > tail.overflow_cap ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(t + gridDim.y + blockIdx.y, static_cast<double>(thr[blockIdx.y]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(t + 2 * gridDim.y + blockIdx.y, static_cast<double>(n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (tail.overflow_count) tail.overflow_count[blockIdx.y] = 0u;
-    if (J.src_blocks > 1) __hip_atomic_store(&tail.done[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next pass
-  }
-  __builtin_amdgcn_s_waitcnt(0);  // this job's rows have reached the host's memory ...
-  __syncthreads();
-  // ... and only then its word: (sequence number of the pass << 1) | the call's error bit
-  if (threadIdx.x == 0) __hip_atomic_store(tail.ready + blockIdx.y, (tail.seq << 1) | (raised ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const float threshold = thr[blockIdx.y];
+  finish_pass<kRefSums>(r, acc, scratch, &last_flag, job_rows, sb, J.src_blocks, tail, raised, [&](double* t, uint32_t job, uint32_t n_jobs) {
+    publish_overflow(tail, job, t + job, t + 2 * n_jobs + job);
+    __hip_atomic_store(t + n_jobs + job, static_cast<double>(threshold), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // float -> double is exact
+  });
 }
 
 // Tail of `sums` behind the n = gridDim.x rows: [n flags][n thresholds][n counts] - see final_reduce_kernel; the rejection
