@@ -295,32 +295,6 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_sgpr_kernel(const JobDe
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Block-wide sum of NV doubles per thread, fixed order: xor-shuffle tree inside each wave64,
-// then waves 0..3 in order.  Result valid in threads 0..NV-1 of the block (value k in thread k).
-template <int NV>
-__device__ __forceinline__ double block_sum(double (&v)[NV], double (*scratch)[NV]) {
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    double x = v[k];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
-    v[k] = x;
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) scratch[wave][k] = v[k];
-  }
-  __syncthreads();
-  double r = 0.0;
-  if (threadIdx.x < NV) {
-    r = scratch[0][threadIdx.x];
-#pragma unroll
-    for (int w = 1; w < kBlockThreads / 64; ++w) r += scratch[w][threadIdx.x];
-  }
-  return r;
-}
 
 // ---------------------------------------------------------------------------------------------
 // N1 (index recovery) + N2 (accumulation).  grid = (max_j src_blocks_j, n_jobs), block = 256.
@@ -426,7 +400,7 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
   }
 
   if (kSums) {
-    const double r = block_sum<MI355_ICP_NSUMS>(acc, scratch);
+    const double r = pass_block_sum<MI355_ICP_NSUMS>(acc, scratch);
     double* job_rows = partials + static_cast<size_t>(J.partial_off) * MI355_ICP_NSUMS;
     if (!tail.done) {
       if (tid < MI355_ICP_NSUMS) job_rows[static_cast<size_t>(sb) * MI355_ICP_NSUMS + tid] = r;
@@ -1140,7 +1114,7 @@ __global__ __launch_bounds__(kBlockThreads) void accumulate_kernel(const JobDesc
       }
     }
   }
-  const double r = block_sum<MI355_ICP_NSUMS>(acc, scratch);
+  const double r = pass_block_sum<MI355_ICP_NSUMS>(acc, scratch);
   double* job_rows = partials + static_cast<size_t>(J.partial_off) * MI355_ICP_NSUMS;
   if (!tail.done) {
     if (threadIdx.x < MI355_ICP_NSUMS) job_rows[static_cast<size_t>(sb) * MI355_ICP_NSUMS + threadIdx.x] = r;
@@ -1181,7 +1155,7 @@ __global__ __launch_bounds__(kBlockThreads) void scatter_results_kernel(const ui
 
 // ---------------------------------------------------------------------------------------------
 // N2 final reduction: one workgroup per job sums that job's per-block partials in a fixed order
-// (thread t takes blocks t, t+256, ... ascending; then the block_sum tree), so a given cloud,
+// (thread t takes blocks t, t+256, ... ascending; then the pass_block_sum tree), so a given cloud,
 // pose and slab always reduces to the same bits.
 // Tail of `sums` behind the n = gridDim.x rows: [n flags][n counts] - this pass's overflow count of every job (what the
 // host books after the pass's single synchronisation) and whether it exceeded what the device-side overflow pass covers
@@ -1201,7 +1175,7 @@ __global__ __launch_bounds__(kBlockThreads) void final_reduce_kernel(const JobDe
 #pragma unroll
     for (int k = 0; k < MI355_ICP_NSUMS; ++k) acc[k] += row[k];
   }
-  const double r = block_sum<MI355_ICP_NSUMS>(acc, scratch);
+  const double r = pass_block_sum<MI355_ICP_NSUMS>(acc, scratch);
   if (threadIdx.x < MI355_ICP_NSUMS) sums[static_cast<size_t>(blockIdx.x) * MI355_ICP_NSUMS + threadIdx.x] = r;
   if (threadIdx.x == 0) {
     double* tail = sums + static_cast<size_t>(gridDim.x) * MI355_ICP_NSUMS;

@@ -32,29 +32,6 @@ __device__ __forceinline__ void transform_point(const float* __restrict__ m, flo
   a = m[8] * x; b = m[9] * y; a = a + b; b = m[10] * z; a = a + b; oz = a + m[11];
 }
 
-template <int NV>
-__device__ __forceinline__ double block_sum(double (&v)[NV], double (*scratch)[NV]) {
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    double x = v[k];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
-    v[k] = x;
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) scratch[wave][k] = v[k];
-  }
-  __syncthreads();
-  double r = 0.0;
-  if (threadIdx.x < NV) {
-    r = scratch[0][threadIdx.x];
-#pragma unroll
-    for (int w = 1; w < kBlockThreads / 64; ++w) r += scratch[w][threadIdx.x];
-  }
-  return r;
-}
 
 }  // namespace
 
@@ -391,7 +368,7 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
       acc[28] += 1.0;
     }
   }
-  const double r = block_sum<kRefSums>(acc, scratch);
+  const double r = pass_block_sum<kRefSums>(acc, scratch);
   double* job_rows = partials + static_cast<size_t>(J.partial_off) * kRefSums;
   if (!tail.done) {
     if (threadIdx.x < kRefSums) job_rows[static_cast<size_t>(sb) * kRefSums + threadIdx.x] = r;
@@ -420,7 +397,7 @@ __global__ __launch_bounds__(kBlockThreads) void ref_final_reduce_kernel(const J
 #pragma unroll
     for (int k = 0; k < kRefSums; ++k) acc[k] += row[k];
   }
-  const double r = block_sum<kRefSums>(acc, scratch);
+  const double r = pass_block_sum<kRefSums>(acc, scratch);
   if (threadIdx.x < kRefSums) sums[static_cast<size_t>(blockIdx.x) * kRefSums + threadIdx.x] = r;
   if (threadIdx.x == 0) write_pass_tail(sums, gridDim.x, blockIdx.x, thr, overflow_count, overflow_cap);
 }
