@@ -532,6 +532,40 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   return a < b ? a : b;
 }
 
+// Wave-wide unsigned minima of EIGHT values per lane at once (one per point of a resolve step).  Reducing them one after
+// the other costs eight butterflies; here the first three exchange steps also TRANSPOSE - a lane hands half of its values
+// to its partner and keeps the other half, so after strides 1, 2, 4 it holds ONE point's partial minimum (over its group of
+// 8 lanes) - and three plain steps (8, 16, 32) finish it: 7 + 3 minima instead of 48.  Lane L ends up with the minimum of
+// point k(L) = 4 (L & 1) + 2 (L >> 1 & 1) + (L >> 2 & 1); wave_min8_of() reads point k's back as a scalar.  All 64 lanes active.
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t wave_min8(const uint32_t (&v)[8]) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const bool b0 = lane & 1u, b1 = lane & 2u, b2 = lane & 4u;
+  uint32_t w[4], x[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // stride 1: lanes with bit 0 clear keep points 0-3
+    const uint32_t mine = b0 ? v[4 + i] : v[i], give = b0 ? v[i] : v[4 + i];
+    w[i] = umin32(mine, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(give), 0xB1, 0xF, 0xF, false)));  // quad_perm [1,0,3,2]
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {  // stride 2: bit 1 clear keeps the lower two of those
+    const uint32_t mine = b1 ? w[2 + i] : w[i], give = b1 ? w[i] : w[2 + i];
+    x[i] = umin32(mine, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(give), 0x4E, 0xF, 0xF, false)));  // quad_perm [2,3,0,1]
+  }
+  uint32_t r;
+  {  // stride 4 (ds_swizzle, bit mode: and 0x1F, or 0, xor 4)
+    const uint32_t mine = b2 ? x[1] : x[0], give = b2 ? x[0] : x[1];
+    r = umin32(mine, static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(give), 0x101F)));
+  }
+  r = umin32(r, static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(r), 0x201F)));  // xor 8
+  r = umin32(r, static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(r), 0x401F)));  // xor 16
+  r = umin32(r, static_cast<uint32_t>(__shfl_xor(static_cast<int>(r), 32, 64)));
+  return r;
+}
+__device__ __forceinline__ uint32_t wave_min8_of(uint32_t r, int k) {  // k: compile-time point number
+  return __builtin_amdgcn_readlane(r, ((k >> 2) & 1) | (((k >> 1) & 1) << 1) | ((k & 1) << 2));
+}
+
 template <int kRun>  // targets per remembered granule: kFusedChunk (VALU filter) or kXbRun (matrix-core filter)
 __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
     const JobDesc* __restrict__ jobs, uint32_t split_mul, const float* __restrict__ sx, const float* __restrict__ sy,
@@ -606,6 +640,7 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
           Pm[k][it] = perm[tbase + it * 64];
         }
       }
+      uint32_t mdb[kN], mjv[kN];
 #pragma unroll
       for (int k = 0; k < kN; ++k) {
         float md = __builtin_inff();
@@ -618,8 +653,25 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
             mj = Pm[k][it];
           }
         }
-        ud[k] = wave_min_u32(__float_as_uint(md));  // md is never NaN (d < md is false for NaN) nor negative
-        uj[k] = wave_min_u32(__float_as_uint(md) == ud[k] ? mj : 0xFFFFFFFFu);
+        mdb[k] = __float_as_uint(md);  // md is never NaN (d < md is false for NaN) nor negative: unsigned order is float order
+        mjv[k] = mj;
+      }
+      if constexpr (kN == 8) {  // all eight points' minima in one transposing reduction each (distance, then index among its ties)
+        const uint32_t rd = wave_min8(mdb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          ud[k] = wave_min8_of(rd, k);
+          mjv[k] = mdb[k] == ud[k] ? mjv[k] : 0xFFFFFFFFu;
+        }
+        const uint32_t rj = wave_min8(mjv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) uj[k] = wave_min8_of(rj, k);
+      } else {
+#pragma unroll
+        for (int k = 0; k < kN; ++k) {
+          ud[k] = wave_min_u32(mdb[k]);
+          uj[k] = wave_min_u32(mdb[k] == ud[k] ? mjv[k] : 0xFFFFFFFFu);
+        }
       }
     };
     // Phase A: granule 1 of every point, kStep points per step (one at a time, a wave's 64 points are 64 dependent
