@@ -57,7 +57,12 @@ class Engine {
     std::vector<Pose> poses;
     std::vector<double> residual;
     std::vector<int> iterations, status, converged;
+    std::string note;  // what mi355_icp_last_error() says after a call that returned MI355_ICP_OK: empty, or e.g. "a
+                       // non-finite distance was met" (coordinates or a pose overflowing float32) - the answer is the oracle's
+                       // for that case, but a caller will want to know
   };
+  // the engine's note after the last call (see Result::note)
+  std::string last_note() const { return mi355_icp_last_error(ctx_); }
 
   Result align(const std::vector<int>& source_ids, const std::vector<int>& target_ids, const std::vector<Pose>& init,
                const mi355_icp_params& params) {
@@ -74,6 +79,7 @@ class Engine {
                           n ? r.poses[0].data() : nullptr, r.residual.data(), r.iterations.data(), r.status.data(),
                           r.converged.data()),
           "mi355_icp_align");
+    r.note = last_note();
     return r;
   }
 
@@ -227,6 +233,7 @@ class ICP {
                                                last_.poses[0].data(), last_.residual.data(), last_.iterations.data(),
                                                last_.status.data());
       if (st != MI355_ICP_OK) throw Error(st, std::string("mi355_icp_align_reference: ") + mi355_icp_last_error(engine_->handle()));
+      last_.note = engine_->last_note();
     } else {
       last_ = engine_->align(sid, tid, init, params_);
     }
