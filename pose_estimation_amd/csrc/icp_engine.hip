@@ -258,6 +258,7 @@ struct mi355_icp_ctx {
   JobDesc* jobs2_dev = nullptr;        JobDesc* jobs2_host = nullptr; size_t jobs2_cap = 0;
   uint64_t overflow_points_total = 0;  // statistics
   uint32_t target_blocks = 12288;    // planner: aim for about this many scan workgroups per launch
+  bool target_blocks_mfma_forced = false;
   uint32_t target_blocks_mfma = 4096; // ... for the matrix-core filter: its workgroups span 512 points and publish two key
                                      // rows per split, so fewer, longer ones cost less key traffic (100k<->100k: resolve
                                      // 82 -> 35 us at equal scan time; profiles/r01o_target_blocks.txt)
@@ -532,7 +533,11 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
     total_src_blocks += (src_clouds[source_ids ? source_ids[k] : 0].n + scan_src - 1) / scan_src;
   float max_d2 = std::numeric_limits<float>::infinity();
   if (max_corr > 0.0f) max_d2 = max_corr * max_corr;  // float32 product, as the oracle
-  const uint64_t blocks_goal = plan.xfilter && plan.xkind == 3 ? c->target_blocks_mfma : c->target_blocks;
+  // matrix-core scan: launches below ~5e10 pairs (a request's candidates against one scene) do better with a quarter of the
+  // workgroups, each walking more tiles - fewer key rows for the resolve to merge, less prologue per pair (6 x 20k<->100k,
+  // reference mode: 2.39 -> 2.31 ms per request; 1M<->1M is 0.6 % FASTER with the full count: profiles/r03c_target_blocks.txt)
+  const uint64_t mfma_goal = c->target_blocks_mfma_forced || total_pairs >= 5e10 ? c->target_blocks_mfma : std::max<uint32_t>(c->target_blocks_mfma / 4, 1);
+  const uint64_t blocks_goal = plan.xfilter && plan.xkind == 3 ? mfma_goal : c->target_blocks;
   const uint32_t want_split = static_cast<uint32_t>(
       std::max<uint64_t>(1, (blocks_goal + std::max<uint64_t>(total_src_blocks, 1) - 1) / std::max<uint64_t>(total_src_blocks, 1)));
   uint64_t out_off = 0, partial_off = 0;
@@ -1354,6 +1359,8 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   c->xbf16_shape = static_cast<int>(env_u32("MI355_ICP_XBF16_SHAPE", static_cast<uint32_t>(c->xbf16_shape)));
   c->target_blocks = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks);
   c->target_blocks_mfma = env_u32("MI355_ICP_TARGET_BLOCKS", c->target_blocks_mfma);  // the same override serves A/B runs of either
+  c->target_blocks_mfma = env_u32("MI355_ICP_TARGET_BLOCKS_MFMA", c->target_blocks_mfma);  // ... or of the matrix-core scan alone
+  c->target_blocks_mfma_forced = std::getenv("MI355_ICP_TARGET_BLOCKS") || std::getenv("MI355_ICP_TARGET_BLOCKS_MFMA");  // then for every size
   c->min_tiles_per_split = env_u32("MI355_ICP_MIN_TILES_PER_SPLIT", c->min_tiles_per_split);
   {
     const char* ss = std::getenv("MI355_ICP_SORT_SOURCES");
