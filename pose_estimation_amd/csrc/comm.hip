@@ -32,11 +32,6 @@ __global__ void rank_order_sum_kernel(const double* __restrict__ gathered, int n
 // Up to 8 job descriptors travel as KERNEL ARGUMENTS (the packet's kernarg segment) and one wave writes them to the device
 // tables: one launch instead of a host-to-device copy per table per pass - a copy is a blit kernel plus its ordering on the
 // stream, several microseconds each, which is what a pass on a coarse pyramid level costs in total.
-struct StageArgs {
-  uint32_t n, has_ref, first, pad_;
-  JobDesc jobs[8];
-  RefJobDesc rjobs[8];
-};
 __global__ void stage_jobs_kernel(StageArgs a, JobDesc* __restrict__ jobs, RefJobDesc* __restrict__ rjobs) {
   constexpr uint32_t kJ = sizeof(JobDesc) / 4, kR = sizeof(RefJobDesc) / 4;
   const uint32_t* src = reinterpret_cast<const uint32_t*>(a.jobs);
@@ -159,6 +154,17 @@ void comm_release(CommState& cs) {
   if (cs.stage_send) (void)hipHostFree(cs.stage_send);
   if (cs.stage_recv) (void)hipHostFree(cs.stage_recv);
   cs = CommState{};
+}
+
+// the same descriptors as one StageArgs value, for a launch that stages them itself (launch_nn_scan); false: too many
+bool fill_stage_args(const JobDesc* jobs_host, const RefJobDesc* rjobs_host, int n, StageArgs* out) {
+  if (n < 1 || n > 8) return false;
+  *out = StageArgs{};
+  out->n = static_cast<uint32_t>(n);
+  out->has_ref = rjobs_host ? 1u : 0u;
+  std::memcpy(out->jobs, jobs_host, static_cast<size_t>(n) * sizeof(JobDesc));
+  if (rjobs_host) std::memcpy(out->rjobs, rjobs_host, static_cast<size_t>(n) * sizeof(RefJobDesc));
+  return true;
 }
 
 int stage_jobs(void* stream, const JobDesc* jobs_host, const RefJobDesc* rjobs_host, int n, JobDesc* jobs_dev, RefJobDesc* rjobs_dev) {

@@ -922,7 +922,10 @@ int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, boo
 
 int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only, bool defer, bool* retry, bool tail_allowed) {
   *retry = false;
-  if (stage_jobs(c->stream, c->jobs_host, nullptr, n_active, c->jobs_dev, nullptr) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
+  // the all-exact scan of a small pass stages the descriptors itself (one dependent launch less)
+  StageArgs staged;
+  const bool self_staged = !plan.fused && !plan.pruned && !c->scan_sgpr && fill_stage_args(c->jobs_host, nullptr, n_active, &staged);
+  if (!self_staged && stage_jobs(c->stream, c->jobs_host, nullptr, n_active, c->jobs_dev, nullptr) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
   uint32_t bx = 0, sbx = 0;
   double pairs = 0.0;
   for (int k = 0; k < n_active; ++k) {
@@ -968,7 +971,9 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
   } else {
     if (plan.merged_keys && plan.out_total) HIP_TRY(c, hipMemsetAsync(c->keys, 0xFF, static_cast<size_t>(plan.out_total) * sizeof(unsigned long long), c->stream));
     c->keys_clean = 0;
-    if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
+    if (self_staged && !bx && stage_jobs(c->stream, c->jobs_host, nullptr, n_active, c->jobs_dev, nullptr) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
+    if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total,
+                           self_staged ? &staged : nullptr, c->jobs_dev, nullptr);
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
     if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, c->partials, c->error_flag, tail);
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
@@ -1178,7 +1183,11 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
   }
   c->owner_epoch += 1;
   for (int k = 0; k < n_active; ++k) c->rjobs_host[k].owner_prefix = 63u - c->owner_epoch;
-  if (stage_jobs(c->stream, c->jobs_host, c->rjobs_host, n_active, c->jobs_dev, c->rjobs_dev) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
+  // the all-exact scan of a coarse level stages the descriptors itself (one dependent launch less)
+  StageArgs staged;
+  bool self_staged = !plan.fused && !plan.pruned && !c->scan_sgpr && fill_stage_args(c->jobs_host, c->rjobs_host, n_active, &staged);
+  for (int k = 0; k < n_active && self_staged; ++k) self_staged = c->jobs_host[k].scan_blocks * c->jobs_host[k].n_split > 0;  // the scan must launch
+  if (!self_staged && stage_jobs(c->stream, c->jobs_host, c->rjobs_host, n_active, c->jobs_dev, c->rjobs_dev) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
   uint32_t bx = 0, sbx = 0;
   double pairs = 0.0;
   for (int k = 0; k < n_active; ++k) {
@@ -1209,7 +1218,8 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
       c->keys_clean = plan.out_total;
     }
     if (!plan.merged_keys) c->keys_clean = 0;
-    if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total);
+    if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total,
+                           self_staged ? &staged : nullptr, c->jobs_dev, c->rjobs_dev);
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
     if (sbx) launch_resolve(c->stream, c->jobs_dev, n_active, sbx, S, T, c->keys, plan.out_total, c->out_index, c->out_dist2, nullptr, c->error_flag);
     else if (bx) c->keys_clean = 0;

@@ -227,6 +227,16 @@ struct RefJobDesc {
 };
 static_assert(sizeof(RefJobDesc) == 80, "RefJobDesc layout");
 
+// Up to 8 job descriptors as KERNEL ARGUMENTS (the packet's kernarg segment): what stage_jobs_kernel writes to the device
+// tables, and what the all-exact scan of a small pass reads its own descriptor from directly (n = 0: not staged) while its
+// first workgroup writes the tables for the launches behind it - one dependent launch less per pass.
+struct StageArgs {
+  uint32_t n, has_ref, first, pad_;
+  JobDesc jobs[8];
+  RefJobDesc rjobs[8];
+};
+
+
 // "Picky" owner key of an accepted pair: atomicMin over these makes the smallest distance win, the lowest source index on
 // ties.  The 6-bit prefix is the pass's tag, DEcreasing from pass to pass, so a key of this pass beats whatever an earlier
 // pass (or another job or level that used the slot) left behind and the table needs no clearing between passes - only at
@@ -284,8 +294,11 @@ struct DevicePlanes {
   const float* y;
   const float* z;
 };
+// staged != nullptr (<= 8 jobs): the descriptors travel as this launch's kernel arguments and its first workgroup writes them
+// to jobs_out / rjobs_out for the launches behind it (no stage_jobs_kernel in front)
 void launch_nn_scan(void* stream, int points_per_lane, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x,
-                    DevicePlanes src, DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride);
+                    DevicePlanes src, DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride,
+                    const StageArgs* staged = nullptr, JobDesc* jobs_out = nullptr, RefJobDesc* rjobs_out = nullptr);
 void launch_nn_scan_fused(void* stream, int points_per_lane, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x,
                           DevicePlanes src, DevicePlanes tgt, unsigned long long* keys3, uint32_t key_stride,
                           uint32_t rank_stride);
@@ -415,5 +428,7 @@ int comm_allgather_host(CommState& cs, const void* send, void* recv, size_t byte
 void comm_release(CommState& cs);  // frees the staging buffers and destroys a native communicator
 // this pass's job descriptors (and reference-mode descriptors, or nullptr) to the device tables, asynchronously on `stream`
 int stage_jobs(void* stream, const JobDesc* jobs_host, const RefJobDesc* rjobs_host, int n, JobDesc* jobs_dev, RefJobDesc* rjobs_dev);
+// the same descriptors as one StageArgs value, for a launch that stages them itself (launch_nn_scan); false: more than 8 jobs
+bool fill_stage_args(const JobDesc* jobs_host, const RefJobDesc* rjobs_host, int n, StageArgs* out);
 
 }  // namespace mi355

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
                                                                  const float* __restrict__ ty,
                                                                  const float* __restrict__ tz,
                                                                  unsigned long long* __restrict__ keys,
-                                                                 uint32_t key_stride) {
+                                                                 uint32_t key_stride, StageArgs staged,
+                                                                 JobDesc* __restrict__ jobs_out, RefJobDesc* __restrict__ rjobs_out) {
   // [buffer][plane][tile/4] float4: 2 x 12 KiB
   __shared__ float4 lds[2][3][kTile / 4];
 
@@ -90,7 +91,21 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
   const unsigned long long diag_t0 = wall_clock64();
   const unsigned long long diag_c0 = clock64();
 #endif
-  const JobDesc& J = jobs[blockIdx.y];
+  // staged.n != 0: this launch IS the staging (stage_jobs_kernel's job, one dependent launch less per small pass): every
+  // workgroup takes its descriptor from the kernel arguments, the first one also writes the device tables for the
+  // launches behind this one
+  if (staged.n && blockIdx.x == 0 && blockIdx.y == 0) {
+    constexpr uint32_t kJ = sizeof(JobDesc) / 4, kR = sizeof(RefJobDesc) / 4;
+    const uint32_t* src_w = reinterpret_cast<const uint32_t*>(staged.jobs);
+    uint32_t* dst_w = reinterpret_cast<uint32_t*>(jobs_out);
+    for (uint32_t w = threadIdx.x; w < staged.n * kJ; w += kBlockThreads) dst_w[w] = src_w[w];
+    if (staged.has_ref) {
+      const uint32_t* rs = reinterpret_cast<const uint32_t*>(staged.rjobs);
+      uint32_t* rd = reinterpret_cast<uint32_t*>(rjobs_out);
+      for (uint32_t w = threadIdx.x; w < staged.n * kR; w += kBlockThreads) rd[w] = rs[w];
+    }
+  }
+  const JobDesc J = staged.n ? staged.jobs[blockIdx.y] : jobs[blockIdx.y];
   const uint32_t n_split = J.n_split;
   const uint32_t sb = blockIdx.x / n_split;
   const uint32_t sp = blockIdx.x - sb * n_split;
@@ -1240,9 +1255,12 @@ __global__ __launch_bounds__(kBlockThreads) void final_reduce_kernel(const JobDe
 
 // ---------------------------------------------------------------------------------------------
 void launch_nn_scan(void* stream, int points_per_lane, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x,
-                    DevicePlanes src, DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride) {
+                    DevicePlanes src, DevicePlanes tgt, unsigned long long* keys, uint32_t key_stride, const StageArgs* staged,
+                    JobDesc* jobs_out, RefJobDesc* rjobs_out) {
   dim3 grid(max_blocks_x, static_cast<uint32_t>(n_jobs));
   hipStream_t st = static_cast<hipStream_t>(stream);
+  static const StageArgs not_staged{};  // n = 0
+  const StageArgs& sa = staged ? *staged : not_staged;
   if (points_per_lane >= 100) {  // experimental scalar-load variant: 100 + P
     if (points_per_lane == 108)
       hipLaunchKernelGGL(nn_scan_sgpr_kernel<8>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tgt.x,
@@ -1258,15 +1276,15 @@ void launch_nn_scan(void* stream, int points_per_lane, const JobDesc* jobs_dev, 
   switch (points_per_lane) {
     case 2:
       hipLaunchKernelGGL(nn_scan_kernel<2>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tgt.x,
-                         tgt.y, tgt.z, keys, key_stride);
+                         tgt.y, tgt.z, keys, key_stride, sa, jobs_out, rjobs_out);
       break;
     case 8:
       hipLaunchKernelGGL(nn_scan_kernel<8>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tgt.x,
-                         tgt.y, tgt.z, keys, key_stride);
+                         tgt.y, tgt.z, keys, key_stride, sa, jobs_out, rjobs_out);
       break;
     default:
       hipLaunchKernelGGL(nn_scan_kernel<4>, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, tgt.x,
-                         tgt.y, tgt.z, keys, key_stride);
+                         tgt.y, tgt.z, keys, key_stride, sa, jobs_out, rjobs_out);
       break;
   }
 }
