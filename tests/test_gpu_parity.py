@@ -464,3 +464,23 @@ def test_rccl_single_rank_communicator(engine):
     finally:
         engine.comm_detach()
     assert np.array_equal(got.poses, ref.poses) and np.array_equal(got.residual, ref.residual)
+
+
+def test_more_jobs_than_publish_words(engine):
+    """1100 tiny alignment jobs in one batched call: more than the 1024 jobs that can publish their own result word when the
+    accumulation launch ends a pass, and more than the 32 whose descriptors travel as kernel arguments - the pass takes the
+    copy + synchronisation path and plain descriptor copies.  A sample of the jobs against the oracle."""
+    import pose_estimation_amd as pa
+    n_jobs = 1100
+    pairs = [st.make_pair(st.synth_cloud_np, 120 + k, 150 + 2 * k, object_index=k) for k in range(4)]
+    engine.set_targets([p[1] for p in pairs])
+    engine.set_sources([p[0] for p in pairs])
+    sid = [k % 4 for k in range(n_jobs)]
+    inits = np.stack([st.rigid_transform(0.02 * (k % 50), (1, 0.5, -0.2), (0.001 * (k % 7), 0, -0.001 * (k % 3))) for k in range(n_jobs)])
+    params = pa.default_params(max_iterations=6, relative_mse_epsilon=1e-7)
+    res = engine.align(inits, params, source_ids=sid, target_ids=sid)
+    assert (res.status == 0).all()
+    for k in (0, 1, 7, 333, 1023, 1024, 1099):
+        o = ora.icp(pairs[sid[k]][0], pairs[sid[k]][1], inits[k], ora.params_from(params))
+        assert res.iterations[k] == o["iterations"] and res.converged[k] == o["converged"], k
+        assert np.linalg.norm(res.poses[k] - o["pose"]) <= POSE_TOL, k

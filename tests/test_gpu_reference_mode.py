@@ -153,3 +153,18 @@ def test_sharded_code_path_with_one_rank_is_bit_identical(engine):
     assert 2 * 2048 * 4 in sizes and 2 * 30 * 8 in sizes    # two jobs: histograms, and 29 sums + the flag each
     again = engine.align_reference(init, 120, 0.005, 2.5, 7, source_ids=[0, 0], target_ids=[0, 0])   # and back to unsharded
     assert np.array_equal(again.poses, ref.poses)
+
+
+def test_more_candidates_than_one_staging_launch_holds(engine):
+    """13 candidate poses of one model: more than the 8 job descriptors that travel as kernel arguments of one launch (the
+    all-exact scan stages them itself only up to 8; beyond, stage_jobs_kernel runs in chunks), with candidates that leave
+    the active set at different passes.  Every candidate against the oracle."""
+    src, tgt, gt = pair6(4000, 3500, 0)
+    engine.set_targets([tgt])
+    engine.set_sources([src])
+    inits = [np.eye(4)] + [st.rigid_transform(0.5 * a, (0.2, 1, -0.4), (0.004 * a, -0.003 * a, 0.002 * a)) @ gt for a in range(1, 13)]
+    res = engine.align_reference(np.stack(inits), 40, 0.005, 2.5, 4)
+    for k in range(len(inits)):
+        o = ora.icp_reference(src, tgt, inits[k], 40, 0.005, 2.5, 4)
+        assert res.passes[k] == o["passes"], k
+        assert np.linalg.norm(res.poses[k] - o["pose"]) <= POSE_TOL, k
