@@ -168,3 +168,51 @@ def test_more_candidates_than_one_staging_launch_holds(engine):
         o = ora.icp_reference(src, tgt, inits[k], 40, 0.005, 2.5, 4)
         assert res.passes[k] == o["passes"], k
         assert np.linalg.norm(res.poses[k] - o["pose"]) <= POSE_TOL, k
+
+
+def _engine_with_env(name, value):
+    import os
+    import pose_estimation_amd as pa
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        return pa.IcpEngine(0)
+    finally:
+        if old is None:
+            os.environ.pop(name)
+        else:
+            os.environ[name] = old
+
+
+def test_pass_ending_launch_gives_the_separate_reduce_kernels_bits_every_time(engine):
+    """The accumulation launch that ends a pass by itself (finish_pass: last workgroup of a job adds the partial rows up,
+    handed over through agent-scope atomics, and writes the host's result block) must return exactly what the separate
+    final-reduce kernel + copy return (MI355_ICP_PASS_TAIL=0) - poses, residuals, pass counts, bit for bit - and the same
+    on every one of 150 repetitions (a row read before it had arrived would show up as a changed low bit sooner or later).
+    Both control loops: reference mode (6 candidates, multi-workgroup jobs on the fine levels, single-workgroup ones on the
+    coarse levels) and the point-to-point loop (5 jobs of different sizes)."""
+    import pose_estimation_amd as pa
+    src, tgt, gt = pair6(9000, 12000, 0)
+    inits = np.stack([np.eye(4)] + [st.rigid_transform(a, (0.2, 1, -0.4), (0.01, -0.02, 0.015)) @ gt for a in (1.0, 2.0, 3.0, 4.0, 5.0)])
+    pairs = [st.make_pair(st.synth_cloud_np, 700 + 911 * k, 900 + 1257 * k, object_index=k) for k in range(5)]
+    params = pa.default_params(max_iterations=8)
+    with _engine_with_env("MI355_ICP_PASS_TAIL", "0") as plain:
+        plain.set_targets([tgt])
+        plain.set_sources([src])
+        want = plain.align_reference(inits, 250, 0.005, 2.5, 8)
+        plain.set_targets([p[1] for p in pairs])
+        plain.set_sources([p[0] for p in pairs])
+        want_p2p = plain.align(np.stack([np.eye(4)] * 5), params, source_ids=list(range(5)), target_ids=list(range(5)))
+    engine.set_targets([tgt])
+    engine.set_sources([src])
+    for rep in range(150):
+        got = engine.align_reference(inits, 250, 0.005, 2.5, 8)
+        assert np.array_equal(got.passes, want.passes), rep
+        assert np.array_equal(got.poses.view(np.uint64), want.poses.view(np.uint64)), rep
+        assert np.array_equal(np.asarray(got.residual).view(np.uint64), np.asarray(want.residual).view(np.uint64)), rep
+    engine.set_targets([p[1] for p in pairs])
+    engine.set_sources([p[0] for p in pairs])
+    for rep in range(150):
+        got = engine.align(np.stack([np.eye(4)] * 5), params, source_ids=list(range(5)), target_ids=list(range(5)))
+        assert np.array_equal(got.iterations, want_p2p.iterations), rep
+        assert np.array_equal(got.poses.view(np.uint64), want_p2p.poses.view(np.uint64)), rep
