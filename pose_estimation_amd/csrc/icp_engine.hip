@@ -301,6 +301,28 @@ int sync_pass(mi355_icp_ctx* c) {
 
 // The same for a pass whose last workgroup publishes `seq` in pinned memory behind its results (PassTail): no copy command
 // to wait for, the word is there as soon as the rows are.
+uint32_t overflow_cap(const mi355_icp_ctx* c, int n_active);
+
+// The PassTail of the next pass, if its accumulation launch may end it (single GPU; every job has a workgroup to be its
+// last one; no more jobs than publish words); done / sums: the loop's own counter array and mapped result block.
+PassTail make_pass_tail(mi355_icp_ctx* c, const Plan& plan, int n_active, uint32_t sbx, bool allowed, bool defer, uint32_t* done, double* sums) {
+  bool on = allowed && c->pass_tail && sbx > 0 && static_cast<size_t>(n_active) <= kReadyWords;
+  for (int k = 0; k < n_active; ++k) on = on && c->jobs_host[k].src_blocks > 0;
+  PassTail tail;
+  if (on) {
+    tail.done = done;
+    tail.sums = sums;
+    tail.overflow_count = plan.fused ? c->overflow_count : nullptr;
+    tail.overflow_cap = defer ? overflow_cap(c, n_active) : 0xFFFFFFFFu;
+    c->pass_seq = (c->pass_seq + 1) & 0x7FFFFFFFu;
+    tail.seq = c->pass_seq;
+    tail.ready = c->ready_mapped;
+    tail.error_flag = c->error_flag;
+  }
+  c->error_word_known = false;
+  return tail;
+}
+
 // Every job publishes (seq << 1 | error bit) in its own word.
 int wait_pass(mi355_icp_ctx* c, uint32_t seq, int n_jobs, uint32_t* error_bit) {
   const auto t0 = std::chrono::steady_clock::now();
@@ -940,22 +962,10 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
   if (plan.out_total > c->out_cap || static_cast<size_t>(plan.partial_total) * MI355_ICP_NSUMS > c->partials_cap ||
       (plan.pruned ? false : plan.fused ? (plan.key_ranks() * key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : key_need > c->keys_cap))
     return fail(c, MI355_ICP_ERR_INTERNAL, "work buffers are smaller than the plan (ensure_buffers not run for this plan)");
-  // single GPU, align loop: the accumulation launch ends the pass by itself (PassTail) - every job has a workgroup to be its last one
+  // single GPU, align loop: the accumulation launch ends the pass by itself (PassTail)
   const bool exchange = c->comm.attached() && !local_only;
-  bool tail_on = tail_allowed && c->pass_tail && !exchange && sbx > 0 && static_cast<size_t>(n_active) <= kReadyWords;
-  for (int k = 0; k < n_active; ++k) tail_on = tail_on && c->jobs_host[k].src_blocks > 0;
-  PassTail tail;
-  if (tail_on) {
-    tail.done = c->p2p_done;
-    tail.sums = c->sums_mapped;
-    tail.overflow_count = plan.fused ? c->overflow_count : nullptr;
-    tail.overflow_cap = defer ? overflow_cap(c, n_active) : 0xFFFFFFFFu;
-    c->pass_seq = (c->pass_seq + 1) & 0x7FFFFFFFu;
-    tail.seq = c->pass_seq;
-    tail.ready = c->ready_mapped;
-    tail.error_flag = c->error_flag;
-  }
-  c->error_word_known = false;
+  const PassTail tail = make_pass_tail(c, plan, n_active, sbx, tail_allowed && !exchange, defer, c->p2p_done, c->sums_mapped);
+  const bool tail_on = tail.done != nullptr;
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (plan.pruned) {
     const int fst = run_pruned_index_phase(c, n_active, sbx, S, T);
@@ -1247,21 +1257,9 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
     for (int k = 0; k < n_active; ++k) c->thr_host[k] = std::numeric_limits<float>::infinity();
     HIP_TRY(c, hipMemcpyAsync(c->thr_dev, c->thr_host, static_cast<size_t>(n_active) * sizeof(float), hipMemcpyHostToDevice, c->stream));
   }
-  // single GPU: the accumulate launch ends the pass by itself (PassTail) - every job has a workgroup to be its last one
-  bool tail_on = c->pass_tail && !sharded && sbx > 0 && static_cast<size_t>(n_active) <= kReadyWords;
-  for (int k = 0; k < n_active; ++k) tail_on = tail_on && c->jobs_host[k].src_blocks > 0;
-  PassTail tail;
-  if (tail_on) {
-    tail.done = c->pass_done;
-    tail.sums = c->ref_sums_mapped;
-    tail.overflow_count = plan.fused ? c->overflow_count : nullptr;
-    tail.overflow_cap = defer ? overflow_cap(c, n_active) : 0xFFFFFFFFu;
-    c->pass_seq = (c->pass_seq + 1) & 0x7FFFFFFFu;
-    tail.seq = c->pass_seq;
-    tail.ready = c->ready_mapped;
-    tail.error_flag = c->error_flag;
-  }
-  c->error_word_known = false;
+  // single GPU: the accumulate launch ends the pass by itself (PassTail)
+  const PassTail tail = make_pass_tail(c, plan, n_active, sbx, !sharded, defer, c->pass_done, c->ref_sums_mapped);
+  const bool tail_on = tail.done != nullptr;
   if (sbx || sharded) {
     if (sbx && !scattered) launch_picky_scatter(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, c->out_index, c->out_dist2, c->thr_dev, c->owner);
     if (sharded) {  // targets are replicated: the owner of a target is the smallest key any rank offered
