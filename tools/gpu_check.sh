@@ -21,6 +21,10 @@ MI355_ICP_SCAN_MODE=xfilter step 900 pytest_gpu_xfilter.txt python -m pytest tes
 MI355_ICP_SCAN_MODE=xbf16 step 900 pytest_gpu_xbf16.txt python -m pytest tests -m gpu -x -q
 MI355_ICP_SCAN_MODE=exact step 900 pytest_gpu_exact.txt python -m pytest tests -m gpu -x -q
 MI355_ICP_SCAN_MODE=pruned step 900 pytest_gpu_pruned.txt python -m pytest tests -m gpu -x -q
+# the A/B switches of the request path: exhaustive k-NN (the committed scene then has no sorted copy to inherit), and the
+# pre-round-2 structure of a reference pass (separate reduce + copy, a sort per pyramid level, scalar solves)
+MI355_ICP_KNN_MODE=brute step 600 pytest_gpu_knn_brute.txt python -m pytest tests/test_gpu_normals.py tests/test_gpu_opencv_adapter.py tests/test_gpu_scene_filters.py tests/test_gpu_plane_fit.py -m gpu -x -q
+MI355_ICP_LEVEL_SORT=1 MI355_ICP_PASS_TAIL=0 MI355_ICP_SOLVE_ISA=scalar step 600 pytest_gpu_plain_passes.txt python -m pytest tests/test_gpu_reference_mode.py tests/test_gpu_normals.py tests/test_gpu_parity.py -m gpu -x -q
 step 300 smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
 step 400 bench.txt python bench.py --steps "${STEPS:-3}" --warmup 1
-tail -3 gpurun_out/pytest_gpu.txt; tail -2 gpurun_out/pytest_gpu_fused.txt; tail -2 gpurun_out/pytest_gpu_xfilter.txt; tail -2 gpurun_out/pytest_gpu_xbf16.txt; tail -2 gpurun_out/pytest_gpu_exact.txt; tail -2 gpurun_out/pytest_gpu_pruned.txt; tail -2 gpurun_out/smoke.txt; tail -1 gpurun_out/bench.txt
+tail -3 gpurun_out/pytest_gpu.txt; tail -2 gpurun_out/pytest_gpu_fused.txt; tail -2 gpurun_out/pytest_gpu_xfilter.txt; tail -2 gpurun_out/pytest_gpu_xbf16.txt; tail -2 gpurun_out/pytest_gpu_exact.txt; tail -2 gpurun_out/pytest_gpu_pruned.txt; tail -2 gpurun_out/pytest_gpu_knn_brute.txt; tail -2 gpurun_out/pytest_gpu_plain_passes.txt; tail -2 gpurun_out/smoke.txt; tail -1 gpurun_out/bench.txt
