@@ -815,8 +815,10 @@ uint32_t overflow_cap(const mi355_icp_ctx* c, int n_active) {
 // `defer`: the points the resolve could not settle are answered on the device (overflow_exact_kernel, up to kOverflowCap
 // per job) and the counts are only copied back, to be looked at after the pass's final synchronisation
 // (overflow_settled); otherwise the host reads the counts here and runs the gathered all-exact scan for them.
+// staged != nullptr: the caller has NOT staged the job descriptors; the matrix-core scan does it itself (its kernel arguments),
+// any other scan of this phase gets them from stage_jobs_kernel first.
 int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint32_t bx, uint32_t sbx, DevicePlanes S,
-                          DevicePlanes T, bool profile, bool defer) {
+                          DevicePlanes T, bool profile, bool defer, const StageArgs* staged = nullptr) {
   const uint32_t rank_stride = plan.key_rows() * plan.out_total;
   // the expansion-filter copy that was built from exactly these target planes (level 0 or a pyramid level), if any
   const XCopy* Xp = nullptr;
@@ -838,12 +840,17 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
     Sscan = DevicePlanes{xs->planes + 4 * sstride, xs->planes + 5 * sstride, xs->planes + 6 * sstride};
     src_perm = xs->perm;
   }
+  const bool self_staged = staged && xf && bx && plan.xkind == 3 && c->xbf16_shape != 1;
+  if (staged && !self_staged &&
+      stage_jobs(c->stream, c->jobs_host, staged->has_ref ? c->rjobs_host : nullptr, n_active, c->jobs_dev, staged->has_ref ? c->rjobs_dev : nullptr) != MI355_ICP_OK)
+    return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
   if (xf) {
     const float* xp = X.planes;
     const size_t st = xstride;
     const int ppl = plan.scan_ppl == 2 ? 2 : 4;  // the MFMA kernel spans 128 * {4, 8} points per workgroup
     if (bx && plan.xkind == 3) {
-      launch_nn_scan_xbf16(c->stream, c->jobs_dev, n_active, bx, Sscan, X.bf, X.bf_table, c->keys3, plan.out_total, rank_stride, c->xbf16_shape);
+      launch_nn_scan_xbf16(c->stream, c->jobs_dev, n_active, bx, Sscan, X.bf, X.bf_table, c->keys3, plan.out_total, rank_stride, c->xbf16_shape,
+                           self_staged ? staged : nullptr, c->jobs_dev, staged && staged->has_ref ? c->rjobs_dev : nullptr);
     } else if (bx && plan.xkind == 0) {
       launch_nn_scan_xfilter(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, xp, xp + st, xp + 2 * st, xp + 3 * st,
                              X.table, c->keys3, plan.out_total, rank_stride);
@@ -945,17 +952,24 @@ int run_pass(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, boo
 int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile, bool local_only, bool defer, bool* retry, bool tail_allowed) {
   *retry = false;
   // the all-exact scan of a small pass stages the descriptors itself (one dependent launch less)
-  StageArgs staged;
-  const bool self_staged = !plan.fused && !plan.pruned && !c->scan_sgpr && fill_stage_args(c->jobs_host, nullptr, n_active, &staged);
-  if (!self_staged && stage_jobs(c->stream, c->jobs_host, nullptr, n_active, c->jobs_dev, nullptr) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
   uint32_t bx = 0, sbx = 0;
   double pairs = 0.0;
+  bool all_scan = true;
   for (int k = 0; k < n_active; ++k) {
     const JobDesc& J = c->jobs_host[k];
     bx = std::max(bx, J.scan_blocks * J.n_split);
     sbx = std::max(sbx, J.src_blocks);
     pairs += static_cast<double>(J.src_n) * static_cast<double>(J.tgt_n);
+    all_scan = all_scan && J.scan_blocks * J.n_split > 0;
   }
+  // small passes: the scan launch takes the descriptors as its kernel arguments and writes the device tables itself - the
+  // all-exact scan always, the matrix-core scan below 5e10 pairs (above, a launch in front costs nothing that shows, and
+  // the benchmark's kernel stays the instantiation it was measured as)
+  StageArgs staged;
+  const bool exact_path = !plan.fused && !plan.pruned && !c->scan_sgpr;
+  const bool mfma_path = plan.fused && plan.xfilter && plan.xkind == 3 && !plan.pruned && pairs < 5e10;
+  const bool self_staged = (exact_path || mfma_path) && all_scan && fill_stage_args(c->jobs_host, nullptr, n_active, &staged);
+  if (!self_staged && stage_jobs(c->stream, c->jobs_host, nullptr, n_active, c->jobs_dev, nullptr) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
   const DevicePlanes S = c->sources.view(), T = c->targets.view();
   // never launch against a buffer the planner did not size for this launch shape (an out-of-bounds kernel can take the GPU down)
   const size_t key_need = static_cast<size_t>(plan.fused ? plan.key_rows() : plan.max_split) * plan.out_total;
@@ -974,14 +988,13 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if (sbx) launch_accumulate(c->stream, c->jobs_dev, n_active, sbx, S, T, c->out_index, c->out_dist2, c->partials, tail);
   } else if (plan.fused) {
-    const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile, defer);
+    const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile, defer, self_staged ? &staged : nullptr);
     if (fst != MI355_ICP_OK) return fst;
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if (sbx) launch_accumulate(c->stream, c->jobs_dev, n_active, sbx, S, T, c->out_index, c->out_dist2, c->partials, tail);
   } else {
     if (plan.merged_keys && plan.out_total) HIP_TRY(c, hipMemsetAsync(c->keys, 0xFF, static_cast<size_t>(plan.out_total) * sizeof(unsigned long long), c->stream));
     c->keys_clean = 0;
-    if (self_staged && !bx && stage_jobs(c->stream, c->jobs_host, nullptr, n_active, c->jobs_dev, nullptr) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
     if (bx) launch_nn_scan(c->stream, plan.scan_ppl + (c->scan_sgpr ? 100 : 0), c->jobs_dev, n_active, bx, S, T, c->keys, plan.out_total,
                            self_staged ? &staged : nullptr, c->jobs_dev, nullptr);
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
@@ -1193,19 +1206,22 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
   }
   c->owner_epoch += 1;
   for (int k = 0; k < n_active; ++k) c->rjobs_host[k].owner_prefix = 63u - c->owner_epoch;
-  // the all-exact scan of a coarse level stages the descriptors itself (one dependent launch less)
-  StageArgs staged;
-  bool self_staged = !plan.fused && !plan.pruned && !c->scan_sgpr && fill_stage_args(c->jobs_host, c->rjobs_host, n_active, &staged);
-  for (int k = 0; k < n_active && self_staged; ++k) self_staged = c->jobs_host[k].scan_blocks * c->jobs_host[k].n_split > 0;  // the scan must launch
-  if (!self_staged && stage_jobs(c->stream, c->jobs_host, c->rjobs_host, n_active, c->jobs_dev, c->rjobs_dev) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
   uint32_t bx = 0, sbx = 0;
   double pairs = 0.0;
+  bool all_scan = true;
   for (int k = 0; k < n_active; ++k) {
     const JobDesc& J = c->jobs_host[k];
     bx = std::max(bx, J.scan_blocks * J.n_split);
     sbx = std::max(sbx, J.src_blocks);
     pairs += static_cast<double>(J.src_n) * static_cast<double>(J.tgt_n);
+    all_scan = all_scan && J.scan_blocks * J.n_split > 0;  // the scan must launch for every job
   }
+  // small passes: the scan launch stages the descriptors itself (one dependent launch less; see run_pass_once)
+  StageArgs staged;
+  const bool exact_path = !plan.fused && !plan.pruned && !c->scan_sgpr;
+  const bool mfma_path = plan.fused && plan.xfilter && plan.xkind == 3 && !plan.pruned && pairs < 5e10;
+  const bool self_staged = (exact_path || mfma_path) && all_scan && fill_stage_args(c->jobs_host, c->rjobs_host, n_active, &staged);
+  if (!self_staged && stage_jobs(c->stream, c->jobs_host, c->rjobs_host, n_active, c->jobs_dev, c->rjobs_dev) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
   const DevicePlanes S = level_view(c->sources, level), T = level_view(c->targets, level);
   const size_t ref_key_need = static_cast<size_t>(plan.fused ? plan.key_rows() : plan.max_split) * plan.out_total;
   if ((plan.pruned ? false : plan.fused ? (plan.key_ranks() * ref_key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : ref_key_need > c->keys_cap) ||
@@ -1219,7 +1235,7 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
     if (fst != MI355_ICP_OK) return fst;
     if (profile) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
   } else if (plan.fused) {
-    const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile, defer);
+    const int fst = run_fused_index_phase(c, plan, n_active, bx, sbx, S, T, profile, defer, self_staged ? &staged : nullptr);
     if (fst != MI355_ICP_OK) return fst;
   } else {
     // merged key rows come back cleared from the resolve (which runs whenever the scan does): one memset per plan, not per pass

@@ -607,7 +607,9 @@ __device__ __forceinline__ uint32_t min16(const f32x16& acc, uint32_t seed) {
 // at 1M<->1M without it: profiles/r02b_scan_ab_lds_dma.txt).
 // kDump (mi355_icp_debug_filter_bounds only, never the product path): additionally writes the lower bound L of EVERY
 // (point, 128-target run) to dump[run * dump_stride + point position] - what the parity tests check the bound on.
-template <int kSets, int kThreads, bool kDump = false>
+// kStaged: the launch is also the staging of a small pass (<= 8 jobs; see nn_scan_kernel): every workgroup reads its
+// descriptor from the kernel arguments and the first one writes the device tables for the launches behind it.
+template <int kSets, int kThreads, bool kDump = false, bool kStaged = false>
 __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDesc* __restrict__ jobs,
                                                                        const float* __restrict__ sx,
                                                                        const float* __restrict__ sy,
@@ -616,12 +618,27 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
                                                                        const float4* __restrict__ tile_table,
                                                                        unsigned long long* __restrict__ keys4,
                                                                        uint32_t key_stride, uint32_t rank_stride,
-                                                                       float* __restrict__ dump = nullptr, uint32_t dump_stride = 0) {
+                                                                       float* __restrict__ dump = nullptr, uint32_t dump_stride = 0,
+                                                                       StageArgs staged = StageArgs{}, JobDesc* __restrict__ jobs_out = nullptr,
+                                                                       RefJobDesc* __restrict__ rjobs_out = nullptr) {
   // [buffer][k half][row slot]: 2 x 32 KiB, + 96 slots the fragment prefetch of a tile's last two steps runs into
   // (blocks 32-34 do not exist: whatever is read there feeds MFMAs whose results are dropped)
   constexpr uint32_t kLdsPad = 96;
   __shared__ uint4 lds[2 * kXbTileVecs + kLdsPad];
-  const JobDesc& J = jobs[blockIdx.y];
+  if constexpr (kStaged) {
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+      constexpr uint32_t kJ = sizeof(JobDesc) / 4, kR = sizeof(RefJobDesc) / 4;
+      const uint32_t* src_w = reinterpret_cast<const uint32_t*>(staged.jobs);
+      uint32_t* dst_w = reinterpret_cast<uint32_t*>(jobs_out);
+      for (uint32_t w = threadIdx.x; w < staged.n * kJ; w += kThreads) dst_w[w] = src_w[w];
+      if (staged.has_ref) {
+        const uint32_t* rs = reinterpret_cast<const uint32_t*>(staged.rjobs);
+        uint32_t* rd = reinterpret_cast<uint32_t*>(rjobs_out);
+        for (uint32_t w = threadIdx.x; w < staged.n * kR; w += kThreads) rd[w] = rs[w];
+      }
+    }
+  }
+  const JobDesc& J = kStaged ? staged.jobs[blockIdx.y] : jobs[blockIdx.y];
   const uint32_t n_split = J.n_split;
   const uint32_t sb = blockIdx.x / n_split;
   const uint32_t sp = blockIdx.x - sb * n_split;
@@ -800,9 +817,15 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
 // 1 = <2 sets, 512 threads> (1.4 % slower: profiles/r02b_scan_ab_lds_dma.txt)
 void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
                           const void* bf_image, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
-                          uint32_t rank_stride, int shape) {
+                          uint32_t rank_stride, int shape, const StageArgs* staged, JobDesc* jobs_out, RefJobDesc* rjobs_out) {
   if (!max_blocks_x) return;
   dim3 grid(max_blocks_x, static_cast<uint32_t>(n_jobs));
+  if (staged && shape != 1) {  // small passes: this launch stages the descriptors itself
+    hipLaunchKernelGGL((nn_scan_xbf16_kernel<4, 256, false, true>), grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x,
+                       src.y, src.z, static_cast<const uint4*>(bf_image), static_cast<const float4*>(tile_table), keys4, key_stride,
+                       rank_stride, nullptr, 0u, *staged, jobs_out, rjobs_out);
+    return;
+  }
   if (shape == 1)
     hipLaunchKernelGGL((nn_scan_xbf16_kernel<2, 512>), grid, dim3(512), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x, src.y,
                        src.z, static_cast<const uint4*>(bf_image), static_cast<const float4*>(tile_table), keys4, key_stride,

@@ -315,7 +315,8 @@ void launch_nn_scan_xmfma(void* stream, int points_per_lane, const JobDesc* jobs
                           uint32_t rank_stride);
 void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
                           const void* bf_image, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
-                          uint32_t rank_stride, int shape);
+                          uint32_t rank_stride, int shape, const StageArgs* staged = nullptr, JobDesc* jobs_out = nullptr,
+                          RefJobDesc* rjobs_out = nullptr);
 void launch_nn_scan_xbf16_dump(void* stream, const JobDesc* jobs_dev, uint32_t blocks_x, DevicePlanes src, const void* bf_image,
                                const void* tile_table, unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride,
                                float* dump, uint32_t dump_stride);
