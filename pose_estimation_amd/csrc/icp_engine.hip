@@ -599,7 +599,11 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   // (512 source slots, tile) leaves most of the chip idle while each of them works through 1024 x 512 pairs on one
   // CU - ~37 us whatever the cloud holds.  Cut every tile into 2, 4 or 8 runs of chunks, one workgroup each, until the
   // launch has a few thousand of them (6 x 20k<->100k with the reference's parameters: 11 such passes per request).
-  if (!plan.fused && !plan.pruned && !c->scan_sgpr) {
+  // The merged key row is handed back cleared by the resolve, which covers ceil(n / kSrcPerBlock) * kSrcPerBlock slots per
+  // job; the scan merges into ceil(n / scan_src) * scan_src of them.  Only while a scan workgroup spans no more than a
+  // resolve workgroup (2 or 4 points per lane; the A/B knob MI355_ICP_SCAN_PPL=8 spans 2048) is every slot the scan
+  // dirtied also cleared - otherwise padding slots would keep finite keys that a later plan could mistake for a point's.
+  if (!plan.fused && !plan.pruned && !c->scan_sgpr && scan_src <= static_cast<uint32_t>(kSrcPerBlock)) {
     uint64_t wgs = 0;
     for (const JobDesc& J : plan.jobs) wgs += static_cast<uint64_t>(J.scan_blocks) * J.tgt_tiles;
     uint32_t sub = 1;
@@ -1860,6 +1864,10 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
   if ((st = run_ref_pass(c, plan, level, 1, rejection_scale, owner_total, c->profile_always)) != MI355_ICP_OK) return st;
   if (out_sums) std::memcpy(out_sums, c->ref_sums_host, kRefSums * sizeof(double));
   if (out_threshold) *out_threshold = c->thr_host[0];
+  // The pass may have ended itself (PassTail): the host then only saw the published words, and c->stream does not
+  // synchronise with the NULL stream the copies below run on.  The kernel's plain stores (selected, index, dist2) are
+  // ordered before these copies only by the end of the kernel: wait for it.
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (J.src_n) {
     if (out_index) HIP_TRY(c, hipMemcpy(out_index, c->out_index + J.out_off, J.src_n * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (out_dist2) HIP_TRY(c, hipMemcpy(out_dist2, c->out_dist2 + J.out_off, J.src_n * sizeof(float), hipMemcpyDeviceToHost));

@@ -166,10 +166,30 @@ __device__ __forceinline__ double pass_block_sum(double (&v)[NV], double (*scrat
 // publishes for itself (no count of finished jobs), and the caller reads the error word (`raised`) at kernel start.
 //   r: pass_block_sum's result of this workgroup (threads < NV); row / n_rows: this workgroup's partial row of the job
 //   extras(block_behind_the_rows, job, n_jobs): thread 0 only; system-scope atomic stores
+//
+// HARDWARE ASSUMPTIONS (gfx950; nothing in the C++ / HSA memory model orders relaxed accesses, so this is a statement about
+// the ISA the file is compiled to, and the #error below keeps it from being compiled to another one):
+//   1. relaxed agent-scope atomic stores / loads of 8 bytes lower to global_store_dwordx2 / global_load_dwordx2 with sc1:
+//      performed at the memory side of the per-XCD L2s, never served from a CU's L1 (MI355X_MICROARCH.md, "Workgroup
+//      dispatch, XCD placement & inter-workgroup visibility": the {8-B agent atomics both sides} form);
+//   2. stores, loads and atomics of a wave are counted on ONE counter (vmcnt) in issue order, so s_waitcnt 0 returns only
+//      when every row this wave stored has been acknowledged by memory (gfx10+ count stores on vscnt, which the immediate 0
+//      does not wait for: there this would be silently wrong);
+//   3. the hand-over is the first row of that guide's table of measured hand-offs: every storing wave waits (s_waitcnt),
+//      the workgroup meets at a barrier, ONE lane adds to the job's counter, the workgroup whose add returned n_rows - 1
+//      is the reader, its other waves read behind a second barrier, and every read of the handed-over rows is an sc1 load.
+// The rows are stored by threads < NV; the barrier between the wait and the add makes that correct for any NV <= the
+// workgroup size (the waits of ALL waves precede the add), not only while the rows come from wave 0.
+// A/B and escape hatch: MI355_ICP_PASS_TAIL=0 takes the separate reduce launch + copy (tools/gpu_check.sh runs the suite
+// that way too; tests/test_gpu_reference_mode.py compares the two bit for bit, 150 repetitions).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "finish_pass relies on gfx950 memory-counter behaviour (see HARDWARE ASSUMPTIONS): build with --offload-arch=gfx950 only"
+#endif
 template <int NV, typename Extras>
 __device__ __forceinline__ void finish_pass(double r, double (&acc)[NV], double (*scratch)[NV], uint32_t* last_flag /* LDS word */,
                                             double* job_rows, uint32_t row, uint32_t n_rows, const PassTail& tail, uint32_t raised,
                                             Extras extras, bool reread_error = false) {
+  static_assert(NV <= kBlockThreads, "one thread per sum stores a row: NV must not exceed the workgroup size");
   const uint32_t job = blockIdx.y, n_jobs = gridDim.y;
   double total = r;
   if (n_rows > 1) {

@@ -7,6 +7,8 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
+import time
 
 import pytest
 
@@ -24,23 +26,36 @@ def run_world(world):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_ranks_worker.py")], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.PIPE, text=True))
-    outs = []
-    try:
-        for p in procs:
-            outs.append(p.communicate(timeout=300))
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, f"rank {r} failed:\n{err[-3000:]}"
-    assert f"RCCL_RANKS_OK {world}" in outs[0][0], outs[0]
+    # every rank writes to files of its own: a rank that fills a 64 KiB pipe (an RCCL banner, a traceback) while the parent
+    # is waiting on another rank would block until the timeout
+    with tempfile.TemporaryDirectory() as tmp:
+        procs, logs = [], []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY="0")
+            out, err = open(os.path.join(tmp, f"rank{r}.out"), "w+"), open(os.path.join(tmp, f"rank{r}.err"), "w+")
+            logs.append((out, err))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_ranks_worker.py")], env=env, stdout=out, stderr=err))
+        deadline = time.monotonic() + 300
+        try:
+            # a dead rank leaves the others in the rendezvous: end the run as soon as one fails
+            while any(p.poll() is None for p in procs) and time.monotonic() < deadline:
+                if any(p.poll() not in (None, 0) for p in procs):
+                    break
+                time.sleep(0.2)
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+                p.wait()
+        texts = []
+        for out, err in logs:
+            out.seek(0), err.seek(0)
+            texts.append((out.read(), err.read()))
+            out.close(), err.close()
+    for r, (p, (out, err)) in enumerate(zip(procs, texts)):
+        assert p.returncode == 0, f"rank {r} failed (rc {p.returncode}):\n{err[-3000:]}"
+    assert f"RCCL_RANKS_OK {world}" in texts[0][0], texts[0]
 
 
 def test_native_rccl_one_rank():
