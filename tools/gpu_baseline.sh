@@ -8,7 +8,7 @@ mkdir -p "$O"
 step() { local secs=$1 log=$2; shift 2; echo "== $* (limit ${secs}s)" | tee -a "$O/steps.log"; timeout -k 10 "$secs" "$@" > "$O/$log" 2>&1; local rc=$?; echo "rc=$rc $log" | tee -a "$O/steps.log"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $log: stopping" | tee -a "$O/steps.log"; exit 99; fi; return $rc; }
 : > "$O/steps.log"
 cd "$R"
-step 900 pytest_gpu.txt python -m pytest tests -m gpu -x -q || exit 1
+step 900 pytest_gpu.txt python -m pytest tests -m gpu -x -q || echo "PYTEST FAILED" | tee -a "$O/steps.log"
 step 400 bench.txt python bench.py --steps 20 --warmup 5 || exit 1
 step 200 refmode.txt python tools/refmode_latency.py --reps 60 || exit 1
 step 200 harness.txt ./build/estimate_pose_harness 20000 100000 6 pipeline || true
