@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xmfma_kernel(const J
 // at two waves per SIMD, tools/ubench_bf16_min.hip) + ~0.14 slots of bookkeeping.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#ifdef MI355_PIN_OFF
+#if defined(MI355_PIN_OFF) || !defined(__HIP_DEVICE_COMPILE__)  // (the host pass must not see a "v" constraint: there it names an x86 register class)
 #define MI355_PIN(frag, acc, cm) ((void)0)
 #else
 #define MI355_PIN(frag, acc, cm) asm volatile("" : "+v"(frag), "+v"(acc), "+v"(cm))
@@ -621,8 +621,8 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
                                                                        float* __restrict__ dump = nullptr, uint32_t dump_stride = 0,
                                                                        StageArgs staged = StageArgs{}, JobDesc* __restrict__ jobs_out = nullptr,
                                                                        RefJobDesc* __restrict__ rjobs_out = nullptr) {
-  // [buffer][k half][row slot]: 2 x 32 KiB, + 96 slots the fragment prefetch of a tile's last two steps runs into
-  // (blocks 32-34 do not exist: whatever is read there feeds MFMAs whose results are dropped)
+  // [buffer][k half][row slot]: 2 x 32 KiB, + slots the fragment prefetch of a tile's last-but-one step runs into (it reads
+  // blocks 31 and 32; block 32 does not exist and what is read there is never used: the tile's final step issues no MFMA for it)
   constexpr uint32_t kLdsPad = 96;
   __shared__ uint4 lds[2 * kXbTileVecs + kLdsPad];
   if constexpr (kStaged) {
@@ -746,29 +746,35 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
     // MI355_PIN: an empty asm that "rewrites" the next MFMA's operand, the accumulator the next minima read and the
     // previous minimum - so step m (one MFMA + 8 minima) can start only when step m - 1's minima are done, which is
     // the alternation the comment above asks for, expressed as data flow the scheduler cannot undo.
-    auto step = [&](u32x4& use_b, u32x4& use_a, u32x4& next_b, u32x4& next_a) {
-      next_b = load_frag(Ap + 96);   // blocks 2p + 3 and 2p + 4 of step p (past the tile's end on its last two steps: see kLdsPad)
-      next_a = load_frag(Ap + 128);
-      Ap += 64;
+    // kLast: the tile's final step.  Its second half would start block 32, which does not exist (the next tile begins with a
+    // prologue of its own behind the barrier): only the minima of block 31 are left to do, so 4 of a tile's 132 MFMAs and the
+    // fragment reads for blocks 33 / 34 are never issued (27.69 -> 27.0 ms at 1M<->1M together with the placement of the
+    // fragment reads below: profiles/r03h_scan_ab_peel.txt).
+    // The fragment reads of a step sit in its MIDDLE: at its head hipcc waits for them with lgkmcnt(0) - the step's own reads
+    // included, an exposed LDS round trip twice per chunk - while from the middle they are four MFMA groups old when the
+    // next step waits.
+    auto step = [&](auto last_tag, u32x4& use_b, u32x4& use_a, u32x4& next_b, u32x4& next_a) {
+      constexpr bool kLast = decltype(last_tag)::value;
 #pragma unroll
       for (int m = 0; m < kSets; ++m) {
         MI355_PIN(use_b, acc_a[m], cmin[(m + kSets - 1) % kSets]);
         acc_b[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, use_b), __builtin_bit_cast(bf16x8, bq[m]), zero, 0, 0, 0);
         cmin[m] = min16(acc_a[m], cmin[m]);
       }
+      if constexpr (!kLast) {
+        next_b = load_frag(Ap + 96);   // blocks 2p + 3 and 2p + 4 of step p (past the tile's end on step 14: see kLdsPad)
+        next_a = load_frag(Ap + 128);
+        Ap += 64;
+      }
 #pragma unroll
       for (int m = 0; m < kSets; ++m) {
         MI355_PIN(use_a, acc_b[m], cmin[(m + kSets - 1) % kSets]);
-        acc_a[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, use_a), __builtin_bit_cast(bf16x8, bq[m]), zero, 0, 0, 0);
+        if constexpr (!kLast)
+          acc_a[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, use_a), __builtin_bit_cast(bf16x8, bq[m]), zero, 0, 0, 0);
         cmin[m] = min16(acc_b[m], cmin[m]);
       }
     };
-#pragma unroll 1
-    for (uint32_t c = 0; c < kXbChunksPerTile; ++c) {  // a 256-target chunk = 8 blocks = 4 steps
-      step(f0_b, f0_a, f1_b, f1_a);
-      step(f1_b, f1_a, f0_b, f0_a);
-      step(f0_b, f0_a, f1_b, f1_a);
-      step(f1_b, f1_a, f0_b, f0_a);
+    auto finish_chunk = [&](uint32_t c) {
       const uint32_t run = ((tile * kXbChunksPerTile + c) << 1) | (hi ? 1u : 0u);
 #pragma unroll
       for (int m = 0; m < kSets; ++m) {
@@ -797,6 +803,23 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
           rawthr[m] = raw_threshold(l3[m], adj[m], ee[m]);
         }
       }
+    };
+    constexpr std::false_type kMid{};
+    constexpr std::true_type kEnd{};
+#pragma unroll 1
+    for (uint32_t c = 0; c + 1 < kXbChunksPerTile; ++c) {  // a 256-target chunk = 8 blocks = 4 steps
+      step(kMid, f0_b, f0_a, f1_b, f1_a);
+      step(kMid, f1_b, f1_a, f0_b, f0_a);
+      step(kMid, f0_b, f0_a, f1_b, f1_a);
+      step(kMid, f1_b, f1_a, f0_b, f0_a);
+      finish_chunk(c);
+    }
+    {  // the tile's last chunk, peeled for its final step
+      step(kMid, f0_b, f0_a, f1_b, f1_a);
+      step(kMid, f1_b, f1_a, f0_b, f0_a);
+      step(kMid, f0_b, f0_a, f1_b, f1_a);
+      step(kEnd, f1_b, f1_a, f0_b, f0_a);
+      finish_chunk(kXbChunksPerTile - 1);
     }
     __syncthreads();
     cur ^= 1;

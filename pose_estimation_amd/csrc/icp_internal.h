@@ -31,7 +31,10 @@ constexpr int kXbTileVecs = 2 * kTile;                   // uint4 per tile of th
 // instructions per source set each time).  The price is a band E that grows with the group's radius: at 1M<->1M groups
 // of 1 / 2 / 4 tiles scan in 28.35 / 27.86 / 27.15 ms and leave 563 / 1210 / 2636 of 10^6 points to the overflow pass
 // (0.23 -> 0.25 ms of resolve): profiles/r02q_scan_ab_centre_groups.txt.
-constexpr int kXbCentreGroup = 4;
+#ifndef MI355_XB_CENTRE_GROUP
+#define MI355_XB_CENTRE_GROUP 4
+#endif
+constexpr int kXbCentreGroup = MI355_XB_CENTRE_GROUP;
 
 #if defined(__HIPCC__)
 // bfloat16 pieces of a float32 (round to nearest even; NaN stays NaN, +-inf stays +-inf).  x ~ hi + lo with
