@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--cpu-baseline-iters-1thread", type=int, default=3, help="... of its 1-thread leg (about 5 s)")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the short all-exact-scan leg (roofline_exact)")
     ap.add_argument("--exact-leg-steps", type=int, default=3)
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the short legs for the other BASELINE configurations (other_configs)")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--collective", choices=["native", "torch"], default="native",
                     help="N > 1: the per-iteration exchange issued inside the engine over RCCL (native) or by torch.distributed")
@@ -116,6 +117,58 @@ def cpu_baseline(src, tgt, iters, iters_1thread):
                   "O(Ns log Nt) exact tree search, NOT a brute-force scan - compare iterations/s, not pairs/s",
         "pose": r["pose"],
     }
+
+
+def other_config_legs(pa, st, np, main_engine):
+    """Short legs for the other single-GPU configurations of BASELINE.json, in the same driver-timed run (the headline line
+    stays config[2]; these are extra keys): config[1] 100k<->100k x 50 iterations, config[3] 64 x (50k<->50k) batched, the
+    1k<->1k stand-in of config[0], and the reference's own request shape - <= 6 candidates of one model against one scene
+    through cv::ppf_match_3d::ICP(250, 0.005f, 2.5f, 8) (opencv_surface_match.cpp:85-94), i.e. mi355_icp_align_reference.
+    Un-profiled host wall clock on resident clouds, one warm-up call each.  tools/bench_configs.py runs the same
+    configurations against the oracle (parity), tools/refmode_latency.py the request shape with its kernel split."""
+    legs = {}
+
+    def p2p(name, n_jobs, ns, nt, iters):
+        pairs = [st.make_pair(pa.synth_cloud, ns, nt, object_index=(k if n_jobs > 1 else -1)) for k in range(n_jobs)]
+        with pa.IcpEngine(main_engine.device_id) as e:
+            e.set_targets([q[1] for q in pairs])
+            e.set_sources([q[0] for q in pairs])
+            ids = list(range(n_jobs))
+            init = np.stack([np.eye(4)] * n_jobs)
+            e.align(init, pa.default_params(max_iterations=2), ids, ids)
+            t0 = time.perf_counter()
+            r = e.align(init, pa.default_params(max_iterations=iters), ids, ids)
+            dt = time.perf_counter() - t0
+        assert all(int(x) == 0 for x in r.status) and all(int(x) == iters for x in r.iterations)
+        legs[name] = {"jobs": n_jobs, "n_source": ns, "n_target": nt, "iterations": iters, "ms_per_iteration": 1e3 * dt / iters,
+                      "pairs_per_s": n_jobs * float(ns) * nt * iters / dt,
+                      "pose_error_vs_truth_max": float(max(np.linalg.norm(r.poses[k] - pairs[k][2]) for k in range(n_jobs)))}
+
+    p2p("config0_stand_in_1k_x_1k", 1, 1000, 1000, 50)
+    p2p("config1_100k_x_100k_50_iterations", 1, 100_000, 100_000, 50)
+    p2p("config3_64_objects_50k_x_50k", 64, 50_000, 50_000, 20)
+    # the reference's request: 6 candidate poses, one 20k-point model, one 100k-point scene with normals
+    T = st.perturbation(-1)
+    gt = np.linalg.inv(T)
+    scene = pa.synth_cloud(st.TARGET_SEED, 100_000, normals=True)
+    model = pa.synth_cloud(st.SOURCE_SEED, 20_000, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T)
+    inits = np.stack([np.eye(4)] + [st.rigid_transform(k, (0.2, 1, -0.4), (0.01, -0.02, 0.015)) @ gt for k in (1.0, 2.0, 3.0, 4.0, 5.0)])
+    with pa.IcpEngine(main_engine.device_id) as e:
+        e.set_targets([scene])
+        e.set_sources([model])
+        for _ in range(3):
+            r = e.align_reference(inits, 250, 0.005, 2.5, 8)
+        times = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            r = e.align_reference(inits, 250, 0.005, 2.5, 8)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    legs["reference_request_6_candidates_20k_model_100k_scene"] = {
+        "call": "mi355_icp_align_reference(250, 0.005, 2.5, 8)", "ms_per_request_median": 1e3 * times[len(times) // 2],
+        "ms_per_request_min": 1e3 * times[0], "calls": len(times), "passes": [int(x) for x in r.passes],
+        "pose_error_vs_truth_max": float(max(np.linalg.norm(q - gt) for q in r.poses))}
+    return legs
 
 
 def visible_gpu_count():
@@ -397,6 +450,8 @@ def main():
                 "note": note2 + " This is north_star's literal form (target tiles through LDS, no MFMA); the default path above "
                                 "returns the same bits faster.",
             }
+        if world == 1 and not a.no_config_legs:
+            out["other_configs"] = other_config_legs(pa, st, np, eng)
         if world == 1 and not a.no_cpu_baseline:
             cb = cpu_baseline(src, tgt, a.cpu_baseline_iters, a.cpu_baseline_iters_1thread)
             cpu_pose = cb.pop("pose")

@@ -176,6 +176,7 @@ class IcpEngine:
         if st != _lib.OK:
             raise IcpError(st, lib.mi355_icp_last_error(None).decode())
         self._h = h
+        self.device_id = device_id
         self.n_targets = 0
         self.n_sources = 0
         self._source_sizes: list[int] = []
