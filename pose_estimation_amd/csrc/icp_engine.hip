@@ -1718,6 +1718,7 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
   auto sid = [&](int k) { return source_ids ? source_ids[k] : 0; };
   auto tid = [&](int k) { return target_ids ? target_ids[k] : 0; };
 
+  bool select_cleared = false;
   for (int level = rp->num_levels - 1; level >= 0; --level) {
     const uint32_t step = 1u << level;
     std::vector<int> part, psid, ptid;
@@ -1747,7 +1748,11 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
     if ((st = ensure_ref_buffers(c, plan, static_cast<size_t>(np), owner_total)) != MI355_ICP_OK) return st;
     // the selection histograms are left clear by every completed pass; make that true whatever an earlier call left behind
     // (sharded passes only: the single-GPU selection of jobs below 64k points keeps its histograms in LDS)
-    if (sharded || plan.out_total >= 65536u) HIP_TRY(c, hipMemsetAsync(c->select_work, 0, c->ref_jobs_cap * (2048 + 4) * sizeof(uint32_t), c->stream));
+    // (once per call: within a call nothing but completed passes touches them)
+    if ((sharded || plan.out_total >= 65536u) && !select_cleared) {
+      HIP_TRY(c, hipMemsetAsync(c->select_work, 0, c->ref_jobs_cap * (2048 + 4) * sizeof(uint32_t), c->stream));
+      select_cleared = true;
+    }
     if ((plan.xfilter || plan.pruned) && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
     if ((plan.pruned || plan.sorted_src) && (st = ensure_level_xcopy(c, c->sources, level)) != MI355_ICP_OK) return st;
 
