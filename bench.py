@@ -39,7 +39,8 @@ SCAN_MODELS = {
               "Every pair is evaluated by one K=16 bf16 MFMA contraction (32 flop per pair: the expansion surrogate of "
               "points quantised to two bfloat16 pieces per coordinate) and one vector issue slot per 128 pairs per lane for "
               "the minimum (8 v_min3_u32 + the MFMA issue per 1024 pairs: the binding resource, see roofline_issue; a "
-              "register-only loop of that mix takes 44.8 cycles per MFMA, the kernel 48.6-49.7: profiles/r02s_pmc_summary.txt); "
+              "register-only loop of that mix takes 44.8 cycles per MFMA, the kernel 49.4 - and issues no MFMA whose result is dropped: "
+              "profiles/r03k_pmc_summary.txt; round 2: 49.7 per issued, 51.3 per useful MFMA); "
               "the exact unfused float32 formula then decides inside the one or two candidate granules, so indices and "
               "distances stay bit-identical to the oracle, and the filter's lower bound is itself a tested invariant "
               "(DESIGN.md 3.1). `achieved` counts the 32 executed MFMA flop per pair; by SURVEY 8d's 8-flop model the same "
@@ -409,7 +410,8 @@ def main():
                 "note": "arithmetic floor of the instruction mix: vector instructions per evaluated pair x 4 cycles per integer or "
                         "MFMA wave-instruction (float32: 2 with >= 2 waves per SIMD) at 2.4 GHz on 1024 SIMDs.  Measured on the "
                         "hardware the same mix costs more: 44.8 cycles per MFMA + 8 minima instead of 36 (tools/ubench_bf16_min.hip), "
-                        "and the chip holds 2.0 GHz under this load - against THAT loop the kernel runs at 90-92 % (DESIGN.md 3.1)",
+                        "and the chip holds 1.95-2.1 GHz under this load - against THAT loop the kernel runs at 91 % (DESIGN.md 3.1); "
+                        "`traffic` counts Infinity-Cache hits too (the 33.5 MB operand image re-streamed per workgroup round and XCD)",
             },
             "roofline_hbm": {
                 "bound": "hbm", "kernel": kernel, "achieved": alg_bytes / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
