@@ -13,6 +13,7 @@ import numpy as np
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _DIR = os.path.join(_ROOT, "oracle")
 _SO = os.path.join(_DIR, "libicp_oracle.so")
+_SO = os.environ.get("MI355_ORACLE_LIB") or _SO  # tools/cpu_sanitize.sh points this at its instrumented build
 NSUMS = 17
 
 
