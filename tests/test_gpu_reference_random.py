@@ -1,0 +1,65 @@
+"""Randomised differential test of reference mode (mi355_icp_align_reference) against the oracle: random cloud sizes down to
+a handful of points (levels that are skipped, levels that end early), random pyramid depths, iteration budgets, tolerances,
+rejection on and off, batches that mix clouds, random initial poses; surfaces with their normals and structureless Gaussian
+clouds with random unit normals.  Same seeds every run."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ora
+import synth_twin as st
+
+pytestmark = pytest.mark.gpu
+CASES = int(os.environ.get("MI355_ICP_REFRANDOM_CASES", "40"))
+
+
+def random_cloud6(rng, n, kind):
+    if kind == 0:  # the benchmark surface
+        return st.synth_cloud_np(int(rng.integers(1, 1 << 30)), n, normals=True)
+    p = rng.standard_normal((n, 3)).astype(np.float32) * np.float32(rng.uniform(0.05, 2.0))
+    if kind == 2:  # flattened: nearly planar, the 6x6 system is close to singular
+        p[:, 2] *= np.float32(1e-3)
+    nrm = rng.standard_normal((n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return np.ascontiguousarray(np.hstack([p, nrm.astype(np.float32)]))
+
+
+def test_randomised_reference_mode_against_the_oracle(engine):
+    rng = np.random.default_rng(20261004)
+    worst = 0.0
+    for case in range(CASES):
+        n_clouds = int(rng.integers(1, 4))
+        kind = int(rng.integers(0, 3))
+        tgts, srcs, gts = [], [], []
+        for _ in range(n_clouds):
+            nt = int(rng.choice([1, 7, 40, 333, 1024, 1025, 5000, 20000]))
+            ns = int(rng.choice([6, 9, 47, 500, 2048, 2049, 7777]))
+            tgt = random_cloud6(rng, nt, kind)
+            T = st.rigid_transform(float(rng.uniform(0.0, 4.0)), rng.standard_normal(3), rng.standard_normal(3) * 0.01)
+            pick = rng.integers(0, nt, ns)
+            base = tgt[pick, :3].astype(np.float64) + rng.standard_normal((ns, 3)) * 1e-3
+            src = ((base - T[:3, 3]) @ T[:3, :3]).astype(np.float32)  # T maps src onto the scene, up to the noise
+            tgts.append(tgt)
+            srcs.append(np.ascontiguousarray(src))
+            gts.append(T)
+        engine.set_targets(tgts)
+        engine.set_sources(srcs)
+        n_jobs = int(rng.integers(1, 5))
+        ids = [int(rng.integers(0, n_clouds)) for _ in range(n_jobs)]
+        inits = np.stack([st.rigid_transform(float(rng.uniform(0, 2.0)), rng.standard_normal(3), rng.standard_normal(3) * 0.005) @ gts[i] for i in ids])
+        iters = int(rng.choice([1, 3, 20, 250]))
+        tol = float(rng.choice([0.005, 0.05, 1e-6]))
+        scale = float(rng.choice([2.5, 0.0, 1.0]))
+        levels = int(rng.integers(1, 11))
+        res = engine.align_reference(inits, iters, tol, scale, levels, source_ids=ids, target_ids=ids)
+        for k, i in enumerate(ids):
+            o = ora.icp_reference(srcs[i], tgts[i], inits[k], iters, tol, scale, levels, nthreads=4)
+            tag = f"case {case} job {k}: clouds {srcs[i].shape[0]} x {tgts[i].shape[0]}, kind {kind}, ({iters}, {tol}, {scale}, {levels})"
+            assert res.status[k] == 0, tag
+            assert res.passes[k] == o["passes"], f"{tag}: passes {res.passes[k]} vs oracle {o['passes']}"
+            err = float(np.linalg.norm(res.poses[k] - o["pose"]))
+            worst = max(worst, err)
+            assert err <= 1e-6 * max(1.0, float(np.abs(o["pose"]).max())), f"{tag}: pose differs by {err}"
+            assert abs(res.residual[k] - o["residual"]) <= 1e-9 * max(1.0, abs(o["residual"])), tag
+    print(f"{CASES} random reference-mode cases, worst pose difference to the oracle {worst:.2e}")
