@@ -115,7 +115,8 @@ def cpu_baseline(src, tgt, iters, iters_1thread):
         "brute_force_equivalent_pairs_per_s": float(src.shape[0]) * float(tgt.shape[0]) * r["iterations"] / dt,
         "sample": f"{r['iterations']} ICP iterations of the same {src.shape[0]}x{tgt.shape[0]} workload on {threads} threads in "
                   f"{dt:.2f} s + {r1['iterations']} iterations on 1 thread in {dt1:.2f} s, KD-tree build included in both; "
-                  "O(Ns log Nt) exact tree search, NOT a brute-force scan - compare iterations/s, not pairs/s",
+                  "O(Ns log Nt) exact tree search, NOT a brute-force scan - compare iterations/s, not pairs/s; "
+                  "threads are capped at 16, this pool's CPU share per GPU (host_cores_visible says what the box has)",
         "pose": r["pose"],
     }
 
