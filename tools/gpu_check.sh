@@ -21,6 +21,8 @@ MI355_ICP_SCAN_MODE=xfilter step 900 pytest_gpu_xfilter.txt python -m pytest tes
 MI355_ICP_SCAN_MODE=xbf16 step 900 pytest_gpu_xbf16.txt python -m pytest tests -m gpu -x -q
 MI355_ICP_SCAN_MODE=exact step 900 pytest_gpu_exact.txt python -m pytest tests -m gpu -x -q
 MI355_ICP_SCAN_MODE=pruned step 900 pytest_gpu_pruned.txt python -m pytest tests -m gpu -x -q
+# the matrix-core scan's other workgroup shape (8 waves x 2 source sets), which no planner rule picks
+MI355_ICP_XBF16_SHAPE=1 MI355_ICP_SCAN_MODE=xbf16 step 600 pytest_gpu_xbf16_shape1.txt python -m pytest tests/test_gpu_fused_filter.py tests/test_gpu_parity.py tests/test_gpu_filter_bounds.py -m gpu -x -q
 # the A/B switches of the request path: exhaustive k-NN (the committed scene then has no sorted copy to inherit), and the
 # pre-round-2 structure of a reference pass (separate reduce + copy, a sort per pyramid level, scalar solves)
 MI355_ICP_KNN_MODE=brute step 600 pytest_gpu_knn_brute.txt python -m pytest tests/test_gpu_normals.py tests/test_gpu_opencv_adapter.py tests/test_gpu_scene_filters.py tests/test_gpu_plane_fit.py -m gpu -x -q
