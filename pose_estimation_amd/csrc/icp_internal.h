@@ -279,9 +279,21 @@ void euler_pose(const double* x6, double* pose16);
 void mat4_mul(const double* a, const double* b, double* c);
 
 // ---- scene preparation (scene_kernels.hip) ----
-constexpr int kSceneThreads = 256;   // compaction workgroup: 4 waves
-constexpr int kSceneTile = 4096;     // points per compaction workgroup (48 KiB of LDS, 16 points per thread):
-                                     // 4096/256 and 8192/1024 tie at 3.7 TB/s, 2048/256 is 18% slower (more look-backs)
+// compaction workgroup (scene_compact_kernel): 12 waves x 16 points per thread = 12288-point tiles, two workgroups per CU at
+// <= 80 registers.  One look-back per tile is a fixed ~6-8 us of a tile's life, so larger tiles amortise it - until the
+// workgroup no longer fits a CU twice: 256 / 512 / 768 / 1024 threads give 4.0 / 4.6 / 4.8 / 5.0 TB/s on a NaN-removal pass over
+// 64M points and 3.8 / 4.5 / 4.6 / 4.0 TB/s with three predicates (profiles/r03l_scene_compact_shapes.txt).  -D overrides: A/B only.
+#ifndef MI355_SCENE_THREADS
+#define MI355_SCENE_THREADS 768
+#endif
+#ifndef MI355_SCENE_PER_THREAD
+#define MI355_SCENE_PER_THREAD 16
+#endif
+#ifndef MI355_SCENE_MIN_WAVES
+#define MI355_SCENE_MIN_WAVES 6      // waves per SIMD the register allocation must leave room for (2 workgroups of 12 waves per CU)
+#endif
+constexpr int kSceneThreads = MI355_SCENE_THREADS;
+constexpr int kSceneTile = MI355_SCENE_THREADS * MI355_SCENE_PER_THREAD;  // points per compaction workgroup, held in registers
 using SceneFilter = mi355_scene_filter;
 struct SceneFilterSet {
   int32_t n;

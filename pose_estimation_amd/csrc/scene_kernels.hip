@@ -27,41 +27,48 @@
 
 namespace mi355 {
 
+#ifdef MI355_ICP_DIAG
+// Diagnostic build only (make diag): eight 100 MHz time stamps per compaction tile - entry, ticket, tile in LDS, flags ranked,
+// prefix ready, look-back done, stores issued, stores complete (tools/scene_timeline.py).  Never in the shipped library.
+__device__ unsigned long long* g_diag_scene = nullptr;
+#define MI355_SCENE_STAMP(k) do { if (threadIdx.x == 0 && g_diag_scene) diag_t[k] = wall_clock64(); } while (0)
+#else
+#define MI355_SCENE_STAMP(k) ((void)0)
+#endif
+
 namespace {
 
 constexpr unsigned long long kFlagAggregate = 1ull << 62, kFlagPrefix = 2ull << 62, kValueMask = (1ull << 62) - 1;
 constexpr int kSpinLimit = 1 << 22;
 
-__device__ __forceinline__ bool keep_point(float x, float y, float z, const SceneFilterSet& F) {
-  bool keep = true;
-#pragma unroll 1
-  for (int k = 0; k < F.n; ++k) {
-    const SceneFilter& f = F.f[k];
-    if (f.kind == MI355_SCENE_FILTER_FINITE) {
-      keep = keep && __builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z);
-    } else if (f.kind == MI355_SCENE_FILTER_SPHERE_KEEP_INSIDE || f.kind == MI355_SCENE_FILTER_SPHERE_REMOVE_INSIDE) {
-      const float dx = f.p[0] - x, dy = f.p[1] - y, dz = f.p[2] - z;
-      float s = dx * dx;
-      const float t = dy * dy, u = dz * dz;
-      s = s + t;
-      s = s + u;
-      const float d = __builtin_sqrtf(s);
-      const bool inside = d <= f.p[3];
-      keep = keep && (f.kind == MI355_SCENE_FILTER_SPHERE_KEEP_INSIDE ? inside : !inside);
-    } else {  // MI355_SCENE_FILTER_PLANE_BAND_REMOVE
-      float num = x * f.p[0];
-      const float t = y * f.p[1], u = z * f.p[2];
-      num = num + t;
-      num = num + u;
-      num = num + f.p[3];
-      float den = x * x;
-      const float v = y * y, w = z * z;
-      den = den + v;
-      den = den + w;
-      const float d = num / __builtin_sqrtf(den);
-      const bool near = static_cast<double>(__builtin_fabsf(d)) <= static_cast<double>(f.p[4]);
-      keep = keep && !near;
-    }
+// One predicate on one point; `keep` comes in as the AND of the predicates before it.  The filter's parameters are passed as
+// VALUES: the caller reads them once per filter - they live in the kernel-argument segment, and fetching them per point (a
+// scalar load with a dynamic index, issued and waited for sixteen times per thread) was 5 us of a tile's 18 us of life.
+__device__ __forceinline__ bool apply_filter(bool keep, float x, float y, float z, int32_t kind, float p0, float p1, float p2, float p3, float p4) {
+  if (kind == MI355_SCENE_FILTER_FINITE) {
+    keep = keep && __builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z);
+  } else if (kind == MI355_SCENE_FILTER_SPHERE_KEEP_INSIDE || kind == MI355_SCENE_FILTER_SPHERE_REMOVE_INSIDE) {
+    const float dx = p0 - x, dy = p1 - y, dz = p2 - z;
+    float s = dx * dx;
+    const float t = dy * dy, u = dz * dz;
+    s = s + t;
+    s = s + u;
+    const float d = __builtin_sqrtf(s);
+    const bool inside = d <= p3;
+    keep = keep && (kind == MI355_SCENE_FILTER_SPHERE_KEEP_INSIDE ? inside : !inside);
+  } else {  // MI355_SCENE_FILTER_PLANE_BAND_REMOVE
+    float num = x * p0;
+    const float t = y * p1, u = z * p2;
+    num = num + t;
+    num = num + u;
+    num = num + p3;
+    float den = x * x;
+    const float v = y * y, w = z * z;
+    den = den + v;
+    den = den + w;
+    const float d = num / __builtin_sqrtf(den);
+    const bool near = static_cast<double>(__builtin_fabsf(d)) <= static_cast<double>(p4);
+    keep = keep && !near;
   }
   return keep;
 }
@@ -72,52 +79,66 @@ __device__ __forceinline__ bool keep_point(float x, float y, float z, const Scen
 // state: one u64 per tile, zeroed before the launch.  counters[0]: tile ticket, counters[1]: kept total (written
 // by the last tile), counters[2]: error flag.
 //
-// A tile is kSceneTile points (12 B each), held in LDS for the whole life of the workgroup.  All 12 sixteen-byte
-// loads of a thread (lane-contiguous, 1 KiB per wave-instruction) are issued up front and land in LDS in file order;
-// thread t then owns points t, t+256, ... (12-byte lane stride in LDS: 3 is coprime with the 32 banks, conflict-free).
-// Keep flags are ranked with wave ballots; ONE look-back per tile; kept points are re-read from LDS on the way out.
-__global__ __launch_bounds__(kSceneThreads) void scene_compact_kernel(const float* __restrict__ in, uint32_t n,
+// A tile is kSceneTile points; thread t owns points t, t + kSceneThreads, ... and holds them in REGISTERS from load to store: three
+// dword loads per point, 12 bytes apart across the lanes (a wave's x, y and z loads of one k together read every byte of the
+// 768 they span; the second and third hit the lines the first brought in), all 48 in flight before the first is used.
+// Rounds 1-2 staged the tile through 48 KiB of LDS (lane-contiguous 16-byte loads, then a transposing read): three
+// workgroups per CU - and a tile lives ~17 us (stamps: tools/scene_timeline.py) of which 3 are its loads, 5-6 its look-back
+// and the rest dependent phases in between, so the bytes in flight, not any unit's throughput, set the rate.  Without the
+// LDS tile the workgroups per CU are bounded by registers only, and the tile can grow (icp_internal.h: 12288 points).
+// Keep flags are ranked with wave ballots; ONE look-back per tile.
+__global__ __launch_bounds__(kSceneThreads, MI355_SCENE_MIN_WAVES) void scene_compact_kernel(const float* __restrict__ in, uint32_t n,
                                                                        SceneFilterSet F, float* __restrict__ out,
                                                                        unsigned long long* __restrict__ state,
                                                                        uint32_t* __restrict__ counters,
                                                                        uint32_t n_tiles) {
   constexpr int kPer = kSceneTile / kSceneThreads;  // points per thread
   constexpr int kWaves = kSceneThreads / 64;
-  constexpr int kF4 = kSceneTile * 3 / 4;           // float4s per tile
-  __shared__ float4 s_pts[kF4];
   __shared__ uint32_t s_tile, s_excl;
   __shared__ uint32_t s_cnt[kPer * kWaves];         // kept points per (k, wave), in point order
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+#ifdef MI355_ICP_DIAG
+  unsigned long long diag_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  MI355_SCENE_STAMP(0);
   if (tid == 0) s_tile = atomicAdd(&counters[0], 1u);
   __syncthreads();
   const uint32_t tile = s_tile;
   if (tile >= n_tiles) return;
+  MI355_SCENE_STAMP(1);
 
   const size_t tile_first = static_cast<size_t>(tile) * kSceneTile;           // first point of the tile
-  const size_t n_f4 = (static_cast<size_t>(n) * 3 + 3) / 4;                   // float4s that hold real data
-  const float4* __restrict__ in4 = reinterpret_cast<const float4*>(in);       // scene buffers are 16-byte aligned
-  const size_t f4_first = tile_first * 3 / 4;
-  float4 r[kF4 / kSceneThreads];
-#pragma unroll
-  for (int j = 0; j < kF4 / kSceneThreads; ++j) {
-    const size_t g = f4_first + j * kSceneThreads + tid;
-    r[j] = g < n_f4 ? in4[g] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-#pragma unroll
-  for (int j = 0; j < kF4 / kSceneThreads; ++j) s_pts[j * kSceneThreads + tid] = r[j];
-  __syncthreads();
-
-  const float* __restrict__ f = reinterpret_cast<const float*>(s_pts);
+  float px[kPer], py[kPer], pz[kPer];
   uint32_t keep_mask = 0;
 #pragma unroll
   for (int k = 0; k < kPer; ++k) {
-    const uint32_t q = k * kSceneThreads + tid;  // point within the tile
-    const bool keep = tile_first + q < n && keep_point(f[3 * q], f[3 * q + 1], f[3 * q + 2], F);
-    const unsigned long long m = __ballot(keep);
-    keep_mask |= (keep ? 1u : 0u) << k;
+    const size_t q = tile_first + static_cast<size_t>(k) * kSceneThreads + tid;
+    const bool there = q < n;
+    const float* __restrict__ src = in + (there ? q : 0) * 3;
+    px[k] = src[0];
+    py[k] = src[1];
+    pz[k] = src[2];
+    keep_mask |= (there ? 1u : 0u) << k;
+  }
+  MI355_SCENE_STAMP(2);
+  // filters outside, the thread's sixteen points inside: a filter's parameters are read once (wave-uniform)
+#pragma unroll 1
+  for (int fi = 0; fi < F.n; ++fi) {
+    const int32_t kind = F.f[fi].kind;
+    const float p0 = F.f[fi].p[0], p1 = F.f[fi].p[1], p2 = F.f[fi].p[2], p3 = F.f[fi].p[3], p4 = F.f[fi].p[4];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const bool keep = apply_filter((keep_mask >> k) & 1u, px[k], py[k], pz[k], kind, p0, p1, p2, p3, p4);
+      keep_mask = (keep_mask & ~(1u << k)) | ((keep ? 1u : 0u) << k);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const unsigned long long m = __ballot((keep_mask >> k) & 1u);
     if (lane == 0) s_cnt[k * kWaves + wave] = static_cast<uint32_t>(__popcll(m));
   }
   __syncthreads();
+  MI355_SCENE_STAMP(3);
   // exclusive prefix of the kPer * kWaves (k, wave) counts, kEpl per lane: every wave computes the total, wave 0 stores
   uint32_t total;
   {
@@ -147,6 +168,7 @@ __global__ __launch_bounds__(kSceneThreads) void scene_compact_kernel(const floa
     }
   }
 
+  MI355_SCENE_STAMP(4);
   // decoupled look-back by wave 0: lane l inspects tile (window - l)
   if (wave == 0) {
     uint32_t exclusive = 0;
@@ -155,6 +177,8 @@ __global__ __launch_bounds__(kSceneThreads) void scene_compact_kernel(const floa
       if (lane == 0) __hip_atomic_store(&state[0], kFlagPrefix | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       if (lane == 0) __hip_atomic_store(&state[tile], kFlagAggregate | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // 64 predecessors per round trip.  (Reading 128 or 256 per round - two or four loads per lane in flight - is SLOWER,
+      // on the LDS-staged kernel of rounds 1-2 and on this one: profiles/r03i_scene_compact_experiments.txt.)
       int64_t window = static_cast<int64_t>(tile) - 1;
       bool done = false;
       while (!done) {
@@ -189,20 +213,27 @@ __global__ __launch_bounds__(kSceneThreads) void scene_compact_kernel(const floa
     }
   }
   __syncthreads();
+  MI355_SCENE_STAMP(5);
   const uint32_t excl = s_excl;
 #pragma unroll
   for (int k = 0; k < kPer; ++k) {
     const bool keep = (keep_mask >> k) & 1u;
     const unsigned long long m = __ballot(keep);
     if (keep) {
-      const uint32_t q = k * kSceneThreads + tid;
       const uint32_t o = excl + s_cnt[k * kWaves + wave] + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
       float* dst = out + static_cast<size_t>(o) * 3;
-      dst[0] = f[3 * q];
-      dst[1] = f[3 * q + 1];
-      dst[2] = f[3 * q + 2];
+      dst[0] = px[k];
+      dst[1] = py[k];
+      dst[2] = pz[k];
     }
   }
+#ifdef MI355_ICP_DIAG
+  MI355_SCENE_STAMP(6);
+  __builtin_amdgcn_s_waitcnt(0);
+  MI355_SCENE_STAMP(7);
+  if (threadIdx.x == 0 && g_diag_scene)
+    for (int k = 0; k < 8; ++k) g_diag_scene[static_cast<size_t>(tile) * 8 + k] = diag_t[k];
+#endif
 }
 
 // Packed AoS xyz (n points) -> SoA planes at plane offset `off`, slots [n, n_padded) filled with `pad`.
@@ -419,6 +450,21 @@ void launch_scene_compact(void* stream, const float* in, uint32_t n, const Scene
   hipLaunchKernelGGL(scene_compact_kernel, dim3(n_tiles), dim3(kSceneThreads), 0, static_cast<hipStream_t>(stream), in, n,
                      filters, out, state, counters, n_tiles);
 }
+
+#ifdef MI355_ICP_DIAG
+extern "C" int mi355_icp_diag_scene_begin(size_t n_tiles) {
+  unsigned long long* buf = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&buf), n_tiles * 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (hipMemset(buf, 0, n_tiles * 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_scene), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+extern "C" int mi355_icp_diag_scene_read(unsigned long long* out, size_t n_tiles) {
+  unsigned long long* buf = nullptr;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(&buf, HIP_SYMBOL(g_diag_scene), sizeof(buf)) != hipSuccess || !buf) return 1;
+  return hipMemcpy(out, buf, n_tiles * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
 
 void launch_scene_to_planes(void* stream, const float* in, uint32_t n, float* planes, size_t stride, uint32_t off,
                             uint32_t n_padded, float pad, uint32_t* counters) {
