@@ -129,28 +129,43 @@ struct PassTail {
 };
 
 #if defined(__HIPCC__)
-// Sum of NV doubles per thread over a 256-thread workgroup: shuffle tree inside each wave, wave results through LDS, added in
-// wave order.  Threads 0..NV-1 return the total of value [threadIdx.x].
+// Sum of NV doubles per thread over a 256-thread workgroup, in a FIXED order: every lane parks its NV values in LDS, one thread
+// per (wave, value) adds that wave's 64 lanes up - four chains of sixteen lanes each, lanes ascending, combined as
+// ((c0 + c1) + (c2 + c3)) - and thread k < NV adds the four wave results in wave order.  Threads 0..NV-1 return the total of
+// value [threadIdx.x].
+// Rounds 1-2 used a shuffle tree inside each wave: six dependent exchanges per value, each two ds_bpermute for a double -
+// 348 LDS-pipe round trips for NV = 29, ~4 us of every accumulation launch whatever the job's size (phase stamps:
+// tools/ref_kernel_phases.py; a coarse reference-mode pass is ~45 us in all).  The parked form is ~0.5 us.
+// Rows are 65 doubles apart: the summing threads read different rows at the same lane position - 64-bit reads 520 bytes apart
+// fall into different banks.
 template <int NV>
 __device__ __forceinline__ double pass_block_sum(double (&v)[NV], double (*scratch)[NV]) {
+  constexpr int kWaves = kBlockThreads / 64;
+  constexpr int kRow = 65;
+  static_assert(kWaves * NV <= kBlockThreads, "one thread per (wave, value)");
+  __shared__ double parked[kWaves * NV * kRow];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    double x = v[k];
+  for (int k = 0; k < NV; ++k) parked[(wave * NV + k) * kRow + lane] = v[k];
+  __syncthreads();
+  if (threadIdx.x < kWaves * NV) {
+    const double* __restrict__ row = parked + threadIdx.x * kRow;  // thread w * NV + k owns wave w's value k
+    double c[4];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
-    v[k] = x;
-  }
-  if (lane == 0) {
+    for (int q = 0; q < 4; ++q) {
+      double a = row[16 * q];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) scratch[wave][k] = v[k];
+      for (int j = 1; j < 16; ++j) a += row[16 * q + j];
+      c[q] = a;
+    }
+    scratch[threadIdx.x / NV][threadIdx.x % NV] = (c[0] + c[1]) + (c[2] + c[3]);
   }
   __syncthreads();
   double r = 0.0;
   if (threadIdx.x < NV) {
     r = scratch[0][threadIdx.x];
 #pragma unroll
-    for (int w = 1; w < kBlockThreads / 64; ++w) r += scratch[w][threadIdx.x];
+    for (int w = 1; w < kWaves; ++w) r += scratch[w][threadIdx.x];
   }
   return r;
 }

@@ -22,6 +22,36 @@
 
 namespace mi355 {
 
+#ifdef MI355_ICP_DIAG
+// Diagnostic build only (make diag): phase stamps (100 MHz) of the reference-mode kernels of ONE workgroup per launch
+// (tools/ref_kernel_phases.py).  Record = [kernel id, n_stamps, t0, t1, ...] in slots of 16 words.
+__device__ unsigned long long* g_diag_ref = nullptr;
+__device__ unsigned int g_diag_ref_n = 0;
+struct RefDiag {
+  unsigned long long t[14];
+  int n = 0;
+  bool on = false;
+  __device__ void begin(bool who) { on = who && g_diag_ref != nullptr; n = 0; stamp(); }
+  __device__ void stamp() { if (on && n < 14) t[n++] = wall_clock64(); }
+  __device__ void end(unsigned long long id) {
+    if (!on) return;
+    stamp();
+    const unsigned int slot = atomicAdd(&g_diag_ref_n, 1u);
+    if (slot >= 4096u) return;
+    g_diag_ref[slot * 16ull] = id;
+    g_diag_ref[slot * 16ull + 1] = static_cast<unsigned long long>(n);
+    for (int k = 0; k < n; ++k) g_diag_ref[slot * 16ull + 2 + k] = t[k];
+  }
+};
+#define REF_DIAG_BEGIN(who) RefDiag rd; rd.begin(who)
+#define REF_DIAG_STAMP() rd.stamp()
+#define REF_DIAG_END(id) rd.end(id)
+#else
+#define REF_DIAG_BEGIN(who) ((void)0)
+#define REF_DIAG_STAMP() ((void)0)
+#define REF_DIAG_END(id) ((void)0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ void transform_point(const float* __restrict__ m, float x, float y, float z, float& ox,
@@ -120,6 +150,7 @@ __global__ __launch_bounds__(kSelThreads) void rejection_select_kernel(const Job
   __shared__ uint32_t bcast[2];
   __shared__ uint32_t wave_tot[kSelThreads / 64];
   __shared__ float thr_shared;
+  REF_DIAG_BEGIN(blockIdx.x == 0 && threadIdx.x == 0);
   const JobDesc& J = jobs[blockIdx.x];
   const uint32_t n = J.src_n;
   if (n == 0) {
@@ -130,19 +161,25 @@ __global__ __launch_bounds__(kSelThreads) void rejection_select_kernel(const Job
   const uint32_t cached = n < cache_n ? n : cache_n;
   for (uint32_t i = threadIdx.x; i < cached; i += kSelThreads) cache[i] = d[i];
   __syncthreads();
+  REF_DIAG_STAMP();  // 1: distances in LDS
   const uint32_t k = (n - 1) / 2;
   const float med = __uint_as_float(radix_select(n, k, hist, bcast, wave_tot, [&](uint32_t i) { return i < cached ? cache[i] : d[i]; }));
+  REF_DIAG_STAMP();  // 2: median
   const float mad = __uint_as_float(radix_select(n, k, hist, bcast, wave_tot, [&](uint32_t i) {
     const float v = i < cached ? cache[i] : d[i];
     return static_cast<float>(__builtin_fabs(static_cast<double>(v) - static_cast<double>(med)));
   }));
+  REF_DIAG_STAMP();  // 3: MAD
   if (threadIdx.x == 0) {
     const float s = 1.48257968f * mad;
     const float t = scale * s;
     thr_out[blockIdx.x] = t + med;
     thr_shared = t + med;
   }
-  if (!owner) return;
+  if (!owner) {
+    REF_DIAG_END(1ull | (static_cast<unsigned long long>(n) << 8));
+    return;
+  }
   __syncthreads();
   const float t = thr_shared;
   const RefJobDesc& RJ = rjobs[blockIdx.x];
@@ -151,6 +188,7 @@ __global__ __launch_bounds__(kSelThreads) void rejection_select_kernel(const Job
     const float v = i < cached ? cache[i] : d[i];
     if (v < t) atomicMin(&owner[RJ.owner_off + static_cast<uint32_t>(idx[i])], picky_key(RJ.owner_prefix, v, RJ.src_index_base + i));
   }
+  REF_DIAG_END(2ull | (static_cast<unsigned long long>(n) << 8));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -303,6 +341,7 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
     uint8_t* __restrict__ selected, double* partials, PassTail tail) {
   __shared__ double scratch[kBlockThreads / 64][kRefSums];
   __shared__ uint32_t last_flag;
+  REF_DIAG_BEGIN(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0);
   const JobDesc& J = jobs[blockIdx.y];
   const uint32_t sb = blockIdx.x;
   if (sb >= J.src_blocks) return;
@@ -331,9 +370,11 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
     dd[p] = dist2[at];
     jt[p] = static_cast<uint32_t>(index[at]);
   }
+  REF_DIAG_STAMP();  // 1: descriptors read, first loads issued
   unsigned long long own[kP];
 #pragma unroll
   for (int p = 0; p < kP; ++p) own[p] = owner[RJ.owner_off + jt[p]];
+  REF_DIAG_STAMP();  // 2: owner loads issued (index and distance arrived)
   bool sel[kP];
   float S0[kP], S1[kP], S2[kP], Qx[kP], Qy[kP], Qz[kP], Nx[kP], Ny[kP], Nz[kP];
 #pragma unroll
@@ -346,6 +387,7 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
     Qx[p] = tx[tj]; Qy[p] = ty[tj]; Qz[p] = tz[tj];
     Nx[p] = nx[nj]; Ny[p] = ny[nj]; Nz[p] = nz[nj];
   }
+  REF_DIAG_STAMP();  // 3: gathers issued (owner arrived)
 #pragma unroll
   for (int p = 0; p < kP; ++p) {
     if (live[p]) selected[J.out_off + local[p]] = sel[p] ? 1 : 0;
@@ -368,7 +410,10 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
       acc[28] += 1.0;
     }
   }
+  REF_DIAG_STAMP();  // 4: products accumulated (gathers arrived)
   const double r = pass_block_sum<kRefSums>(acc, scratch);
+  REF_DIAG_STAMP();  // 5: block sum
+  REF_DIAG_END(3ull | (static_cast<unsigned long long>(J.src_n) << 8) | (static_cast<unsigned long long>(J.src_blocks) << 40));
   double* job_rows = partials + static_cast<size_t>(J.partial_off) * kRefSums;
   if (!tail.done) {
     if (threadIdx.x < kRefSums) job_rows[static_cast<size_t>(sb) * kRefSums + threadIdx.x] = r;
@@ -471,5 +516,23 @@ void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, 
   hipLaunchKernelGGL(ref_final_reduce_kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0,
                      static_cast<hipStream_t>(stream), jobs_dev, partials, sums, thr, overflow_count, overflow_cap);
 }
+
+#ifdef MI355_ICP_DIAG
+extern "C" int mi355_icp_diag_ref_begin(void) {
+  unsigned long long* buf = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&buf), 4096 * 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (hipMemset(buf, 0, 4096 * 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  const unsigned int zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag_ref_n), &zero, sizeof(zero)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_ref), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+extern "C" int mi355_icp_diag_ref_read(unsigned long long* out, unsigned int* n) {
+  unsigned long long* buf = nullptr;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(&buf, HIP_SYMBOL(g_diag_ref), sizeof(buf)) != hipSuccess || !buf) return 1;
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(g_diag_ref_n), sizeof(*n)) != hipSuccess) return 1;
+  return hipMemcpy(out, buf, 4096 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
 
 }  // namespace mi355
