@@ -84,9 +84,14 @@ __global__ __launch_bounds__(kBlockThreads) void subsample_kernel(const float* _
 // kSelThreads threads cooperate; `value_of(i)` yields element i.  Returns the element of 0-based rank k.
 constexpr int kSelThreads = 1024;
 
+// After a pass the digit's bin holds the only values that can still be the answer.  Once there are at most 64 of them the
+// remaining passes (a histogram clear, a walk with LDS atomics, a 2048-bin scan and four barriers each: ~1.2 us + the walk) are
+// replaced by ONE walk that collects the candidates and one wave that ranks them against each other by counting: the value whose
+// rank interval [#smaller, #smaller-or-equal) holds k.  Typically that happens after the first pass on the coarse pyramid levels
+// and after the second anywhere (22 of 32 bits fixed).
 template <typename F>
-__device__ uint32_t radix_select(uint32_t n, uint32_t k, uint32_t* hist /* 2048 */, uint32_t* bcast /* 2 */,
-                                 uint32_t* wave_tot /* 16 */, F value_of) {
+__device__ uint32_t radix_select(uint32_t n, uint32_t k, uint32_t* hist /* 2048 */, uint32_t* bcast /* 3 */,
+                                 uint32_t* wave_tot /* 16 */, uint32_t* cand /* 64 */, uint32_t* cand_n, F value_of) {
   uint32_t prefix = 0, mask = 0;
   const int shifts[3] = {21, 10, 0};
   const int widths[3] = {11, 11, 10};
@@ -95,6 +100,7 @@ __device__ uint32_t radix_select(uint32_t n, uint32_t k, uint32_t* hist /* 2048 
     const int shift = shifts[pass];
     const uint32_t nb = 1u << widths[pass];
     for (uint32_t b = threadIdx.x; b < 2048; b += kSelThreads) hist[b] = 0;
+    if (threadIdx.x == 0) *cand_n = 0;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += kSelThreads) {
       const uint32_t bits = __float_as_uint(value_of(i));
@@ -122,13 +128,36 @@ __device__ uint32_t radix_select(uint32_t n, uint32_t k, uint32_t* hist /* 2048 
         const bool second = k >= excl + c0;
         bcast[0] = 2 * threadIdx.x + (second ? 1u : 0u);
         bcast[1] = k - excl - (second ? c0 : 0u);
+        bcast[2] = second ? c1 : c0;  // values in the chosen bin
       }
     }
     __syncthreads();
     prefix |= bcast[0] << shift;
     mask |= (nb - 1) << shift;
     k = bcast[1];
+    const uint32_t in_bin = bcast[2];
     __syncthreads();
+    if (pass < 2 && in_bin <= 64u) {  // wave-uniform: everyone read the same words
+      for (uint32_t i = threadIdx.x; i < n; i += kSelThreads) {
+        const uint32_t bits = __float_as_uint(value_of(i));
+        if ((bits & mask) == prefix) cand[atomicAdd(cand_n, 1u)] = bits;  // exactly in_bin appends
+      }
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        const uint32_t c = threadIdx.x < in_bin ? cand[threadIdx.x] : 0xFFFFFFFFu;
+        uint32_t less = 0, leq = 0;
+        for (uint32_t j = 0; j < in_bin; ++j) {
+          const uint32_t cj = cand[j];  // one address for the whole wave: an LDS broadcast
+          less += cj < c ? 1u : 0u;
+          leq += cj <= c ? 1u : 0u;
+        }
+        if (threadIdx.x < in_bin && less <= k && k < leq) bcast[0] = c;  // equal values all qualify and write the same bits
+      }
+      __syncthreads();
+      const uint32_t answer = bcast[0];
+      __syncthreads();
+      return answer;
+    }
   }
   return prefix;
 }
@@ -147,8 +176,10 @@ __global__ __launch_bounds__(kSelThreads) void rejection_select_kernel(const Job
                                                                         unsigned long long* __restrict__ owner) {
   extern __shared__ float cache[];
   __shared__ uint32_t hist[2048];
-  __shared__ uint32_t bcast[2];
+  __shared__ uint32_t bcast[3];
   __shared__ uint32_t wave_tot[kSelThreads / 64];
+  __shared__ uint32_t cand[64];
+  __shared__ uint32_t cand_n;
   __shared__ float thr_shared;
   REF_DIAG_BEGIN(blockIdx.x == 0 && threadIdx.x == 0);
   const JobDesc& J = jobs[blockIdx.x];
@@ -163,9 +194,9 @@ __global__ __launch_bounds__(kSelThreads) void rejection_select_kernel(const Job
   __syncthreads();
   REF_DIAG_STAMP();  // 1: distances in LDS
   const uint32_t k = (n - 1) / 2;
-  const float med = __uint_as_float(radix_select(n, k, hist, bcast, wave_tot, [&](uint32_t i) { return i < cached ? cache[i] : d[i]; }));
+  const float med = __uint_as_float(radix_select(n, k, hist, bcast, wave_tot, cand, &cand_n, [&](uint32_t i) { return i < cached ? cache[i] : d[i]; }));
   REF_DIAG_STAMP();  // 2: median
-  const float mad = __uint_as_float(radix_select(n, k, hist, bcast, wave_tot, [&](uint32_t i) {
+  const float mad = __uint_as_float(radix_select(n, k, hist, bcast, wave_tot, cand, &cand_n, [&](uint32_t i) {
     const float v = i < cached ? cache[i] : d[i];
     return static_cast<float>(__builtin_fabs(static_cast<double>(v) - static_cast<double>(med)));
   }));
