@@ -207,6 +207,8 @@ struct mi355_icp_ctx {
   uint32_t* ready_mapped = nullptr;
   uint32_t pass_seq = 0;
   bool error_word_known = false;       // the last pass brought the call's error word along (PassTail::error_flag): no copy needed
+  bool want_selected = false;          // this call wants the per-point winner mask written (mi355_icp_reference_pass)
+  bool error_flag_clean = true;        // the device word is known to be zero (the last call read it as zero): no fill launch at the next call's start
   uint32_t error_word = 0;
   bool pass_tail = true;               // MI355_ICP_PASS_TAIL=0: final-reduce launch + device-to-host copy instead (A/B)
   size_t keys_clean = 0;               // leading slots of `keys` known to hold ~0 (merged key rows of reference mode are
@@ -440,7 +442,7 @@ int grow(mi355_icp_ctx* c, T*& ptr, size_t& cap, size_t need) {
   return MI355_ICP_OK;
 }
 
-int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs) {
+int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs, bool* overflow_cleared = nullptr) {
   int st;
   {
     const size_t before = c->keys_cap;
@@ -465,6 +467,7 @@ int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs) {
       if (c->overflow_count_host) { HIP_TRY(c, hipHostFree(c->overflow_count_host)); c->overflow_count_host = nullptr; }
       const size_t want = std::max<size_t>(n_jobs, 8) * 2;
       HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->overflow_count), want * sizeof(uint32_t)));
+      if (overflow_cleared) *overflow_cleared = false;  // a new buffer holds anything
       HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->overflow_count_host), want * sizeof(uint32_t), hipHostMallocDefault));
       c->overflow_jobs_cap = want;
     }
@@ -490,7 +493,11 @@ int ensure_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs) {
   }
   // the per-job overflow counters are zero between passes (the final-reduce kernels reset them); make that true at the
   // start of every call too, whatever an earlier call left behind when it failed half way
-  if (plan.fused) HIP_TRY(c, hipMemsetAsync(c->overflow_count, 0, c->overflow_jobs_cap * sizeof(uint32_t), c->stream));
+  // (reference mode calls this once per pyramid level: one clear per CALL is enough - `overflow_cleared` remembers)
+  if (plan.fused && !(overflow_cleared && *overflow_cleared)) {
+    HIP_TRY(c, hipMemsetAsync(c->overflow_count, 0, c->overflow_jobs_cap * sizeof(uint32_t), c->stream));
+    if (overflow_cleared) *overflow_cleared = true;
+  }
   return MI355_ICP_OK;
 }
 
@@ -1051,11 +1058,21 @@ int check_error_flag(mi355_icp_ctx* c) {
   if (c->error_word_known) {  // the last pass was a reference-mode one that ended itself: it read the word for us
     c->error_word_known = false;
     if (c->error_word) c->err = "a non-finite distance was met during the scan (overflowing pose or coordinates)";
+    c->error_flag_clean = c->error_word == 0;
     return MI355_ICP_OK;
   }
   HIP_TRY(c, hipMemcpyAsync(c->flag_host, c->error_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (*c->flag_host) c->err = "a non-finite distance was met during the scan (overflowing pose or coordinates)";
+  c->error_flag_clean = *c->flag_host == 0;
+  return MI355_ICP_OK;
+}
+
+// Start of a call that may raise the error word: clear it unless the previous call read it as zero (a fill is a launch of its
+// own in front of the call's first kernel).  From here on the word counts as dirty until check_error_flag has read it again.
+int reset_error_flag(mi355_icp_ctx* c) {
+  if (!c->error_flag_clean) HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+  c->error_flag_clean = false;
   return MI355_ICP_OK;
 }
 
@@ -1287,7 +1304,7 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
       if (cst != MI355_ICP_OK) return fail(c, cst, std::string("cross-rank owner table: ") + (why ? why : "?"));
     }
     if (sbx) launch_ref_accumulate(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, S, T, c->targets.normal_view(), c->out_index,
-                                   c->out_dist2, c->thr_dev, c->owner, c->selected, c->ref_partials, tail);
+                                   c->out_dist2, c->thr_dev, c->owner, c->want_selected ? c->selected : nullptr, c->ref_partials, tail);
   }
   // the pass result, ref_sums_dev or (PassTail) ref_sums_host directly: [n x 29 sums][n overflow-excess flags][n thresholds][n overflow counts]
   if (!tail_on) launch_ref_final_reduce(c->stream, c->jobs_dev, n_active, c->ref_partials, c->ref_sums_dev, c->thr_dev, plan.fused ? c->overflow_count : nullptr,
@@ -1515,7 +1532,7 @@ int mi355_icp_align(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const i
   if ((st = ensure_buffers(c, plan, static_cast<size_t>(n_jobs))) != MI355_ICP_OK) return st;
   if ((plan.xfilter || plan.pruned) && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;
   if ((plan.pruned || plan.sorted_src) && (st = ensure_xtarget(c, c->sources)) != MI355_ICP_OK) return st;
-  HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+  if (const int est = reset_error_flag(c); est != MI355_ICP_OK) return est;
   c->error_word_known = false;
 
   struct JobState { double pose[16]; double prev_mse = 0.0; double residual = 0.0; int iters = 0; int status = MI355_ICP_OK; int converged = 0; };
@@ -1576,7 +1593,7 @@ int mi355_icp_correspond(mi355_icp_ctx* c, int n_jobs, const int* source_ids, co
   if ((st = ensure_buffers(c, plan, static_cast<size_t>(n_jobs))) != MI355_ICP_OK) return st;
   if ((plan.xfilter || plan.pruned) && (st = ensure_xtarget(c, c->targets)) != MI355_ICP_OK) return st;
   if ((plan.pruned || plan.sorted_src) && (st = ensure_xtarget(c, c->sources)) != MI355_ICP_OK) return st;
-  HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+  if (const int est = reset_error_flag(c); est != MI355_ICP_OK) return est;
   c->error_word_known = false;
   for (int k = 0; k < n_jobs; ++k) {
     JobDesc J = plan.jobs[static_cast<size_t>(k)];
@@ -1698,10 +1715,13 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
   auto level_total = [&](int s, int level) -> uint64_t {
     return (sharded ? shard_total[static_cast<size_t>(s)] : c->sources.clouds[static_cast<size_t>(s)].n) >> level;
   };
-  HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+  if (const int est = reset_error_flag(c); est != MI355_ICP_OK) return est;
   c->error_word_known = false;
-  c->owner_epoch = 0;  // the picky pass tags restart with every call (table cleared at its first pass): a function of the
-                       // call's pass sequence only, hence the same on every rank of a slab-sharded run
+  // Slab-sharded: the picky pass tags restart with every call (table cleared at its first pass) - a function of the call's pass
+  // sequence only, hence the same on every rank whatever the ranks' engines did before.  One GPU: the tags simply run on across
+  // calls (a key of ANY later pass beats the keys of earlier ones), so the 4.8 MB table of a request's six candidates is cleared
+  // once per 63 passes - every third or fourth request - instead of at the start of each.
+  if (sharded) c->owner_epoch = 0;
   c->call_pruned = (rp->flags & MI355_ICP_FLAG_PRUNED_SCAN) != 0;
   const bool profile = c->profile_always || (rp->flags & MI355_ICP_FLAG_PROFILE) != 0;
 
@@ -1718,7 +1738,7 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
   auto sid = [&](int k) { return source_ids ? source_ids[k] : 0; };
   auto tid = [&](int k) { return target_ids ? target_ids[k] : 0; };
 
-  bool select_cleared = false;
+  bool select_cleared = false, overflow_cleared = false;
   for (int level = rp->num_levels - 1; level >= 0; --level) {
     const uint32_t step = 1u << level;
     std::vector<int> part, psid, ptid;
@@ -1738,7 +1758,7 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
     Plan plan;
     const int np = static_cast<int>(part.size());
     if ((st = make_plan_on(c, level_clouds(c->sources, level), level_clouds(c->targets, level), np, psid.data(), ptid.data(), 0.0f, plan)) != MI355_ICP_OK) return st;
-    if ((st = ensure_buffers(c, plan, static_cast<size_t>(np))) != MI355_ICP_OK) return st;
+    if ((st = ensure_buffers(c, plan, static_cast<size_t>(np), &overflow_cleared)) != MI355_ICP_OK) return st;
     std::vector<uint32_t> owner_off(static_cast<size_t>(np));
     size_t owner_total = 0;
     for (int a = 0; a < np; ++a) {
@@ -1855,7 +1875,7 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
   if ((st = ensure_ref_buffers(c, plan, 1, owner_total)) != MI355_ICP_OK) return st;
   if ((plan.xfilter || plan.pruned) && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
   if ((plan.pruned || plan.sorted_src) && (st = ensure_level_xcopy(c, c->sources, level)) != MI355_ICP_OK) return st;
-  HIP_TRY(c, hipMemsetAsync(c->error_flag, 0, sizeof(uint32_t), c->stream));
+  if (const int est = reset_error_flag(c); est != MI355_ICP_OK) return est;
   c->error_word_known = false;
   c->owner_epoch = 0;
   JobDesc J = plan.jobs[0];
@@ -1866,7 +1886,10 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
   R.step = 1u << level;
   c->jobs_host[0] = J;
   c->rjobs_host[0] = R;
-  if ((st = run_ref_pass(c, plan, level, 1, rejection_scale, owner_total, c->profile_always)) != MI355_ICP_OK) return st;
+  c->want_selected = out_selected != nullptr;
+  st = run_ref_pass(c, plan, level, 1, rejection_scale, owner_total, c->profile_always);
+  c->want_selected = false;
+  if (st != MI355_ICP_OK) return st;
   if (out_sums) std::memcpy(out_sums, c->ref_sums_host, kRefSums * sizeof(double));
   if (out_threshold) *out_threshold = c->thr_host[0];
   // The pass may have ended itself (PassTail): the host then only saw the published words, and c->stream does not

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
   REF_DIAG_STAMP();  // 3: gathers issued (owner arrived)
 #pragma unroll
   for (int p = 0; p < kP; ++p) {
-    if (live[p]) selected[J.out_off + local[p]] = sel[p] ? 1 : 0;
+    if (selected && live[p]) selected[J.out_off + local[p]] = sel[p] ? 1 : 0;  // the per-pass diagnostic only (mi355_icp_reference_pass)
     if (sel[p]) {
       float px, py, pz;
       transform_point(pose, S0[p], S1[p], S2[p], px, py, pz);  // the level-start point
