@@ -46,6 +46,35 @@ namespace mi355 {
 // Never compiled into the shipped library; stamps leave the kernel through this buffer alone.
 __device__ unsigned long long* g_diag_stamps = nullptr;
 #endif
+#ifdef MI355_ICP_DIAG
+// ... and phase stamps of ONE workgroup per launch of the small-pass kernels (tools/p2p_kernel_phases.py): records of 16 words,
+// [kernel id | n << 8, n_stamps, t0, t1, ...]
+__device__ unsigned long long* g_diag_p2p = nullptr;
+__device__ unsigned int g_diag_p2p_n = 0;
+struct P2pDiag {
+  unsigned long long t[14];
+  int n = 0;
+  bool on = false;
+  __device__ void begin(bool who) { on = who && g_diag_p2p != nullptr; n = 0; stamp(); }
+  __device__ void stamp() { if (on && n < 14) t[n++] = wall_clock64(); }
+  __device__ void end(unsigned long long id) {
+    if (!on) return;
+    stamp();
+    const unsigned int slot = atomicAdd(&g_diag_p2p_n, 1u);
+    if (slot >= 4096u) return;
+    g_diag_p2p[slot * 16ull] = id;
+    g_diag_p2p[slot * 16ull + 1] = static_cast<unsigned long long>(n);
+    for (int k = 0; k < n; ++k) g_diag_p2p[slot * 16ull + 2 + k] = t[k];
+  }
+};
+#define P2P_DIAG_BEGIN(who) P2pDiag pd; pd.begin(who)
+#define P2P_DIAG_STAMP() pd.stamp()
+#define P2P_DIAG_END(id) pd.end(id)
+#else
+#define P2P_DIAG_BEGIN(who) ((void)0)
+#define P2P_DIAG_STAMP() ((void)0)
+#define P2P_DIAG_END(id) ((void)0)
+#endif
 
 namespace {
 
@@ -91,6 +120,7 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
   const unsigned long long diag_t0 = wall_clock64();
   const unsigned long long diag_c0 = clock64();
 #endif
+  P2P_DIAG_BEGIN(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0);
   // staged.n != 0: this launch IS the staging (stage_jobs_kernel's job, one dependent launch less per small pass): every
   // workgroup takes its descriptor from the kernel arguments, the first one also writes the device tables for the
   // launches behind this one
@@ -156,6 +186,7 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
     lds[0][2][tid] = gz[g];
   }
   __syncthreads();
+  P2P_DIAG_STAMP();  // 1: descriptor, transforms, first tile in LDS
 
   uint32_t cur = 0;
   for (uint32_t tile = tile0; tile < tile1; ++tile) {
@@ -206,6 +237,7 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
   // One key row per split - except in sub_split mode, where the (many, small) workgroups of a point merge into ONE row with
   // an integer atomicMin: the unsigned minimum of (d2 bits, chunk id) is the same whatever the order, and the resolve then
   // reads one key per point instead of one per workgroup (the host clears the row before the launch).
+  P2P_DIAG_STAMP();  // 2: tiles scanned
   const uint32_t out = (J.sub_split > 1 ? 0u : sp * key_stride) + J.out_off + sb * kScanSrcPerBlock + tid;
 #pragma unroll
   for (int p = 0; p < kPointsPerLane; ++p) {
@@ -214,6 +246,7 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_kernel(const JobDesc* _
     if (J.sub_split > 1) atomicMin(&keys[out + p * kBlockThreads], key);
     else keys[out + p * kBlockThreads] = key;
   }
+  P2P_DIAG_END(3ull | (static_cast<unsigned long long>(J.src_n) << 8));
 #ifdef MI355_ICP_DIAG
   if (g_diag_stamps && threadIdx.x == 0) {
     unsigned xcc;
@@ -328,6 +361,7 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
   __shared__ double scratch[kSums ? kBlockThreads / 64 : 1][MI355_ICP_NSUMS];
   __shared__ uint32_t last_flag;
 
+  P2P_DIAG_BEGIN(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0);
   const JobDesc& J = jobs[blockIdx.y];
   const uint32_t sb = kSums ? blockIdx.x : blockIdx.x / kResolvePointsPerLane;
   if (sb >= J.src_blocks) return;
@@ -343,24 +377,41 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
   for (int k = 0; k < MI355_ICP_NSUMS; ++k) acc[k] = 0.0;
 
   const int p_first = kSums ? 0 : static_cast<int>(blockIdx.x % kResolvePointsPerLane);
-  const int p_end = kSums ? kResolvePointsPerLane : p_first + 1;
-#pragma unroll 1
-  for (int p = p_first; p < p_end; ++p) {
+  constexpr int kPts = kSums ? kResolvePointsPerLane : 1;
+  // A point is a chain of dependent reads: its key (one per split) -> the chunk the key names.  The keys and the source
+  // coordinates of ALL the lane's points are read first, side by side - only the chunk reads are left to follow one another -
+  // so the lane waits for 1 + kPts round trips, not 3 kPts: at 1k<->1k that chain IS the launch (phase stamps, round 3).
+  unsigned long long key_of[kPts];
+  float s0x_of[kPts], s0y_of[kPts], s0z_of[kPts];
+#pragma unroll
+  for (int u = 0; u < kPts; ++u) {
+    const uint32_t local = sb * kSrcPerBlock + (p_first + u) * kBlockThreads + tid;
+    const bool there = local < J.src_n;
+    unsigned long long key = ~0ull;
+    for (uint32_t sp = 0; sp < n_split; ++sp) {
+      const unsigned long long k = keys[sp * key_stride + J.out_off + (there ? local : 0u)];
+      key = k < key ? k : key;
+    }
+    key_of[u] = key;
+    const uint32_t i = J.src_off + (there ? local : 0u);
+    s0x_of[u] = sx[i];
+    s0y_of[u] = sy[i];
+    s0z_of[u] = sz[i];
+  }
+  P2P_DIAG_STAMP();  // 1: descriptor read, key and source loads issued
+#pragma unroll
+  for (int u = 0; u < kPts; ++u) {
+    const int p = p_first + u;
     const uint32_t local = sb * kSrcPerBlock + p * kBlockThreads + tid;
     // the scan's padding lanes merge keys as well: the whole span of this workgroup goes back cleared (a job's slots are
     // padded to kSrcPad, a multiple of this kernel's span and of the scan's)
     if (!kSums && J.sub_split > 1 && local >= J.src_n) keys[J.out_off + local] = ~0ull;
     if (local < J.src_n) {
-      unsigned long long key = ~0ull;
-      for (uint32_t sp = 0; sp < n_split; ++sp) {
-        const unsigned long long k = keys[sp * key_stride + J.out_off + local];
-        key = k < key ? k : key;
-      }
+      const unsigned long long key = key_of[u];
       if (!kSums && J.sub_split > 1) keys[J.out_off + local] = ~0ull;
       const uint32_t best_bits = static_cast<uint32_t>(key >> 32);
       const uint32_t chunk = static_cast<uint32_t>(key);
-      const uint32_t i = J.src_off + local;
-      const float s0x = sx[i], s0y = sy[i], s0z = sz[i];
+      const float s0x = s0x_of[u], s0y = s0y_of[u], s0z = s0z_of[u];
       float qx, qy, qz;
       transform_point(pose, s0x, s0y, s0z, qx, qy, qz);
 
@@ -414,8 +465,12 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
     }
   }
 
+  P2P_DIAG_STAMP();  // 2: chunks re-scanned, products accumulated
+  if (!kSums) P2P_DIAG_END(2ull | (static_cast<unsigned long long>(J.src_n) << 8));
   if (kSums) {
     const double r = pass_block_sum<MI355_ICP_NSUMS>(acc, scratch);
+    P2P_DIAG_STAMP();  // 3: block sum
+    P2P_DIAG_END(1ull | (static_cast<unsigned long long>(J.src_n) << 8));
     double* job_rows = partials + static_cast<size_t>(J.partial_off) * MI355_ICP_NSUMS;
     if (!tail.done) {
       if (tid < MI355_ICP_NSUMS) job_rows[static_cast<size_t>(sb) * MI355_ICP_NSUMS + tid] = r;
@@ -1312,6 +1367,21 @@ extern "C" int mi355_icp_diag_begin(size_t n_slots) {
   if (hipMalloc(reinterpret_cast<void**>(&buf), n_slots * 4 * sizeof(unsigned long long)) != hipSuccess) return 1;
   if (hipMemset(buf, 0, n_slots * 4 * sizeof(unsigned long long)) != hipSuccess) return 1;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+extern "C" int mi355_icp_diag_p2p_begin(void) {
+  unsigned long long* buf = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&buf), 4096 * 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (hipMemset(buf, 0, 4096 * 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  const unsigned int zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag_p2p_n), &zero, sizeof(zero)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_p2p), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+extern "C" int mi355_icp_diag_p2p_read(unsigned long long* out, unsigned int* n) {
+  unsigned long long* buf = nullptr;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(&buf, HIP_SYMBOL(g_diag_p2p), sizeof(buf)) != hipSuccess || !buf) return 1;
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(g_diag_p2p_n), sizeof(*n)) != hipSuccess) return 1;
+  return hipMemcpy(out, buf, 4096 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 extern "C" int mi355_icp_diag_read(unsigned long long* out, size_t n_slots) {
   unsigned long long* buf = nullptr;
