@@ -207,6 +207,7 @@ struct mi355_icp_ctx {
   uint32_t* ready_mapped = nullptr;
   uint32_t pass_seq = 0;
   bool error_word_known = false;       // the last pass brought the call's error word along (PassTail::error_flag): no copy needed
+  uint32_t max_sub_split = 32;        // finest cut of a tile for small all-exact launches (a divisor of the 32 chunks of a tile)
   bool want_selected = false;          // this call wants the per-point winner mask written (mi355_icp_reference_pass)
   bool error_flag_clean = true;        // the device word is known to be zero (the last call read it as zero): no fill launch at the next call's start
   uint32_t error_word = 0;
@@ -614,7 +615,7 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
     uint64_t wgs = 0;
     for (const JobDesc& J : plan.jobs) wgs += static_cast<uint64_t>(J.scan_blocks) * J.tgt_tiles;
     uint32_t sub = 1;
-    while (sub < 8 && wgs * sub < 4096) sub *= 2;
+    while (sub < c->max_sub_split && wgs * sub < 4096) sub *= 2;
     if (sub > 1) {
       plan.merged_keys = true;
       plan.max_split = 1;  // key rows: the workgroups of a point merge into one (atomicMin)
@@ -1407,6 +1408,8 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   c->target_blocks_mfma = env_u32("MI355_ICP_TARGET_BLOCKS_MFMA", c->target_blocks_mfma);  // ... or of the matrix-core scan alone
   c->target_blocks_mfma_forced = std::getenv("MI355_ICP_TARGET_BLOCKS") || std::getenv("MI355_ICP_TARGET_BLOCKS_MFMA");  // then for every size
   c->min_tiles_per_split = env_u32("MI355_ICP_MIN_TILES_PER_SPLIT", c->min_tiles_per_split);
+  c->max_sub_split = std::min<uint32_t>(32u, std::max<uint32_t>(1u, env_u32("MI355_ICP_MAX_SUB_SPLIT", c->max_sub_split)));
+  while (c->max_sub_split & (c->max_sub_split - 1)) c->max_sub_split &= c->max_sub_split - 1;  // a power of two
   {
     const char* ss = std::getenv("MI355_ICP_SORT_SOURCES");
     if (ss && std::string(ss) == "0") c->sort_sources = false;
