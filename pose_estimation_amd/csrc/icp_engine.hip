@@ -208,6 +208,7 @@ struct mi355_icp_ctx {
   uint32_t pass_seq = 0;
   bool error_word_known = false;       // the last pass brought the call's error word along (PassTail::error_flag): no copy needed
   uint32_t max_sub_split = 32;        // finest cut of a tile for small all-exact launches (a divisor of the 32 chunks of a tile)
+  uint32_t sub_split_wgs = 2048;      // ... cut finer only while the launch has fewer workgroups than this
   bool want_selected = false;          // this call wants the per-point winner mask written (mi355_icp_reference_pass)
   bool error_flag_clean = true;        // the device word is known to be zero (the last call read it as zero): no fill launch at the next call's start
   uint32_t error_word = 0;
@@ -605,8 +606,8 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   plan.partial_total = static_cast<uint32_t>(partial_off);
   // Small all-exact launches (the coarse pyramid levels of reference mode, small models): even one workgroup per
   // (512 source slots, tile) leaves most of the chip idle while each of them works through 1024 x 512 pairs on one
-  // CU - ~37 us whatever the cloud holds.  Cut every tile into 2, 4 or 8 runs of chunks, one workgroup each, until the
-  // launch has a few thousand of them (6 x 20k<->100k with the reference's parameters: 11 such passes per request).
+  // CU - ~37 us whatever the cloud holds.  Cut every tile into 2, 4 ... 32 runs of chunks, one workgroup each, until the
+  // launch has one or two thousand of them (6 x 20k<->100k with the reference's parameters: 11 such passes per request).
   // The merged key row is handed back cleared by the resolve, which covers ceil(n / kSrcPerBlock) * kSrcPerBlock slots per
   // job; the scan merges into ceil(n / scan_src) * scan_src of them.  Only while a scan workgroup spans no more than a
   // resolve workgroup (2 or 4 points per lane; the A/B knob MI355_ICP_SCAN_PPL=8 spans 2048) is every slot the scan
@@ -615,7 +616,10 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
     uint64_t wgs = 0;
     for (const JobDesc& J : plan.jobs) wgs += static_cast<uint64_t>(J.scan_blocks) * J.tgt_tiles;
     uint32_t sub = 1;
-    while (sub < c->max_sub_split && wgs * sub < 4096) sub *= 2;
+    // measured on the request shape (gpurun_out/subsplit, round 3): up to 16 runs while the launch stays under ~2048
+    // workgroups; the last halving (32 runs of ONE chunk: every workgroup still pays descriptor, transforms and a tile
+    // load for 32 x 512 pairs) only pays for launches that would otherwise not even cover the CUs
+    while (sub < c->max_sub_split && wgs * sub < (sub >= 16 ? c->sub_split_wgs / 4 : c->sub_split_wgs)) sub *= 2;
     if (sub > 1) {
       plan.merged_keys = true;
       plan.max_split = 1;  // key rows: the workgroups of a point merge into one (atomicMin)
@@ -1410,6 +1414,7 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   c->min_tiles_per_split = env_u32("MI355_ICP_MIN_TILES_PER_SPLIT", c->min_tiles_per_split);
   c->max_sub_split = std::min<uint32_t>(32u, std::max<uint32_t>(1u, env_u32("MI355_ICP_MAX_SUB_SPLIT", c->max_sub_split)));
   while (c->max_sub_split & (c->max_sub_split - 1)) c->max_sub_split &= c->max_sub_split - 1;  // a power of two
+  c->sub_split_wgs = std::max<uint32_t>(1u, env_u32("MI355_ICP_SUB_SPLIT_WGS", c->sub_split_wgs));
   {
     const char* ss = std::getenv("MI355_ICP_SORT_SOURCES");
     if (ss && std::string(ss) == "0") c->sort_sources = false;
