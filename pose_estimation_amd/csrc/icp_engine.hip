@@ -269,6 +269,9 @@ struct mi355_icp_ctx {
   bool call_pruned = false;          // this call asked for the pruned scan (MI355_ICP_FLAG_PRUNED_SCAN)
   int xbf16_shape = 0;               // 0: <4 sets, 256 threads> workgroups, 1: <2 sets, 512 threads> (MI355_ICP_XBF16_SHAPE)
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
+  bool plan_debug = false;           // MI355_ICP_PLAN_DEBUG=1: one line per plan on stderr
+  bool split_model = true;           // small matrix-core launches: pick the split that fills whole rounds of resident workgroups (MI355_ICP_SPLIT_MODEL=0: A/B)
+  uint32_t scan_slots = 512;         // matrix-core scan workgroups resident at once: 2 per CU (256 VGPRs x 4 waves each)
   bool level_sort = false;           // MI355_ICP_LEVEL_SORT=1: every pyramid level's sorted copy from a radix sort of its own (A/B)
   bool sort_sources = true;          // matrix-core scan: walk the sources in Morton order (MI355_ICP_SORT_SOURCES=0 turns it off: A/B)
 };
@@ -569,8 +572,30 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   // reference mode: 2.39 -> 2.31 ms per request; 1M<->1M is 0.6 % FASTER with the full count: profiles/r03c_target_blocks.txt)
   const uint64_t mfma_goal = c->target_blocks_mfma_forced || total_pairs >= 5e10 ? c->target_blocks_mfma : std::max<uint32_t>(c->target_blocks_mfma / 4, 1);
   const uint64_t blocks_goal = plan.xfilter && plan.xkind == 3 ? mfma_goal : c->target_blocks;
-  const uint32_t want_split = static_cast<uint32_t>(
+  uint32_t want_split = static_cast<uint32_t>(
       std::max<uint64_t>(1, (blocks_goal + std::max<uint64_t>(total_src_blocks, 1) - 1) / std::max<uint64_t>(total_src_blocks, 1)));
+  // Small matrix-core launches run for one to four rounds of resident workgroups (2 per CU), so the LAST round decides:
+  // 100k<->100k cut in 4 is 784 workgroups = 1.53 rounds of 512, the second round half empty.  Pick the cut that
+  // minimises rounds x (tiles per workgroup + a workgroup's fixed cost of about one tile) instead; any cut is valid
+  // (balanced runs of tiles), and at these sizes the whole operand image sits in every XCD's L2 whichever runs its
+  // workgroups walk, so the XCD rounding below has nothing to protect.
+  bool model_split = false;
+  if (plan.xfilter && plan.xkind == 3 && c->split_model && !c->target_blocks_mfma_forced && total_pairs < 5e10 && total_src_blocks) {
+    uint32_t tiles = 1;
+    for (int k = 0; k < n_jobs; ++k) tiles = std::max(tiles, tgt_clouds[target_ids ? target_ids[k] : 0].padded / kTile);
+    const uint32_t cap = std::max<uint32_t>(1, tiles / std::max<uint32_t>(1, c->min_tiles_per_split));
+    double best_cost = std::numeric_limits<double>::infinity();
+    for (uint32_t s = 1; s <= std::min<uint32_t>(cap, 64); ++s) {
+      const uint64_t rounds = (total_src_blocks * s + c->scan_slots - 1) / c->scan_slots;
+      // per-workgroup time in tiles (+1: prologue and key rows); the last round's stragglers (workgroups differ by how often
+      // their points improve); the resolve merges one more key row per cut.  Coefficients fitted to three shapes on one box
+      // (profiles/r03q_split_model_ab.txt): 100k<->100k, 6 x 20k<->100k, 6 x 20k<->285k
+      const double w = (tiles + s - 1) / s + 1.0;
+      const double cost = static_cast<double>(rounds) * w + 0.1 * w + 0.5 * s;
+      if (cost < best_cost) { best_cost = cost; want_split = s; }
+    }
+    model_split = true;
+  }
   uint64_t out_off = 0, partial_off = 0;
   for (int k = 0; k < n_jobs; ++k) {
     const CloudEntry& S = src_clouds[source_ids ? source_ids[k] : 0];
@@ -588,7 +613,7 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
     uint32_t split = std::min(std::max<uint32_t>(want_split, 1), cap);
     // XCD-aware: workgroups b and b+8 share an XCD (and its L2); with n_split in {1,2,4} or a multiple of 8 they
     // also share the run of target tiles they stream
-    split = xcd_round(split);
+    if (!model_split) split = xcd_round(split);
     J.n_split = split;
     J.split_q = J.tgt_tiles / split;
     J.split_r = J.tgt_tiles % split;
@@ -638,6 +663,10 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
       if (J.tgt_tiles > kPrunedMaxTiles) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "MI355_ICP_SCAN_MODE=pruned: a target cloud has more than 16M points");
 
   if (static_cast<uint64_t>(plan.key_rows()) * plan.out_total > 0xFFFF0000ull) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "batch too large");
+  if (c->plan_debug)
+    std::fprintf(stderr, "mi355_icp plan: %d jobs, %.3g pairs, fused %d xkind %d ppl %d, source blocks %llu, want_split %u%s -> split %u, %u workgroups x %d, sub_split %u\n",
+                 n_jobs, total_pairs, int(plan.fused), plan.xkind, plan.scan_ppl, static_cast<unsigned long long>(total_src_blocks), want_split,
+                 model_split ? " (model)" : "", plan.jobs[0].n_split, plan.max_blocks_x, n_jobs, plan.jobs[0].sub_split);
   return MI355_ICP_OK;
 }
 
@@ -1412,6 +1441,8 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   c->target_blocks_mfma = env_u32("MI355_ICP_TARGET_BLOCKS_MFMA", c->target_blocks_mfma);  // ... or of the matrix-core scan alone
   c->target_blocks_mfma_forced = std::getenv("MI355_ICP_TARGET_BLOCKS") || std::getenv("MI355_ICP_TARGET_BLOCKS_MFMA");  // then for every size
   c->min_tiles_per_split = env_u32("MI355_ICP_MIN_TILES_PER_SPLIT", c->min_tiles_per_split);
+  if (const char* v = std::getenv("MI355_ICP_SPLIT_MODEL")) c->split_model = std::atoi(v) != 0;
+  c->plan_debug = env_u32("MI355_ICP_PLAN_DEBUG", 0) != 0;
   c->max_sub_split = std::min<uint32_t>(32u, std::max<uint32_t>(1u, env_u32("MI355_ICP_MAX_SUB_SPLIT", c->max_sub_split)));
   while (c->max_sub_split & (c->max_sub_split - 1)) c->max_sub_split &= c->max_sub_split - 1;  // a power of two
   c->sub_split_wgs = std::max<uint32_t>(1u, env_u32("MI355_ICP_SUB_SPLIT_WGS", c->sub_split_wgs));
@@ -1425,6 +1456,11 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
     return MI355_ICP_ERR_HIP;
   };
   if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+  {
+    int cus = 0;
+    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id)) != hipSuccess) return bail("hipDeviceGetAttribute", e);
+    if (cus > 0) c->scan_slots = std::max<uint32_t>(1u, env_u32("MI355_ICP_SCAN_SLOTS", 2u * static_cast<uint32_t>(cus)));
+  }
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
   for (auto& ev : c->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
