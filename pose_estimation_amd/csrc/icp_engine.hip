@@ -270,6 +270,7 @@ struct mi355_icp_ctx {
   int xbf16_shape = 0;               // 0: <4 sets, 256 threads> workgroups, 1: <2 sets, 512 threads> (MI355_ICP_XBF16_SHAPE)
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
   bool plan_debug = false;           // MI355_ICP_PLAN_DEBUG=1: one line per plan on stderr
+  double split_model_pairs = 5e10;    // ... below this many pairs per launch (MI355_ICP_SPLIT_MODEL_PAIRS: A/B)
   bool split_model = true;           // small matrix-core launches: pick the split that fills whole rounds of resident workgroups (MI355_ICP_SPLIT_MODEL=0: A/B)
   uint32_t scan_slots = 512;         // matrix-core scan workgroups resident at once: 2 per CU (256 VGPRs x 4 waves each)
   bool level_sort = false;           // MI355_ICP_LEVEL_SORT=1: every pyramid level's sorted copy from a radix sort of its own (A/B)
@@ -580,7 +581,7 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   // (balanced runs of tiles), and at these sizes the whole operand image sits in every XCD's L2 whichever runs its
   // workgroups walk, so the XCD rounding below has nothing to protect.
   bool model_split = false;
-  if (plan.xfilter && plan.xkind == 3 && c->split_model && !c->target_blocks_mfma_forced && total_pairs < 5e10 && total_src_blocks) {
+  if (plan.xfilter && plan.xkind == 3 && c->split_model && !c->target_blocks_mfma_forced && total_pairs < c->split_model_pairs && total_src_blocks) {
     uint32_t tiles = 1;
     for (int k = 0; k < n_jobs; ++k) tiles = std::max(tiles, tgt_clouds[target_ids ? target_ids[k] : 0].padded / kTile);
     const uint32_t cap = std::max<uint32_t>(1, tiles / std::max<uint32_t>(1, c->min_tiles_per_split));
@@ -1442,6 +1443,7 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   c->target_blocks_mfma_forced = std::getenv("MI355_ICP_TARGET_BLOCKS") || std::getenv("MI355_ICP_TARGET_BLOCKS_MFMA");  // then for every size
   c->min_tiles_per_split = env_u32("MI355_ICP_MIN_TILES_PER_SPLIT", c->min_tiles_per_split);
   if (const char* v = std::getenv("MI355_ICP_SPLIT_MODEL")) c->split_model = std::atoi(v) != 0;
+  if (const char* v = std::getenv("MI355_ICP_SPLIT_MODEL_PAIRS")) c->split_model_pairs = std::atof(v);
   c->plan_debug = env_u32("MI355_ICP_PLAN_DEBUG", 0) != 0;
   c->max_sub_split = std::min<uint32_t>(32u, std::max<uint32_t>(1u, env_u32("MI355_ICP_MAX_SUB_SPLIT", c->max_sub_split)));
   while (c->max_sub_split & (c->max_sub_split - 1)) c->max_sub_split &= c->max_sub_split - 1;  // a power of two

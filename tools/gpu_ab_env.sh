@@ -17,7 +17,7 @@ for rep in $(seq 1 ${REPS:-2}); do
     run 120 "$O/lat_${name}_$rep.json" python tools/refmode_latency.py --reps 40
     run 300 "$O/cfg_${name}_$rep.jsonl" python tools/bench_configs.py
     run 300 "$O/ref_${name}_$rep.jsonl" python tools/bench_reference_mode.py
-    run 120 "$O/har_${name}_$rep.txt" ./build/estimate_pose_harness 20000 300000 6 pipeline
+    run 120 "$O/har_${name}_$rep.txt" ./build/estimate_pose_harness ${HARNESS:-20000 300000} 6 pipeline
     python3 - "$O" "$name" "$rep" <<'PY' | tee -a "$O/summary.txt"
 import json, sys
 O, name, rep = sys.argv[1:4]
