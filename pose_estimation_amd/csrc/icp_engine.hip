@@ -269,6 +269,7 @@ struct mi355_icp_ctx {
   bool call_pruned = false;          // this call asked for the pruned scan (MI355_ICP_FLAG_PRUNED_SCAN)
   int xbf16_shape = 0;               // 0: <4 sets, 256 threads> workgroups, 1: <2 sets, 512 threads> (MI355_ICP_XBF16_SHAPE)
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
+  int resolve_wave_points = 0;       // MI355_ICP_RESOLVE_WAVE_POINTS=16|32|64: points per wave of the filter's resolve (0: by launch size)
   bool plan_debug = false;           // MI355_ICP_PLAN_DEBUG=1: one line per plan on stderr
   double split_model_pairs = 5e10;    // ... below this many pairs per launch (MI355_ICP_SPLIT_MODEL_PAIRS: A/B)
   bool split_model = true;           // small matrix-core launches: pick the split that fills whole rounds of resident workgroups (MI355_ICP_SPLIT_MODEL=0: A/B)
@@ -929,7 +930,11 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
     const float* xp = X.planes;
     const size_t st = xstride;
     const bool xb = plan.xkind == 3;
-    launch_resolve_xfilter(c->stream, xb ? kXbRun : kFusedChunk, xb ? 2u : 1u, c->jobs_dev, n_active, sbx, xb ? Sscan : S, xb ? src_perm : nullptr,
+    // points of the launch (padded): the resolve spreads a small launch over more waves, 16 or 32 points each instead of 64 -
+    // a wave's time is one round trip per 8 points (6 x 20k points: 21.6 -> 8.2 us per wave, request 2.03 -> 1.94 ms;
+    // 600k points do best with 32, from a million on the 64-point waves are as fast: profiles/r03q_resolve_wave_points.txt)
+    const int wave_points = c->resolve_wave_points ? c->resolve_wave_points : (plan.out_total <= 300000u ? 16 : plan.out_total <= 1500000u ? 32 : 64);
+    launch_resolve_xfilter(c->stream, xb ? kXbRun : kFusedChunk, xb ? 2u : 1u, wave_points, c->jobs_dev, n_active, sbx, xb ? Sscan : S, xb ? src_perm : nullptr,
                            DevicePlanes{xp + 4 * st, xp + 5 * st, xp + 6 * st}, X.perm,
                            c->keys3, plan.out_total, rank_stride, c->out_index, c->out_dist2, c->overflow_list, c->overflow_count,
                            c->error_flag);
@@ -1445,6 +1450,10 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   if (const char* v = std::getenv("MI355_ICP_SPLIT_MODEL")) c->split_model = std::atoi(v) != 0;
   if (const char* v = std::getenv("MI355_ICP_SPLIT_MODEL_PAIRS")) c->split_model_pairs = std::atof(v);
   c->plan_debug = env_u32("MI355_ICP_PLAN_DEBUG", 0) != 0;
+  {
+    const uint32_t wp = env_u32("MI355_ICP_RESOLVE_WAVE_POINTS", 0);
+    if (wp == 16 || wp == 32 || wp == 64) c->resolve_wave_points = static_cast<int>(wp);
+  }
   c->max_sub_split = std::min<uint32_t>(32u, std::max<uint32_t>(1u, env_u32("MI355_ICP_MAX_SUB_SPLIT", c->max_sub_split)));
   while (c->max_sub_split & (c->max_sub_split - 1)) c->max_sub_split &= c->max_sub_split - 1;  // a power of two
   c->sub_split_wgs = std::max<uint32_t>(1u, env_u32("MI355_ICP_SUB_SPLIT_WGS", c->sub_split_wgs));

@@ -373,7 +373,8 @@ void launch_nn_scan_xbf16_dump(void* stream, const JobDesc* jobs_dev, uint32_t b
 // run_len: targets per remembered granule (kFusedChunk, or kXbRun with two key rows per split: split_mul = 2)
 // src_perm != nullptr: `src` is a Morton-ordered copy (position -> original index in src_perm); results and overflow ids
 // are written at original indices
-void launch_resolve_xfilter(void* stream, int run_len, uint32_t split_mul, const JobDesc* jobs_dev, int n_jobs,
+// wave_points: 64, 32 or 16 points per wave (matrix-core filter only; small launches spread over more waves)
+void launch_resolve_xfilter(void* stream, int run_len, uint32_t split_mul, int wave_points, const JobDesc* jobs_dev, int n_jobs,
                             uint32_t max_src_blocks, DevicePlanes src, const uint32_t* src_perm, DevicePlanes sorted_original, const uint32_t* perm,
                             const unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride, int32_t* out_index,
                             float* out_dist2, uint32_t* overflow_list, uint32_t* overflow_count, uint32_t* error_flag);

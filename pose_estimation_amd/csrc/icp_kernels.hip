@@ -69,10 +69,12 @@ struct P2pDiag {
 };
 #define P2P_DIAG_BEGIN(who) P2pDiag pd; pd.begin(who)
 #define P2P_DIAG_STAMP() pd.stamp()
+#define P2P_DIAG_STAMP_WAIT() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pd.stamp(); } while (0)  // loads landed
 #define P2P_DIAG_END(id) pd.end(id)
 #else
 #define P2P_DIAG_BEGIN(who) ((void)0)
 #define P2P_DIAG_STAMP() ((void)0)
+#define P2P_DIAG_STAMP_WAIT() ((void)0)
 #define P2P_DIAG_END(id) ((void)0)
 #endif
 
@@ -636,7 +638,12 @@ __device__ __forceinline__ uint32_t wave_min8_of(uint32_t r, int k) {  // k: com
   return __builtin_amdgcn_readlane(r, ((k >> 2) & 1) | (((k >> 1) & 1) << 1) | ((k & 1) << 2));
 }
 
-template <int kRun>  // targets per remembered granule: kFusedChunk (VALU filter) or kXbRun (matrix-core filter)
+// kRun: targets per remembered granule, kFusedChunk (VALU filter) or kXbRun (matrix-core filter).
+// kWavePoints: points per wave (lanes past it idle through the key merge and lend a hand in the granule scans).  A wave
+// works through its points kStep at a time, each step one dependent round trip to the caches: 64 points are 8 trips
+// (~2.2 us each: tools/p2p_kernel_phases.py).  A launch too small to fill the chip with 64-point waves (a request's
+// candidates: 30k-120k points = 0.5-2 waves per SIMD) takes 16 or 32 points per wave on 4 or 2 times the waves instead.
+template <int kRun, int kWavePoints = 64>
 __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
     const JobDesc* __restrict__ jobs, uint32_t split_mul, const float* __restrict__ sx, const float* __restrict__ sy,
     const float* __restrict__ sz, const uint32_t* __restrict__ src_perm, const float* __restrict__ sox, const float* __restrict__ soy,
@@ -644,16 +651,19 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
     uint32_t key_stride, uint32_t rank_stride, int32_t* __restrict__ out_index, float* __restrict__ out_dist2,
     uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ overflow_count) {
   static_assert(kRun % 64 == 0, "a granule is read 64 targets at a time");
+  static_assert(kWavePoints == 64 || kWavePoints == 32 || kWavePoints == 16, "points per wave");
+  constexpr uint32_t kBlockPoints = kBlockThreads / 64 * kWavePoints;
   const JobDesc& J = jobs[blockIdx.y];
-  if (blockIdx.x * kBlockThreads >= J.src_n) return;  // grid.x covers the largest job in groups of 256 points
+  if (blockIdx.x * kBlockPoints >= J.src_n) return;  // grid.x covers the largest job in groups of kBlockPoints points
   float pose[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
   const uint32_t n_rows = J.n_split * split_mul;  // key rows: one per split (two for the matrix-core filter's wave halves)
   const uint32_t lane = threadIdx.x & 63u;
+  P2P_DIAG_BEGIN(blockIdx.x % 16 == 0 && blockIdx.y == 0 && threadIdx.x == 0);
   {
-    const uint32_t local = blockIdx.x * kBlockThreads + threadIdx.x;
-    const bool valid = local < J.src_n;
+    const uint32_t local = blockIdx.x * kBlockPoints + (threadIdx.x >> 6) * kWavePoints + lane;
+    const bool valid = lane < static_cast<uint32_t>(kWavePoints) && local < J.src_n;
     unsigned long long k1 = ~0ull, k2 = ~0ull, k3 = ~0ull;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (valid) {
@@ -752,6 +762,7 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
     // 16 points per step, and 16 or 32 points per wave on more waves - neither moved the request latency.)
     constexpr int kStep = kRun >= 128 ? 8 : 4;
     unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+    P2P_DIAG_STAMP_WAIT();  // 1: key rows merged, point transformed
     while (todo) {
       int s[kStep];
       bool real[kStep];
@@ -772,6 +783,10 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
     }
     // Phase B: the points whose second granule could still hold the minimum or a tie (a few per cent)
     todo = __builtin_amdgcn_ballot_w64(valid && L2 <= __uint_as_float(res_d));
+    P2P_DIAG_STAMP();  // 2: first granules
+#ifdef MI355_ICP_DIAG
+    const unsigned long long diag_second = __builtin_popcountll(todo);
+#endif
     while (todo) {
       const int s = __builtin_ctzll(todo);
       todo &= todo - 1;
@@ -782,6 +797,8 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
         res_j = uj;
       }
     }
+    P2P_DIAG_STAMP();  // 3: second granules
+    P2P_DIAG_END(4ull | (static_cast<unsigned long long>(J.src_n) << 8) | (diag_second << 40) | (static_cast<unsigned long long>(n_rows) << 48));
     if (!valid) return;
     // `local` is a position in the (possibly Morton-ordered) source planes the scan walked; answers go to the point's own slot
     const uint32_t orig = src_perm ? src_perm[J.src_off + local] : local;
@@ -1402,20 +1419,24 @@ void launch_resolve_fused(void* stream, const JobDesc* jobs_dev, int n_jobs, uin
                      overflow_count, error_flag);
 }
 
-void launch_resolve_xfilter(void* stream, int run_len, uint32_t split_mul, const JobDesc* jobs_dev, int n_jobs,
+void launch_resolve_xfilter(void* stream, int run_len, uint32_t split_mul, int wave_points, const JobDesc* jobs_dev, int n_jobs,
                             uint32_t max_src_blocks, DevicePlanes src, const uint32_t* src_perm, DevicePlanes sorted_original, const uint32_t* perm,
                             const unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride, int32_t* out_index,
                             float* out_dist2, uint32_t* overflow_list, uint32_t* overflow_count, uint32_t* error_flag) {
-  dim3 grid(max_src_blocks * kResolvePointsPerLane, static_cast<uint32_t>(n_jobs));  // one workgroup per 256 points
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (run_len == kXbRun)
-    hipLaunchKernelGGL(resolve_xfilter_kernel<kXbRun>, grid, dim3(kBlockThreads), 0, st, jobs_dev, split_mul, src.x, src.y, src.z, src_perm,
-                       sorted_original.x, sorted_original.y, sorted_original.z, perm, keys4, key_stride, rank_stride, out_index,
-                       out_dist2, overflow_list, overflow_count);
-  else
-    hipLaunchKernelGGL(resolve_xfilter_kernel<kFusedChunk>, grid, dim3(kBlockThreads), 0, st, jobs_dev, split_mul, src.x, src.y,
-                       src.z, src_perm, sorted_original.x, sorted_original.y, sorted_original.z, perm, keys4, key_stride, rank_stride,
+  const uint32_t groups = max_src_blocks * kResolvePointsPerLane;  // 256-point groups of the largest job
+  auto go = [&](auto kernel, uint32_t per_group) {
+    hipLaunchKernelGGL(kernel, dim3(groups * per_group, static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0, st, jobs_dev, split_mul, src.x,
+                       src.y, src.z, src_perm, sorted_original.x, sorted_original.y, sorted_original.z, perm, keys4, key_stride, rank_stride,
                        out_index, out_dist2, overflow_list, overflow_count);
+  };
+  if (run_len == kXbRun) {
+    if (wave_points == 16) go(resolve_xfilter_kernel<kXbRun, 16>, 4);
+    else if (wave_points == 32) go(resolve_xfilter_kernel<kXbRun, 32>, 2);
+    else go(resolve_xfilter_kernel<kXbRun, 64>, 1);
+  } else {
+    go(resolve_xfilter_kernel<kFusedChunk, 64>, 1);
+  }
   (void)error_flag;  // a point with no finite distance goes to the all-exact scan, which raises the flag
 }
 

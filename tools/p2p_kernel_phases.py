@@ -17,7 +17,8 @@ lib = pa._lib.lib
 lib.mi355_icp_diag_p2p_read.argtypes = [C.c_void_p, C.c_void_p]
 names = {1: ("resolve_accumulate<sums>", ["descr + key/src loads issued", "chunks + products", "block sum", "end"]),
          2: ("resolve_accumulate<idx>", ["descr + key/src loads issued", "chunk", "end"]),
-         3: ("nn_scan_kernel (block 0)", ["descr, transforms, tile 0", "tiles scanned", "keys out"])}
+         3: ("nn_scan_kernel (block 0)", ["descr, transforms, tile 0", "tiles scanned", "keys out"]),
+         4: ("resolve_xfilter (wave 0 of every 16th block)", ["descr, key rows, transform", "first granules", "second granules", "end"])}
 
 
 def dump(title):
@@ -25,13 +26,19 @@ def dump(title):
     n = C.c_uint(0)
     assert lib.mi355_icp_diag_p2p_read(buf.ctypes.data, C.byref(n)) == 0
     print(f"--- {title}: {n.value} records")
-    for r in buf[:min(n.value, 60)]:
-        kid, npts = int(r[0]) & 0xFF, (int(r[0]) >> 8)
+    groups = {}
+    for r in buf[:min(n.value, 4096)]:
+        kid, npts = int(r[0]) & 0xFF, (int(r[0]) >> 8) & 0xFFFFFFFF
+        extra = (int(r[0]) >> 40) & 0xFF, int(r[0]) >> 48
         cnt = int(r[1])
         t = r[2:2 + cnt].astype(np.int64)
-        d = np.diff(t) / 100.0
+        groups.setdefault((kid, npts, extra[1]), []).append((np.diff(t) / 100.0, extra[0]))
+    for (kid, npts, rows), recs in sorted(groups.items()):
         nm, ph = names[kid]
-        print(f"{nm:26s} n={npts:6d}  total {((t[-1] - t[0]) / 100.0):6.2f} us | " + "  ".join(f"{p} {x:5.2f}" for p, x in zip(ph, d)))
+        d = np.median(np.stack([x for x, _ in recs]), axis=0)
+        mx = np.max(np.stack([x for x, _ in recs]), axis=0)
+        more = f"  key rows {rows}, second-granule points per wave median {np.median([e for _, e in recs]):.0f} max {max(e for _, e in recs)}" if kid == 4 else ""
+        print(f"{nm:26s} n={npts:6d} x{len(recs):4d}  total {d.sum():6.2f} us (max {mx.sum():6.2f}) | " + "  ".join(f"{p} {x:5.2f} (max {m:5.2f})" for p, x, m in zip(ph, d, mx)) + more)
 
 
 src, tgt, gt = st.make_pair(pa.synth_cloud, 1000, 1000)
