@@ -758,8 +758,8 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_xfilter_kernel(
     // memory round trips: 0.15 ms at any size).  A step with fewer than kStep points left repeats its first one.
     // kStep = 8 for the 128-target granule of the matrix-core filter: 8 x 2 x 4 loads in flight per lane, 8 round trips
     // per wave (6 x 20k points against 100k targets: 48 -> ~30 us; the 64-target granule keeps 4 x 1 x 4).
-    // (Tried in round 2 for the small launches of reference mode, where this kernel lasts ~28 us whatever the point count:
-    // 16 points per step, and 16 or 32 points per wave on more waves - neither moved the request latency.)
+    // (16 points per step did not help in round 2.  Fewer points per wave on more waves - kWavePoints - does: round 2 tried it
+    // while the key-row chain above still dominated the kernel and saw nothing; round 3's phase stamps showed 2.2 us per step.)
     constexpr int kStep = kRun >= 128 ? 8 : 4;
     unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
     P2P_DIAG_STAMP_WAIT();  // 1: key rows merged, point transformed

@@ -7,8 +7,10 @@
 // winners; sums in double).  Compile with -ffp-contract=off like icp_kernels.hip.
 //
 //   subsample_kernel          level planes:  out[i] = in[i * step], padded
-//   rejection_select_kernel   per job, ONE workgroup: exact rank select (3-pass 11/11/10-bit radix on the
-//                             float bits, LDS histograms) of d2, then of |d2 - med|  ->  threshold
+//   rejection_select_reg_kernel  per job, ONE workgroup, values in registers (jobs of up to 32k points): exact rank
+//                             select (11-bit radix digits from the highest bit that differs, LDS histograms, the last
+//                             <= 256 candidates ranked by counting) of d2, then of |d2 - med|  ->  threshold
+//   rejection_select_kernel   the same with the values in LDS / global memory (3-pass 11/11/10-bit radix), up to 64k points
 //   select_hist/pick_kernel   the same selection across many workgroups, for jobs of >= 64k points
 //   picky_scatter_kernel      accepted pairs: atomicMin(owner[target], d2 bits << 32 | source index)
 //   ref_accumulate_kernel     winners: 21 + 6 normal-equation sums, sum |p-q|^2, count (29 doubles)
@@ -46,10 +48,14 @@ struct RefDiag {
 #define REF_DIAG_BEGIN(who) RefDiag rd; rd.begin(who)
 #define REF_DIAG_STAMP() rd.stamp()
 #define REF_DIAG_END(id) rd.end(id)
+#define REF_DIAG_ARG , RefDiag& rd
+#define REF_DIAG_PASS , rd
 #else
 #define REF_DIAG_BEGIN(who) ((void)0)
 #define REF_DIAG_STAMP() ((void)0)
 #define REF_DIAG_END(id) ((void)0)
+#define REF_DIAG_ARG
+#define REF_DIAG_PASS
 #endif
 
 namespace {
@@ -91,7 +97,7 @@ constexpr int kSelThreads = 1024;
 // and after the second anywhere (22 of 32 bits fixed).
 template <typename F>
 __device__ uint32_t radix_select(uint32_t n, uint32_t k, uint32_t* hist /* 2048 */, uint32_t* bcast /* 3 */,
-                                 uint32_t* wave_tot /* 16 */, uint32_t* cand /* 64 */, uint32_t* cand_n, F value_of) {
+                                 uint32_t* wave_tot /* 16 */, uint32_t* cand /* 64 */, uint32_t* cand_n, F value_of REF_DIAG_ARG) {
   uint32_t prefix = 0, mask = 0;
   const int shifts[3] = {21, 10, 0};
   const int widths[3] = {11, 11, 10};
@@ -107,6 +113,7 @@ __device__ uint32_t radix_select(uint32_t n, uint32_t k, uint32_t* hist /* 2048 
       if ((bits & mask) == prefix) atomicAdd(&hist[(bits >> shift) & (nb - 1)], 1u);
     }
     __syncthreads();
+    REF_DIAG_STAMP();  // histogram walk
     // Which digit holds rank k?  Parallel scan over the 2048 bins (2 per thread): wave64 shuffle scan, wave totals
     // through LDS.  (A serial walk by one lane costs ~100 us per pass: one dependent LDS read per bin.)
     {
@@ -137,12 +144,14 @@ __device__ uint32_t radix_select(uint32_t n, uint32_t k, uint32_t* hist /* 2048 
     k = bcast[1];
     const uint32_t in_bin = bcast[2];
     __syncthreads();
+    REF_DIAG_STAMP();  // bin scan
     if (pass < 2 && in_bin <= 64u) {  // wave-uniform: everyone read the same words
       for (uint32_t i = threadIdx.x; i < n; i += kSelThreads) {
         const uint32_t bits = __float_as_uint(value_of(i));
         if ((bits & mask) == prefix) cand[atomicAdd(cand_n, 1u)] = bits;  // exactly in_bin appends
       }
       __syncthreads();
+      REF_DIAG_STAMP();  // candidates collected
       if (threadIdx.x < 64) {
         const uint32_t c = threadIdx.x < in_bin ? cand[threadIdx.x] : 0xFFFFFFFFu;
         uint32_t less = 0, leq = 0;
@@ -194,12 +203,12 @@ __global__ __launch_bounds__(kSelThreads) void rejection_select_kernel(const Job
   __syncthreads();
   REF_DIAG_STAMP();  // 1: distances in LDS
   const uint32_t k = (n - 1) / 2;
-  const float med = __uint_as_float(radix_select(n, k, hist, bcast, wave_tot, cand, &cand_n, [&](uint32_t i) { return i < cached ? cache[i] : d[i]; }));
+  const float med = __uint_as_float(radix_select(n, k, hist, bcast, wave_tot, cand, &cand_n, [&](uint32_t i) { return i < cached ? cache[i] : d[i]; } REF_DIAG_PASS));
   REF_DIAG_STAMP();  // 2: median
   const float mad = __uint_as_float(radix_select(n, k, hist, bcast, wave_tot, cand, &cand_n, [&](uint32_t i) {
     const float v = i < cached ? cache[i] : d[i];
     return static_cast<float>(__builtin_fabs(static_cast<double>(v) - static_cast<double>(med)));
-  }));
+  } REF_DIAG_PASS));
   REF_DIAG_STAMP();  // 3: MAD
   if (threadIdx.x == 0) {
     const float s = 1.48257968f * mad;
@@ -218,6 +227,185 @@ __global__ __launch_bounds__(kSelThreads) void rejection_select_kernel(const Job
   for (uint32_t i = threadIdx.x; i < n; i += kSelThreads) {
     const float v = i < cached ? cache[i] : d[i];
     if (v < t) atomicMin(&owner[RJ.owner_off + static_cast<uint32_t>(idx[i])], picky_key(RJ.owner_prefix, v, RJ.src_index_base + i));
+  }
+  REF_DIAG_END(2ull | (static_cast<unsigned long long>(n) << 8));
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same selection with the job's values in REGISTERS (jobs of up to kVpt x 1024 points: the coarse and middle pyramid
+// levels and a request's model at full resolution).  Phase stamps of the kernel above at 20k values (round 3,
+// tools/ref_kernel_phases.py): every walk over the LDS copy - a loop of dependent LDS reads - costs 2-4 us and a select
+// makes three of them, its first histogram walk on a digit (sign, exponent, two mantissa bits) that puts half the values in
+// two or three bins.  Here a walk is an unrolled run over kVpt registers; the first digit starts at the highest bit in which
+// the job's smallest and largest value DIFFER (their common prefix decides nothing), which spreads 20k squared distances over
+// hundreds of bins; up to 256 values left in the chosen bin are ranked against each other by counting, all 1024 threads
+// sharing the comparisons.  The selected element is the same one - the value of rank k in unsigned order of the bits.
+constexpr uint32_t kSelCand = 256;
+
+struct SelectShared {
+  uint32_t hist[2048];
+  uint32_t bcast[2][3];
+  uint32_t wave_lo[kSelThreads / 64], wave_hi[kSelThreads / 64], wave_tot[kSelThreads / 64];
+  uint32_t cand[kSelCand];
+  uint32_t cand_n;
+  uint32_t answer;
+};
+
+// hist[] all zero and cand_n == 0 on entry and on return.  v[j] belongs to element threadIdx.x + j * kSelThreads (< n).
+// [lo, hi] (the same words in every thread) encloses the values, and every value has lo's bits above the highest bit in which
+// lo and hi differ: the exact smallest and largest value do, and so does (0, largest value).
+template <int kVpt>
+__device__ uint32_t register_select(const uint32_t (&v)[kVpt], uint32_t n, uint32_t k, uint32_t lo, uint32_t hi, SelectShared& S REF_DIAG_ARG) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (lo == hi) return lo;  // (block-uniform) one distinct value
+  int undecided = 32 - __builtin_clz(lo ^ hi);                                   // bits [undecided - 1, 0] can differ
+  uint32_t mask = undecided >= 32 ? 0u : ~((1u << undecided) - 1u), prefix = lo & mask;  // the bits above them: common to all
+  int parity = 0;
+#pragma unroll 1
+  while (true) {
+    const int width = undecided < 11 ? undecided : 11, shift = undecided - width;
+    const uint32_t digits = (1u << width) - 1u;
+#pragma unroll
+    for (int j = 0; j < kVpt; ++j)
+      if (tid + j * kSelThreads < n && (v[j] & mask) == prefix) atomicAdd(&S.hist[(v[j] >> shift) & digits], 1u);
+    __syncthreads();
+    REF_DIAG_STAMP();  // histogram
+    // which digit holds rank k: scan over the 2048 bins, two per thread (cleared on the way for the next user)
+    const uint32_t c0 = S.hist[2 * tid], c1 = S.hist[2 * tid + 1];
+    S.hist[2 * tid] = 0;
+    S.hist[2 * tid + 1] = 0;
+    const uint32_t mine = c0 + c1;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = __shfl_up(incl, off, 64);
+      if (lane >= static_cast<uint32_t>(off)) incl += up;
+    }
+    if (lane == 63) S.wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int w = 0; w < kSelThreads / 64; ++w) base += static_cast<uint32_t>(w) < wave ? S.wave_tot[w] : 0u;
+    const uint32_t excl = base + incl - mine;
+    if (mine && k >= excl && k < excl + mine) {  // exactly one thread
+      const bool second = k >= excl + c0;
+      S.bcast[parity][0] = 2 * tid + (second ? 1u : 0u);
+      S.bcast[parity][1] = k - excl - (second ? c0 : 0u);
+      S.bcast[parity][2] = second ? c1 : c0;  // values in the chosen bin
+    }
+    __syncthreads();
+    prefix |= S.bcast[parity][0] << shift;
+    mask |= digits << shift;
+    k = S.bcast[parity][1];
+    const uint32_t in_bin = S.bcast[parity][2];
+    parity ^= 1;  // the next pass writes the other triple: no barrier needed between this read and that write
+    undecided = shift;
+    REF_DIAG_STAMP();  // bin found
+    if (undecided == 0) return prefix;  // (block-uniform, like every branch here: all threads read the same words)
+    if (in_bin <= kSelCand) {
+#pragma unroll
+      for (int j = 0; j < kVpt; ++j)
+        if (tid + j * kSelThreads < n && (v[j] & mask) == prefix) S.cand[atomicAdd(&S.cand_n, 1u)] = v[j];  // exactly in_bin appends
+      __syncthreads();
+      // candidate c = tid / 4 against every fourth candidate from tid % 4 on; the four partial counts meet in neighbouring lanes
+      const uint32_t c = tid >> 2, q = tid & 3u;
+      const uint32_t mine_v = c < in_bin ? S.cand[c] : 0xFFFFFFFFu;
+      uint32_t less = 0, leq = 0;
+      for (uint32_t j = q; j < in_bin; j += 4) {
+        const uint32_t cj = S.cand[j];
+        less += cj < mine_v ? 1u : 0u;
+        leq += cj <= mine_v ? 1u : 0u;
+      }
+      less += __shfl_xor(less, 1, 64);
+      leq += __shfl_xor(leq, 1, 64);
+      less += __shfl_xor(less, 2, 64);
+      leq += __shfl_xor(leq, 2, 64);
+      if (q == 0 && c < in_bin && less <= k && k < leq) S.answer = mine_v;  // equal values all qualify and write the same bits
+      if (tid == 0) S.cand_n = 0;
+      __syncthreads();
+      REF_DIAG_STAMP();  // candidates ranked
+      return S.answer;
+    }
+  }
+}
+
+// grid = n_jobs, block = kSelThreads; every job of the launch has at most kVpt * kSelThreads points.
+template <int kVpt>
+__global__ __launch_bounds__(kSelThreads) void rejection_select_reg_kernel(const JobDesc* __restrict__ jobs, const float* __restrict__ dist2,
+                                                                            float scale, float* __restrict__ thr_out,
+                                                                            const RefJobDesc* __restrict__ rjobs, const int32_t* __restrict__ index,
+                                                                            unsigned long long* __restrict__ owner) {
+  __shared__ SelectShared S;
+  REF_DIAG_BEGIN(blockIdx.x == 0 && threadIdx.x == 0);
+  const JobDesc& J = jobs[blockIdx.x];
+  const uint32_t n = J.src_n, tid = threadIdx.x;
+  if (n == 0) {
+    if (tid == 0) thr_out[blockIdx.x] = __builtin_inff();
+    return;
+  }
+  const float* __restrict__ d = dist2 + J.out_off;
+  uint32_t v[kVpt];
+#pragma unroll
+  for (int j = 0; j < kVpt; ++j) {
+    const uint32_t i = tid + j * kSelThreads;
+    v[j] = i < n ? __float_as_uint(d[i]) : 0xFFFFFFFFu;
+  }
+  S.hist[2 * tid] = 0;
+  S.hist[2 * tid + 1] = 0;
+  if (tid == 0) S.cand_n = 0;
+  // smallest and largest distance of the job (the selections start at the highest bit in which they differ)
+  uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+  for (int j = 0; j < kVpt; ++j)
+    if (tid + j * kSelThreads < n) {
+      lo = v[j] < lo ? v[j] : lo;
+      hi = v[j] > hi ? v[j] : hi;
+    }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
+    lo = a < lo ? a : lo;
+    hi = b > hi ? b : hi;
+  }
+  if ((tid & 63u) == 0) {
+    S.wave_lo[tid >> 6] = lo;
+    S.wave_hi[tid >> 6] = hi;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < kSelThreads / 64; ++w) {
+    const uint32_t a = S.wave_lo[w], b = S.wave_hi[w];
+    lo = a < lo ? a : lo;
+    hi = b > hi ? b : hi;
+  }
+  REF_DIAG_STAMP();  // 1: distances in registers, their range known
+  const uint32_t k = (n - 1) / 2;
+  const float med = __uint_as_float(register_select<kVpt>(v, n, k, lo, hi, S REF_DIAG_PASS));
+  __syncthreads();  // the second selection reuses the words the first one's last readers may still be reading
+  auto deviation = [&](uint32_t bits) {
+    return __float_as_uint(static_cast<float>(__builtin_fabs(static_cast<double>(__uint_as_float(bits)) - static_cast<double>(med))));
+  };
+  uint32_t dev[kVpt];
+#pragma unroll
+  for (int j = 0; j < kVpt; ++j) dev[j] = deviation(v[j]);
+  // the largest deviation is the smallest or the largest distance's (the rounded difference is monotone in |d2 - med|)
+  const uint32_t dev_lo = deviation(lo), dev_hi = deviation(hi);
+  const float mad = __uint_as_float(register_select<kVpt>(dev, n, k, 0u, dev_lo > dev_hi ? dev_lo : dev_hi, S REF_DIAG_PASS));
+  const float mad_s = 1.48257968f * mad;  // every thread: the same float32 operations on the same operands, as the kernel above
+  const float mad_t = scale * mad_s;
+  const float t = mad_t + med;
+  if (tid == 0) thr_out[blockIdx.x] = t;
+  if (!owner) {
+    REF_DIAG_END(1ull | (static_cast<unsigned long long>(n) << 8));
+    return;
+  }
+  const RefJobDesc& RJ = rjobs[blockIdx.x];
+  const int32_t* __restrict__ idx = index + J.out_off;
+#pragma unroll
+  for (int j = 0; j < kVpt; ++j) {
+    const uint32_t i = tid + j * kSelThreads;
+    const float val = __uint_as_float(v[j]);
+    if (i < n && val < t) atomicMin(&owner[RJ.owner_off + static_cast<uint32_t>(idx[i])], picky_key(RJ.owner_prefix, val, RJ.src_index_base + i));
   }
   REF_DIAG_END(2ull | (static_cast<unsigned long long>(n) << 8));
 }
@@ -495,6 +683,19 @@ bool launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, 
                              float* thr, uint32_t* hists, uint32_t* states, const RefJobDesc* rjobs_dev, const int32_t* index,
                              unsigned long long* owner) {
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (max_n <= 32u * kSelThreads) {  // the jobs' values fit the registers of one workgroup each
+    // one workgroup offering 20k pairs takes longer than the launch it saves (26 + 7 -> 58 us); a few thousand do not
+    const bool scatter = rjobs_dev && index && owner && max_n <= 4096u;
+    auto go = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(n_jobs)), dim3(kSelThreads), 0, st, jobs_dev, dist2, scale, thr, rjobs_dev, index,
+                         scatter ? owner : nullptr);
+    };
+    if (max_n <= 4u * kSelThreads) go(rejection_select_reg_kernel<4>);
+    else if (max_n <= 8u * kSelThreads) go(rejection_select_reg_kernel<8>);
+    else if (max_n <= 20u * kSelThreads) go(rejection_select_reg_kernel<20>);
+    else go(rejection_select_reg_kernel<32>);
+    return scatter;
+  }
   if (max_n < 65536u || !hists) {
     static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(rejection_select_kernel),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;

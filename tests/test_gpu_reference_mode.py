@@ -20,7 +20,8 @@ def pair6(ns, nt, k=-1):
     return src, tgt, np.linalg.inv(T)
 
 
-@pytest.mark.parametrize("ns,nt", [(3000, 2500), (1337, 777), (40000, 30000), (5000, 100)])
+# sizes: every register blocking of the one-workgroup selection (4, 8, 20, 32 values per thread) and the LDS kernel above them
+@pytest.mark.parametrize("ns,nt", [(3000, 2500), (1337, 777), (40000, 30000), (5000, 100), (25000, 9000), (18000, 4000)])
 def test_reference_pass_matches_oracle(engine, ns, nt):
     src, tgt, gt = pair6(ns, nt)
     engine.set_targets([tgt])
@@ -40,6 +41,24 @@ def test_reference_pass_matches_oracle(engine, ns, nt):
             assert np.array_equal(sel, sel_o)
             assert sums[28] == n_o
             np.testing.assert_allclose(sums, s_o, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("distinct,n", [(1, 3000), (7, 5000), (300, 9000), (2, 64), (5000, 21000)])
+def test_rejection_threshold_with_repeated_distances(engine, distinct, n):
+    """The rank selection's corner cases: one distinct distance (nothing to select), a handful of values with hundreds of copies
+    each (the chosen radix bin never gets small: the selection runs to the last bit), a few hundred (ranked by counting), all
+    against the oracle's sort-based median."""
+    src, tgt, gt = pair6(distinct, 2000)
+    src = np.ascontiguousarray(np.tile(src, (n // distinct + 1, 1))[:n])
+    engine.set_targets([tgt])
+    engine.set_sources([src])
+    start = st.rigid_transform(0.7, (0.1, 1, 0.3), (0.004, 0.001, -0.002))
+    for scale in (2.5, 0.0):
+        idx, d2, sel, thr, sums = engine.reference_pass(start, start, 0, scale)
+        n_o, s_o, idx_o, d2_o, sel_o, thr_o = ora.ref_pass(src, tgt, start, start, scale, nthreads=ora.max_threads())
+        assert np.array_equal(idx, idx_o) and np.array_equal(d2.view(np.uint32), d2_o.view(np.uint32))
+        assert np.float32(thr).view(np.uint32) == np.float32(thr_o).view(np.uint32)
+        assert np.array_equal(sel, sel_o) and sums[28] == n_o
 
 
 def test_align_reference_matches_oracle_with_the_reference_parameters(engine):

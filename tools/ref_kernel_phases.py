@@ -38,4 +38,7 @@ for r in buf[:min(n.value, 4096)]:
     t = r[2:2 + cnt].astype(np.int64)
     d = np.diff(t) / 100.0
     nm, ph = names[kid]
+    if len(d) != len(ph):  # the select kernels stamp inside their radix passes too (histogram walk, bin scan, candidates): print them raw
+        print(f"{nm:26s} n={npts:6d} blocks={nblk:3d}  total {((t[-1] - t[0]) / 100.0):6.2f} us | stamps " + " ".join(f"{x:5.2f}" for x in d))
+        continue
     print(f"{nm:26s} n={npts:6d} blocks={nblk:3d}  total {((t[-1] - t[0]) / 100.0):6.2f} us | " + "  ".join(f"{p} {x:5.2f}" for p, x in zip(ph, d)))
