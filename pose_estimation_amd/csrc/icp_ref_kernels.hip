@@ -47,12 +47,14 @@ struct RefDiag {
 };
 #define REF_DIAG_BEGIN(who) RefDiag rd; rd.begin(who)
 #define REF_DIAG_STAMP() rd.stamp()
+#define REF_DIAG_STAMP_WAIT() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); rd.stamp(); } while (0)  // loads landed
 #define REF_DIAG_END(id) rd.end(id)
 #define REF_DIAG_ARG , RefDiag& rd
 #define REF_DIAG_PASS , rd
 #else
 #define REF_DIAG_BEGIN(who) ((void)0)
 #define REF_DIAG_STAMP() ((void)0)
+#define REF_DIAG_STAMP_WAIT() ((void)0)
 #define REF_DIAG_END(id) ((void)0)
 #define REF_DIAG_ARG
 #define REF_DIAG_PASS
@@ -589,24 +591,32 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
     dd[p] = dist2[at];
     jt[p] = static_cast<uint32_t>(index[at]);
   }
-  REF_DIAG_STAMP();  // 1: descriptors read, first loads issued
+  REF_DIAG_STAMP_WAIT();  // 1: descriptors read, distances and indices arrived
+  // the owner keys and the rows of the pairs that pass the threshold go out together (neither address depends on the other's
+  // data): one round trip for both.  A pair the threshold rejects needs no rows - its lanes sit the gathers out.
   unsigned long long own[kP];
-#pragma unroll
-  for (int p = 0; p < kP; ++p) own[p] = owner[RJ.owner_off + jt[p]];
-  REF_DIAG_STAMP();  // 2: owner loads issued (index and distance arrived)
-  bool sel[kP];
+  bool near[kP];
   float S0[kP], S1[kP], S2[kP], Qx[kP], Qy[kP], Qz[kP], Nx[kP], Ny[kP], Nz[kP];
 #pragma unroll
   for (int p = 0; p < kP; ++p) {
-    sel[p] = live[p] && (dd[p] < t) && own[p] == picky_key(RJ.owner_prefix, dd[p], RJ.src_index_base + local[p]);
-    const uint32_t i = J.src_off + (live[p] ? local[p] : 0u);
-    const uint32_t tj = J.tgt_off + jt[p];
-    const size_t nj = static_cast<size_t>(RJ.normal_off) + static_cast<size_t>(jt[p]) * RJ.step;
-    S0[p] = sx[i]; S1[p] = sy[i]; S2[p] = sz[i];
-    Qx[p] = tx[tj]; Qy[p] = ty[tj]; Qz[p] = tz[tj];
-    Nx[p] = nx[nj]; Ny[p] = ny[nj]; Nz[p] = nz[nj];
+    near[p] = live[p] && (dd[p] < t);
+    own[p] = 0ull;
+    S0[p] = S1[p] = S2[p] = Qx[p] = Qy[p] = Qz[p] = Nx[p] = Ny[p] = Nz[p] = 0.f;
+    if (near[p]) {
+      own[p] = owner[RJ.owner_off + jt[p]];
+      const uint32_t i = J.src_off + local[p];
+      const uint32_t tj = J.tgt_off + jt[p];
+      const size_t nj = static_cast<size_t>(RJ.normal_off) + static_cast<size_t>(jt[p]) * RJ.step;
+      S0[p] = sx[i]; S1[p] = sy[i]; S2[p] = sz[i];
+      Qx[p] = tx[tj]; Qy[p] = ty[tj]; Qz[p] = tz[tj];
+      Nx[p] = nx[nj]; Ny[p] = ny[nj]; Nz[p] = nz[nj];
+    }
   }
-  REF_DIAG_STAMP();  // 3: gathers issued (owner arrived)
+  REF_DIAG_STAMP();  // 2: owner keys and rows requested
+  bool sel[kP];
+#pragma unroll
+  for (int p = 0; p < kP; ++p) sel[p] = near[p] && own[p] == picky_key(RJ.owner_prefix, dd[p], RJ.src_index_base + local[p]);
+  REF_DIAG_STAMP_WAIT();  // 3: source, target and normal rows arrived
 #pragma unroll
   for (int p = 0; p < kP; ++p) {
     if (selected && live[p]) selected[J.out_off + local[p]] = sel[p] ? 1 : 0;  // the per-pass diagnostic only (mi355_icp_reference_pass)

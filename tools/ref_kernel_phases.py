@@ -31,7 +31,7 @@ with pa.IcpEngine(0) as eng:
     lib.mi355_icp_diag_ref_read.argtypes = [C.c_void_p, C.c_void_p]
     assert lib.mi355_icp_diag_ref_read(buf.ctypes.data, C.byref(n)) == 0
 names = {1: ("rejection_select", ["cache", "median", "MAD", "end"]), 2: ("rejection_select+scatter", ["cache", "median", "MAD", "scatter"]),
-         3: ("ref_accumulate (block 0)", ["descr+issue", "idx,d2 arrive", "owner arrives", "gathers+products", "block sum", "end"])}
+         3: ("ref_accumulate (block 0)", ["descr, idx, d2 arrive", "owner + rows requested", "owner + rows arrive", "products", "block sum", "end"])}
 for r in buf[:min(n.value, 4096)]:
     kid, npts, nblk = int(r[0]) & 0xFF, (int(r[0]) >> 8) & 0xFFFFFFFF, int(r[0]) >> 40
     cnt = int(r[1])
