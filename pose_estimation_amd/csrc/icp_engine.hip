@@ -105,6 +105,7 @@ struct LevelPlanes {  // compacted copy of every cloud of a set at pyramid level
   std::vector<uint32_t> index_base;  // per cloud: index, in the WHOLE level cloud, of this rank's first level point (0 unless sharded)
   std::vector<uint32_t> n_total;     // per cloud: points of the whole level cloud over all ranks (= clouds[k].n unless sharded)
   XCopy xt;  // targets only
+  void* rows = nullptr;  // targets only: the records the point-to-plane accumulate gathers (launch_target_rows), built on demand
   DevicePlanes view() const { return DevicePlanes{planes, planes + stride, planes + 2 * stride}; }
 };
 
@@ -118,6 +119,7 @@ struct CloudSet {
   // decides WHICH of its points belong to a pyramid level (global indices 0, step, 2 step, ...).  Empty = not sharded.
   std::vector<uint64_t> shard_begin, shard_total;
   XCopy xt;  // level-0 expansion-filter copy (targets only)
+  void* rows = nullptr;  // level-0 records for the point-to-plane accumulate (targets with normals only; built on demand)
   DevicePlanes view() const { return DevicePlanes{planes, planes + stride, planes + 2 * stride}; }
   DevicePlanes normal_view() const { return DevicePlanes{normals, normals + stride, normals + 2 * stride}; }
 };
@@ -358,9 +360,12 @@ int wait_pass(mi355_icp_ctx* c, uint32_t seq, int n_jobs, uint32_t* error_bit) {
 void release_cloud_buffers(mi355_icp_ctx* c, CloudSet& set) {
   c->pool.give(set.planes);
   c->pool.give(set.normals);
+  c->pool.give(set.rows);
   set.planes = set.normals = nullptr;
+  set.rows = nullptr;
   for (auto& lv : set.levels) {
     c->pool.give(lv.planes);
+    c->pool.give(lv.rows);
     free_xcopy(c->pool, lv.xt);
   }
   set.levels.clear();
@@ -1130,6 +1135,7 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
   if (want_begin != set.shard_begin || want_total != set.shard_total) {  // levels built for another slab geometry: drop them
     for (auto& lv : set.levels) {
       c->pool.give(lv.planes);
+      c->pool.give(lv.rows);
       free_xcopy(c->pool, lv.xt);
     }
     set.levels.clear();
@@ -1196,6 +1202,31 @@ int ensure_level_xcopy(mi355_icp_ctx* c, CloudSet& set, int level) {
   launch_super_tiles(c->stream, lv.xt.table, static_cast<uint32_t>(lv.stride / kTile), lv.xt.super);
   HIP_TRY(c, hipGetLastError());
   lv.xt.valid = true;
+  return MI355_ICP_OK;
+}
+
+// The records the point-to-plane accumulate gathers for pyramid level `level` of the targets (ensure_level has run): built once
+// per upload from the level's planes and the level-0 normals.
+int ensure_target_rows(mi355_icp_ctx* c, CloudSet& set, int level, const void** rows_out) {
+  void*& rows = level ? set.levels[static_cast<size_t>(level) - 1].rows : set.rows;
+  if (!rows) {
+    const size_t stride = level ? set.levels[static_cast<size_t>(level) - 1].stride : set.stride;
+    const std::vector<CloudEntry>& clouds = level ? set.levels[static_cast<size_t>(level) - 1].clouds : set.clouds;
+    const DevicePlanes view = level ? set.levels[static_cast<size_t>(level) - 1].view() : set.view();
+    void* fresh = nullptr;
+    HIP_TRY(c, c->pool.take(&fresh, std::max<size_t>(stride, 1) * 32));
+    for (size_t k = 0; k < clouds.size(); ++k) {
+      const uint32_t first = level ? set.levels[static_cast<size_t>(level) - 1].first[k] : 0u;
+      launch_target_rows(c->stream, view, clouds[k].off, clouds[k].n, set.normal_view(), set.clouds[k].off + first, 1u << level, fresh);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      c->pool.give(fresh);
+      return fail(c, MI355_ICP_ERR_HIP, std::string("building the target rows: ") + hipGetErrorString(e));
+    }
+    rows = fresh;
+  }
+  *rows_out = rows;
   return MI355_ICP_OK;
 }
 
@@ -1284,6 +1315,8 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
   const bool self_staged = (exact_path || mfma_path) && all_scan && fill_stage_args(c->jobs_host, c->rjobs_host, n_active, &staged);
   if (!self_staged && stage_jobs(c->stream, c->jobs_host, c->rjobs_host, n_active, c->jobs_dev, c->rjobs_dev) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
   const DevicePlanes S = level_view(c->sources, level), T = level_view(c->targets, level);
+  const void* target_rows = nullptr;  // built by the level's first pass after an upload
+  if (const int rst = ensure_target_rows(c, c->targets, level, &target_rows); rst != MI355_ICP_OK) return rst;
   const size_t ref_key_need = static_cast<size_t>(plan.fused ? plan.key_rows() : plan.max_split) * plan.out_total;
   if ((plan.pruned ? false : plan.fused ? (plan.key_ranks() * ref_key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : ref_key_need > c->keys_cap) ||
       plan.out_total > c->out_cap || plan.out_total > c->selected_cap || owner_total > c->owner_cap ||
@@ -1343,7 +1376,7 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
       const int cst = comm_min_u64(c->comm, c->owner, std::max<size_t>(owner_total, 1), c->stream, &why);
       if (cst != MI355_ICP_OK) return fail(c, cst, std::string("cross-rank owner table: ") + (why ? why : "?"));
     }
-    if (sbx) launch_ref_accumulate(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, S, T, c->targets.normal_view(), c->out_index,
+    if (sbx) launch_ref_accumulate(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, S, target_rows, c->out_index,
                                    c->out_dist2, c->thr_dev, c->owner, c->want_selected ? c->selected : nullptr, c->ref_partials, tail);
   }
   // the pass result, ref_sums_dev or (PassTail) ref_sums_host directly: [n x 29 sums][n overflow-excess flags][n thresholds][n overflow counts]

@@ -412,8 +412,11 @@ void launch_select_pick(void* stream, const JobDesc* jobs_dev, int n_jobs, uint3
 void launch_picky_scatter(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
                           uint32_t max_src_blocks, const int32_t* index, const float* dist2, const float* thr,
                           unsigned long long* owner);
+// rows: 32 bytes per point of a pyramid level, (x, y, z, nx | ny, nz, 0, 0); normal of level-0 row normal_off + j * step
+void launch_target_rows(void* stream, DevicePlanes level, uint32_t level_off, uint32_t n, DevicePlanes normals, uint32_t normal_off,
+                        uint32_t step, void* rows);
 void launch_ref_accumulate(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
-                           uint32_t max_src_blocks, DevicePlanes src, DevicePlanes tgt, DevicePlanes normals,
+                           uint32_t max_src_blocks, DevicePlanes src, const void* target_rows,
                            const int32_t* index, const float* dist2, const float* thr, const unsigned long long* owner,
                            uint8_t* selected, double* partials, const PassTail& tail);
 void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums, const float* thr,

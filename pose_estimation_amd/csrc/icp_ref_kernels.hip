@@ -551,13 +551,28 @@ __device__ __forceinline__ void write_pass_tail(double* sums, uint32_t n_jobs, u
   if (overflow_count) overflow_count[job] = 0u;
 }
 
-// grid = (max src_blocks, n_jobs).  src/tgt are the LEVEL planes; normals are the level-0 normal planes.
+// The target rows the accumulate gathers, one 32-byte record per point of a pyramid level: (x, y, z, nx | ny, nz, 0, 0) -
+// coordinates of the level's compacted planes, normal of the level-0 row the point came from.  Built once per upload.
+// The accumulate is bound by the ISSUE of its scattered loads (64 different lines per instruction; phase stamps, round 3:
+// 6 of a launch's 11 us at 6 x 20k pairs), and a record is two such loads where six planes were six.
+// grid = ceil(n / 256), block = 256.
+__global__ __launch_bounds__(kBlockThreads) void target_rows_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                    const float* __restrict__ z, uint32_t level_off, uint32_t n,
+                                                                    const float* __restrict__ nx, const float* __restrict__ ny,
+                                                                    const float* __restrict__ nz, uint32_t normal_off, uint32_t step,
+                                                                    float4* __restrict__ rows) {
+  const uint32_t j = blockIdx.x * kBlockThreads + threadIdx.x;
+  if (j >= n) return;
+  const size_t nj = static_cast<size_t>(normal_off) + static_cast<size_t>(j) * step;
+  rows[2 * static_cast<size_t>(level_off + j)] = make_float4(x[level_off + j], y[level_off + j], z[level_off + j], nx[nj]);
+  rows[2 * static_cast<size_t>(level_off + j) + 1] = make_float4(ny[nj], nz[nj], 0.f, 0.f);
+}
+
+// grid = (max src_blocks, n_jobs).  src are the LEVEL planes, rows the level's target records (target_rows_kernel).
 // With tail.done set the launch also ENDS the pass (single-GPU reference mode): finish_pass, icp_internal.h.
 __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
     const JobDesc* __restrict__ jobs, const RefJobDesc* __restrict__ rjobs, const float* __restrict__ sx,
-    const float* __restrict__ sy, const float* __restrict__ sz, const float* __restrict__ tx,
-    const float* __restrict__ ty, const float* __restrict__ tz, const float* __restrict__ nx,
-    const float* __restrict__ ny, const float* __restrict__ nz, const int32_t* __restrict__ index,
+    const float* __restrict__ sy, const float* __restrict__ sz, const float4* __restrict__ rows, const int32_t* __restrict__ index,
     const float* __restrict__ dist2, const float* __restrict__ thr, const unsigned long long* __restrict__ owner,
     uint8_t* __restrict__ selected, double* partials, PassTail tail) {
   __shared__ double scratch[kBlockThreads / 64][kRefSums];
@@ -605,11 +620,12 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
     if (near[p]) {
       own[p] = owner[RJ.owner_off + jt[p]];
       const uint32_t i = J.src_off + local[p];
-      const uint32_t tj = J.tgt_off + jt[p];
-      const size_t nj = static_cast<size_t>(RJ.normal_off) + static_cast<size_t>(jt[p]) * RJ.step;
       S0[p] = sx[i]; S1[p] = sy[i]; S2[p] = sz[i];
-      Qx[p] = tx[tj]; Qy[p] = ty[tj]; Qz[p] = tz[tj];
-      Nx[p] = nx[nj]; Ny[p] = ny[nj]; Nz[p] = nz[nj];
+      const float4* rec = rows + 2 * static_cast<size_t>(J.tgt_off + jt[p]);
+      const float4 a = rec[0];
+      const float2 b = *reinterpret_cast<const float2*>(rec + 1);
+      Qx[p] = a.x; Qy[p] = a.y; Qz[p] = a.z;
+      Nx[p] = a.w; Ny[p] = b.x; Nz[p] = b.y;
     }
   }
   REF_DIAG_STAMP();  // 2: owner keys and rows requested
@@ -744,13 +760,20 @@ void launch_picky_scatter(void* stream, const JobDesc* jobs_dev, const RefJobDes
                      static_cast<hipStream_t>(stream), jobs_dev, rjobs_dev, index, dist2, thr, owner);
 }
 
+void launch_target_rows(void* stream, DevicePlanes level, uint32_t level_off, uint32_t n, DevicePlanes normals, uint32_t normal_off,
+                        uint32_t step, void* rows) {
+  if (!n) return;
+  hipLaunchKernelGGL(target_rows_kernel, dim3((n + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
+                     level.x, level.y, level.z, level_off, n, normals.x, normals.y, normals.z, normal_off, step, static_cast<float4*>(rows));
+}
+
 void launch_ref_accumulate(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
-                           uint32_t max_src_blocks, DevicePlanes src, DevicePlanes tgt, DevicePlanes normals,
+                           uint32_t max_src_blocks, DevicePlanes src, const void* target_rows,
                            const int32_t* index, const float* dist2, const float* thr, const unsigned long long* owner,
                            uint8_t* selected, double* partials, const PassTail& tail) {
   hipLaunchKernelGGL(ref_accumulate_kernel, dim3(max_src_blocks, static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0,
-                     static_cast<hipStream_t>(stream), jobs_dev, rjobs_dev, src.x, src.y, src.z, tgt.x, tgt.y, tgt.z,
-                     normals.x, normals.y, normals.z, index, dist2, thr, owner, selected, partials, tail);
+                     static_cast<hipStream_t>(stream), jobs_dev, rjobs_dev, src.x, src.y, src.z, static_cast<const float4*>(target_rows),
+                     index, dist2, thr, owner, selected, partials, tail);
 }
 
 void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums, const float* thr,
