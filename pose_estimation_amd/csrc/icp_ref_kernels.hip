@@ -253,6 +253,26 @@ struct SelectShared {
   uint32_t answer;
 };
 
+// The value of rank k among cand[0, m), m <= kSelCand, by counting (a barrier lies between the writes of cand and this call):
+// candidate c = tid / 4 against every fourth candidate from tid % 4 on; the four partial counts meet in neighbouring lanes.
+__device__ uint32_t rank_candidates(SelectShared& S, uint32_t m, uint32_t k) {
+  const uint32_t tid = threadIdx.x, c = tid >> 2, q = tid & 3u;
+  const uint32_t mine_v = c < m ? S.cand[c] : 0xFFFFFFFFu;
+  uint32_t less = 0, leq = 0;
+  for (uint32_t j = q; j < m; j += 4) {
+    const uint32_t cj = S.cand[j];
+    less += cj < mine_v ? 1u : 0u;
+    leq += cj <= mine_v ? 1u : 0u;
+  }
+  less += __shfl_xor(less, 1, 64);
+  leq += __shfl_xor(leq, 1, 64);
+  less += __shfl_xor(less, 2, 64);
+  leq += __shfl_xor(leq, 2, 64);
+  if (q == 0 && c < m && less <= k && k < leq) S.answer = mine_v;  // equal values all qualify and write the same bits
+  __syncthreads();
+  return S.answer;
+}
+
 // hist[] all zero and cand_n == 0 on entry and on return.  v[j] belongs to element threadIdx.x + j * kSelThreads (< n).
 // [lo, hi] (the same words in every thread) encloses the values, and every value has lo's bits above the highest bit in which
 // lo and hi differ: the exact smallest and largest value do, and so does (0, largest value).
@@ -309,24 +329,10 @@ __device__ uint32_t register_select(const uint32_t (&v)[kVpt], uint32_t n, uint3
       for (int j = 0; j < kVpt; ++j)
         if (tid + j * kSelThreads < n && (v[j] & mask) == prefix) S.cand[atomicAdd(&S.cand_n, 1u)] = v[j];  // exactly in_bin appends
       __syncthreads();
-      // candidate c = tid / 4 against every fourth candidate from tid % 4 on; the four partial counts meet in neighbouring lanes
-      const uint32_t c = tid >> 2, q = tid & 3u;
-      const uint32_t mine_v = c < in_bin ? S.cand[c] : 0xFFFFFFFFu;
-      uint32_t less = 0, leq = 0;
-      for (uint32_t j = q; j < in_bin; j += 4) {
-        const uint32_t cj = S.cand[j];
-        less += cj < mine_v ? 1u : 0u;
-        leq += cj <= mine_v ? 1u : 0u;
-      }
-      less += __shfl_xor(less, 1, 64);
-      leq += __shfl_xor(leq, 1, 64);
-      less += __shfl_xor(less, 2, 64);
-      leq += __shfl_xor(leq, 2, 64);
-      if (q == 0 && c < in_bin && less <= k && k < leq) S.answer = mine_v;  // equal values all qualify and write the same bits
       if (tid == 0) S.cand_n = 0;
-      __syncthreads();
+      const uint32_t answer = rank_candidates(S, in_bin, k);
       REF_DIAG_STAMP();  // candidates ranked
-      return S.answer;
+      return answer;
     }
   }
 }
@@ -352,6 +358,16 @@ __global__ __launch_bounds__(kSelThreads) void rejection_select_reg_kernel(const
     const uint32_t i = tid + j * kSelThreads;
     v[j] = i < n ? __float_as_uint(d[i]) : 0xFFFFFFFFu;
   }
+  const uint32_t k = (n - 1) / 2;
+  float med, mad;
+  if (n <= kSelCand) {  // (block-uniform) the coarsest pyramid levels: every value is a candidate, no histogram at all
+    if (tid < n) S.cand[tid] = v[0];
+    __syncthreads();
+    med = __uint_as_float(rank_candidates(S, n, k));
+    if (tid < n) S.cand[tid] = __float_as_uint(static_cast<float>(__builtin_fabs(static_cast<double>(__uint_as_float(v[0])) - static_cast<double>(med))));
+    __syncthreads();
+    mad = __uint_as_float(rank_candidates(S, n, k));
+  } else {
   S.hist[2 * tid] = 0;
   S.hist[2 * tid + 1] = 0;
   if (tid == 0) S.cand_n = 0;
@@ -381,8 +397,7 @@ __global__ __launch_bounds__(kSelThreads) void rejection_select_reg_kernel(const
     hi = b > hi ? b : hi;
   }
   REF_DIAG_STAMP();  // 1: distances in registers, their range known
-  const uint32_t k = (n - 1) / 2;
-  const float med = __uint_as_float(register_select<kVpt>(v, n, k, lo, hi, S REF_DIAG_PASS));
+  med = __uint_as_float(register_select<kVpt>(v, n, k, lo, hi, S REF_DIAG_PASS));
   __syncthreads();  // the second selection reuses the words the first one's last readers may still be reading
   auto deviation = [&](uint32_t bits) {
     return __float_as_uint(static_cast<float>(__builtin_fabs(static_cast<double>(__uint_as_float(bits)) - static_cast<double>(med))));
@@ -392,7 +407,8 @@ __global__ __launch_bounds__(kSelThreads) void rejection_select_reg_kernel(const
   for (int j = 0; j < kVpt; ++j) dev[j] = deviation(v[j]);
   // the largest deviation is the smallest or the largest distance's (the rounded difference is monotone in |d2 - med|)
   const uint32_t dev_lo = deviation(lo), dev_hi = deviation(hi);
-  const float mad = __uint_as_float(register_select<kVpt>(dev, n, k, 0u, dev_lo > dev_hi ? dev_lo : dev_hi, S REF_DIAG_PASS));
+  mad = __uint_as_float(register_select<kVpt>(dev, n, k, 0u, dev_lo > dev_hi ? dev_lo : dev_hi, S REF_DIAG_PASS));
+  }
   const float mad_s = 1.48257968f * mad;  // every thread: the same float32 operations on the same operands, as the kernel above
   const float mad_t = scale * mad_s;
   const float t = mad_t + med;
