@@ -27,6 +27,13 @@ MI355_ICP_XBF16_SHAPE=1 MI355_ICP_SCAN_MODE=xbf16 step 600 pytest_gpu_xbf16_shap
 # pre-round-2 structure of a reference pass (separate reduce + copy, a sort per pyramid level, scalar solves)
 MI355_ICP_KNN_MODE=brute step 600 pytest_gpu_knn_brute.txt python -m pytest tests/test_gpu_normals.py tests/test_gpu_opencv_adapter.py tests/test_gpu_scene_filters.py tests/test_gpu_plane_fit.py -m gpu -x -q
 MI355_ICP_LEVEL_SORT=1 MI355_ICP_PASS_TAIL=0 MI355_ICP_SOLVE_ISA=scalar step 600 pytest_gpu_plain_passes.txt python -m pytest tests/test_gpu_reference_mode.py tests/test_gpu_normals.py tests/test_gpu_parity.py -m gpu -x -q
+# round-3 planner knobs: odd cuts of the target (a chip of 48 or 200 resident workgroups makes the split model pick 3, 5, 7, 11 ...
+# runs of tiles; the split model off; every tile of a small launch in 32 runs, or whole), and each wave blocking of the filter's resolve
+FORCED="tests/test_gpu_fused_filter.py tests/test_gpu_parity.py tests/test_gpu_filter_bounds.py tests/test_gpu_reference_mode.py tests/test_gpu_reference_random.py"
+MI355_ICP_SCAN_SLOTS=48 step 600 pytest_gpu_slots48.txt python -m pytest $FORCED -m gpu -x -q
+MI355_ICP_SCAN_SLOTS=200 MI355_ICP_RESOLVE_WAVE_POINTS=32 step 600 pytest_gpu_slots200.txt python -m pytest $FORCED -m gpu -x -q
+MI355_ICP_SPLIT_MODEL=0 MI355_ICP_RESOLVE_WAVE_POINTS=64 MI355_ICP_MAX_SUB_SPLIT=1 step 600 pytest_gpu_model0.txt python -m pytest $FORCED -m gpu -x -q
+MI355_ICP_SPLIT_MODEL_PAIRS=1e30 MI355_ICP_RESOLVE_WAVE_POINTS=16 MI355_ICP_SUB_SPLIT_WGS=100000 step 600 pytest_gpu_model_all.txt python -m pytest $FORCED -m gpu -x -q
 step 300 smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
 step 400 bench.txt python bench.py --steps "${STEPS:-3}" --warmup 1
-tail -3 gpurun_out/pytest_gpu.txt; tail -2 gpurun_out/pytest_gpu_fused.txt; tail -2 gpurun_out/pytest_gpu_xfilter.txt; tail -2 gpurun_out/pytest_gpu_xbf16.txt; tail -2 gpurun_out/pytest_gpu_exact.txt; tail -2 gpurun_out/pytest_gpu_pruned.txt; tail -2 gpurun_out/pytest_gpu_knn_brute.txt; tail -2 gpurun_out/pytest_gpu_plain_passes.txt; tail -2 gpurun_out/smoke.txt; tail -1 gpurun_out/bench.txt
+tail -3 gpurun_out/pytest_gpu.txt; tail -2 gpurun_out/pytest_gpu_fused.txt; tail -2 gpurun_out/pytest_gpu_xfilter.txt; tail -2 gpurun_out/pytest_gpu_xbf16.txt; tail -2 gpurun_out/pytest_gpu_exact.txt; tail -2 gpurun_out/pytest_gpu_pruned.txt; tail -2 gpurun_out/pytest_gpu_knn_brute.txt; tail -2 gpurun_out/pytest_gpu_plain_passes.txt; tail -1 gpurun_out/pytest_gpu_slots48.txt; tail -1 gpurun_out/pytest_gpu_slots200.txt; tail -1 gpurun_out/pytest_gpu_model0.txt; tail -1 gpurun_out/pytest_gpu_model_all.txt; tail -2 gpurun_out/smoke.txt; tail -1 gpurun_out/bench.txt
