@@ -1161,13 +1161,19 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
     }
     lv.stride = static_cast<size_t>(std::max<uint64_t>(total, pad_multiple));
     HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&lv.planes), 3 * lv.stride * sizeof(float)));
+    // a set with normals (targets of reference mode): the level's target rows come out of the same launch (ensure_target_rows)
+    if (set.normals && c->pool.take(&lv.rows, lv.stride * 32) != hipSuccess) {
+      c->pool.give(lv.planes);
+      return fail(c, MI355_ICP_ERR_HIP, "building pyramid level: no memory for the target rows");
+    }
     hipError_t e = hipSuccess;
     if (total == 0) e = hipMemsetAsync(lv.planes, 0, 3 * lv.stride * sizeof(float), c->stream);
     for (size_t k = 0; k < set.clouds.size() && e == hipSuccess; ++k)
       launch_subsample(c->stream, set.planes, set.stride, set.clouds[k].off + first[k], lv.planes, lv.stride, lv.clouds[k].off,
-                       lv.clouds[k].n, lv.clouds[k].padded, step, pad_value);
+                       lv.clouds[k].n, lv.clouds[k].padded, step, pad_value, set.normals, lv.rows);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) {  // the level is not adopted: give its planes back
+      c->pool.give(lv.rows);
       c->pool.give(lv.planes);
       return fail(c, MI355_ICP_ERR_HIP, std::string("building pyramid level: ") + hipGetErrorString(e));
     }

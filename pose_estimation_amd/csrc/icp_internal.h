@@ -400,8 +400,10 @@ void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t 
 void launch_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums,
                          uint32_t* overflow_count, uint32_t overflow_cap);
 
+// normals + rows given: the level's target rows are written along (the normals share the planes' layout: same stride, same offsets)
 void launch_subsample(void* stream, const float* in, size_t in_stride, uint32_t in_off, float* out, size_t out_stride,
-                      uint32_t out_off, uint32_t n_level, uint32_t n_padded, uint32_t step, float pad);
+                      uint32_t out_off, uint32_t n_level, uint32_t n_padded, uint32_t step, float pad, const float* normals = nullptr,
+                      void* rows = nullptr);
 bool launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_n, const float* dist2, float scale,
                              float* thr, uint32_t* hists, uint32_t* states, const RefJobDesc* rjobs_dev = nullptr,
                              const int32_t* index = nullptr, unsigned long long* owner = nullptr);

@@ -74,16 +74,25 @@ __device__ __forceinline__ void transform_point(const float* __restrict__ m, flo
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
+// normals != nullptr (targets uploaded with normals): the launch also writes the level's target rows (target_rows_kernel's
+// records: the level's coordinates with the normal of the level-0 row each point came from) - one launch less per level of a new scene.
 __global__ __launch_bounds__(kBlockThreads) void subsample_kernel(const float* __restrict__ in, size_t in_stride,
                                                                    uint32_t in_off, float* __restrict__ out,
                                                                    size_t out_stride, uint32_t out_off, uint32_t n_level,
-                                                                   uint32_t n_padded, uint32_t step, float pad) {
+                                                                   uint32_t n_padded, uint32_t step, float pad,
+                                                                   const float* __restrict__ normals, float4* __restrict__ rows) {
   const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
   if (i >= n_padded) return;
+  float v[3];
 #pragma unroll
   for (int plane = 0; plane < 3; ++plane) {
-    const float v = i < n_level ? in[plane * in_stride + in_off + static_cast<size_t>(i) * step] : pad;
-    out[plane * out_stride + out_off + i] = v;
+    v[plane] = i < n_level ? in[plane * in_stride + in_off + static_cast<size_t>(i) * step] : pad;
+    out[plane * out_stride + out_off + i] = v[plane];
+  }
+  if (normals && i < n_level) {
+    const size_t nj = in_off + static_cast<size_t>(i) * step;
+    rows[2 * static_cast<size_t>(out_off + i)] = make_float4(v[0], v[1], v[2], normals[nj]);
+    rows[2 * static_cast<size_t>(out_off + i) + 1] = make_float4(normals[in_stride + nj], normals[2 * in_stride + nj], 0.f, 0.f);
   }
 }
 
@@ -710,11 +719,12 @@ __global__ __launch_bounds__(kBlockThreads) void ref_final_reduce_kernel(const J
 
 // ---------------------------------------------------------------------------------------------
 void launch_subsample(void* stream, const float* in, size_t in_stride, uint32_t in_off, float* out, size_t out_stride,
-                      uint32_t out_off, uint32_t n_level, uint32_t n_padded, uint32_t step, float pad) {
+                      uint32_t out_off, uint32_t n_level, uint32_t n_padded, uint32_t step, float pad, const float* normals,
+                      void* rows) {
   if (!n_padded) return;
   hipLaunchKernelGGL(subsample_kernel, dim3((n_padded + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0,
                      static_cast<hipStream_t>(stream), in, in_stride, in_off, out, out_stride, out_off, n_level, n_padded,
-                     step, pad);
+                     step, pad, rows ? normals : nullptr, static_cast<float4*>(rows));
 }
 
 // max_n: largest job of the launch.  hists / states: scratch zeroed once at allocation (the pick kernel leaves the
