@@ -234,6 +234,8 @@ struct mi355_icp_ctx {
   bool scene_normals_valid = false; uint32_t scene_normals_padded = 0;
   unsigned long long* scene_state = nullptr; size_t scene_state_cap = 0;
   float* plane_hyp = nullptr; uint32_t* plane_counts = nullptr; double* plane_partials = nullptr; size_t plane_partials_cap = 0;  // RANSAC plane fit
+  // ... its read-backs land in pinned memory: hypotheses and counters (ONE device block, one copy), then the moment rows
+  unsigned char* plane_host = nullptr; size_t plane_host_cap = 0;
   uint32_t* scene_counters = nullptr;       // device: ticket, kept total, error bits
   uint32_t* scene_counters_host = nullptr;  // pinned
 
@@ -1555,9 +1557,9 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   (void)hipFree(c->knn_i);
   (void)hipFree(c->knn_out);
   (void)hipFree(c->scene_state);
-  (void)hipFree(c->plane_hyp);
-  (void)hipFree(c->plane_counts);
+  (void)hipFree(c->plane_hyp);  // the counters live behind the hypotheses in the same block
   (void)hipFree(c->plane_partials);
+  (void)hipHostFree(c->plane_host);
   (void)hipFree(c->scene_counters);
   if (c->scene_counters_host) (void)hipHostFree(c->scene_counters_host);
   (void)hipFree(c->xt_scratch);
@@ -2193,22 +2195,31 @@ int mi355_icp_scene_fit_plane(mi355_icp_ctx* c, const mi355_plane_fit_params* fp
   HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t n = c->scene_n, n_hyp = static_cast<uint32_t>(fp->max_iterations);
   const uint32_t blocks = (n + 4 * kBlockThreads - 1) / (4 * kBlockThreads);
-  if (!c->plane_hyp) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->plane_hyp), (kPlaneMaxHypotheses + 1) * 4 * sizeof(float)));
-  if (!c->plane_counts) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->plane_counts), (kPlaneMaxHypotheses + 1) * sizeof(uint32_t)));
+  constexpr size_t kHypBytes = (kPlaneMaxHypotheses + 1) * 4 * sizeof(float), kCountBytes = (kPlaneMaxHypotheses + 1) * sizeof(uint32_t);
+  if (!c->plane_hyp) {  // hypotheses | counters: one block, one read-back
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->plane_hyp), kHypBytes + kCountBytes));
+    c->plane_counts = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(c->plane_hyp) + kHypBytes);
+  }
   int st;
   if ((st = grow(c, c->plane_partials, c->plane_partials_cap, static_cast<size_t>(blocks) * kPlaneMoments)) != MI355_ICP_OK) return st;
+  const size_t host_need = kHypBytes + kCountBytes + static_cast<size_t>(blocks) * kPlaneMoments * sizeof(double);
+  if (host_need > c->plane_host_cap) {
+    if (c->plane_host) { HIP_TRY(c, hipHostFree(c->plane_host)); c->plane_host = nullptr; c->plane_host_cap = 0; }
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->plane_host), host_need + host_need / 4, hipHostMallocDefault));
+    c->plane_host_cap = host_need + host_need / 4;
+  }
   const float* scene = c->scene[c->scene_cur];
-  std::vector<float> planes(4 * static_cast<size_t>(n_hyp));
-  std::vector<uint32_t> counts(n_hyp);
-  HIP_TRY(c, hipMemsetAsync(c->plane_counts, 0, (kPlaneMaxHypotheses + 1) * sizeof(uint32_t), c->stream));
+  const float* planes = reinterpret_cast<const float*>(c->plane_host);
+  const uint32_t* counts = reinterpret_cast<const uint32_t*>(c->plane_host + kHypBytes);
+  const double* rows = reinterpret_cast<const double*>(c->plane_host + kHypBytes + kCountBytes);
+  HIP_TRY(c, hipMemsetAsync(c->plane_counts, 0, kCountBytes, c->stream));
   launch_plane_hypotheses(c->stream, scene, n, fp->seed, n_hyp, c->plane_hyp);
   launch_plane_support(c->stream, scene, n, c->plane_hyp, n_hyp, fp->distance_threshold, c->plane_counts);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(planes.data(), c->plane_hyp, planes.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(counts.data(), c->plane_counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->plane_host, c->plane_hyp, kHypBytes + kCountBytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   int iterations = 0;
-  const int best = plane_choose(counts.data(), planes.data(), n_hyp, n, fp->probability, &iterations);
+  const int best = plane_choose(counts, planes, n_hyp, n, fp->probability, &iterations);
   if (out_iterations) *out_iterations = iterations;
   if (best < 0) return fail(c, MI355_ICP_ERR_NUMERIC, "scene_fit_plane: no three points of the scene span a plane");
   float coeff[4] = {planes[4 * best], planes[4 * best + 1], planes[4 * best + 2], planes[4 * best + 3]};
@@ -2216,8 +2227,8 @@ int mi355_icp_scene_fit_plane(mi355_icp_ctx* c, const mi355_plane_fit_params* fp
   if (fp->optimize) {
     launch_plane_moments(c->stream, scene, n, coeff, fp->distance_threshold, c->plane_partials, blocks);
     HIP_TRY(c, hipGetLastError());
-    std::vector<double> rows(static_cast<size_t>(blocks) * kPlaneMoments);
-    HIP_TRY(c, hipMemcpyAsync(rows.data(), c->plane_partials, rows.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->plane_host + kHypBytes + kCountBytes, c->plane_partials, static_cast<size_t>(blocks) * kPlaneMoments * sizeof(double),
+                              hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     double m[kPlaneMoments] = {0};
     for (uint32_t b = 0; b < blocks; ++b)  // fixed order: the same scene and plane always give the same bits
@@ -2225,16 +2236,12 @@ int mi355_icp_scene_fit_plane(mi355_icp_ctx* c, const mi355_plane_fit_params* fp
     float refined[4];
     if (plane_refine(m, coeff, refined) == MI355_ICP_OK) {  // a degenerate inlier set keeps the hypothesis (PCL: optimisation fails, model kept)
       std::memcpy(coeff, refined, sizeof(coeff));
-      uint32_t cnt = 0;
-      float* slot = c->plane_hyp + 4 * kPlaneMaxHypotheses;      // the spare hypothesis slot and its counter
-      uint32_t* cslot = c->plane_counts + kPlaneMaxHypotheses;
-      HIP_TRY(c, hipMemcpyAsync(slot, coeff, sizeof(coeff), hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));  // `coeff` is pageable
-      launch_plane_support(c->stream, scene, n, slot, 1, fp->distance_threshold, cslot);
+      uint32_t* cslot = c->plane_counts + kPlaneMaxHypotheses;  // the spare counter (cleared with the others above)
+      launch_plane_support_one(c->stream, scene, n, coeff, fp->distance_threshold, cslot);  // the refitted plane rides in the kernel arguments
       HIP_TRY(c, hipGetLastError());
-      HIP_TRY(c, hipMemcpyAsync(&cnt, cslot, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(c->plane_host + kHypBytes + kPlaneMaxHypotheses * sizeof(uint32_t), cslot, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
-      inliers = cnt;
+      inliers = counts[kPlaneMaxHypotheses];
     }
   }
   std::memcpy(out_coefficients, coeff, sizeof(coeff));

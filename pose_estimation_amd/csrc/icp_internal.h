@@ -322,6 +322,8 @@ constexpr int kPlaneMaxHypotheses = 1024;
 constexpr int kPlaneMoments = 10;
 void launch_plane_hypotheses(void* stream, const float* scene, uint32_t n, unsigned long long seed, uint32_t n_hyp, float* planes4);
 void launch_plane_support(void* stream, const float* scene, uint32_t n, const float* planes4, uint32_t n_hyp, float threshold, uint32_t* counts);
+// one plane, passed by value (host memory): its inlier count is ADDED to *count
+void launch_plane_support_one(void* stream, const float* scene, uint32_t n, const float* plane4, float threshold, uint32_t* count);
 void launch_plane_moments(void* stream, const float* scene, uint32_t n, const float* plane4, float threshold, double* partials, uint32_t n_blocks);
 // host side (host_math.cpp): PCL's adaptive choice replayed over the counts; the refined plane from the moments
 int plane_choose(const uint32_t* counts, const float* planes4, uint32_t n_hyp, uint32_t n_points, double probability, int* iterations);

@@ -342,13 +342,14 @@ __global__ void plane_hypotheses_kernel(const float* __restrict__ scene, uint32_
 
 // Support of every hypothesis in one pass: a thread takes 4 points; for each plane the wave's inlier ballots are counted
 // and one lane adds them to the workgroup's LDS counters, which go to the global counters at the end.  Integer counts.
+// planes == nullptr: ONE plane, `one`, handed over as a kernel argument (the refitted plane: no upload in front of the launch).
 __global__ __launch_bounds__(kBlockThreads) void plane_support_kernel(const float* __restrict__ scene, uint32_t n,
                                                                        const float4* __restrict__ planes, uint32_t n_hyp, float threshold,
-                                                                       uint32_t* __restrict__ counts) {
+                                                                       uint32_t* __restrict__ counts, float4 one) {
   __shared__ float4 sp[kPlaneMaxHypotheses];
   __shared__ uint32_t sc[kPlaneMaxHypotheses];
   for (uint32_t h = threadIdx.x; h < n_hyp; h += kBlockThreads) {
-    sp[h] = planes[h];
+    sp[h] = planes ? planes[h] : one;
     sc[h] = 0;
   }
   __syncthreads();
@@ -429,7 +430,13 @@ void launch_plane_support(void* stream, const float* scene, uint32_t n, const fl
   const uint32_t blocks = (n + 4 * kBlockThreads - 1) / (4 * kBlockThreads);
   if (!blocks) return;
   hipLaunchKernelGGL(plane_support_kernel, dim3(blocks), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), scene, n,
-                     reinterpret_cast<const float4*>(planes4), n_hyp, threshold, counts);
+                     reinterpret_cast<const float4*>(planes4), n_hyp, threshold, counts, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+void launch_plane_support_one(void* stream, const float* scene, uint32_t n, const float* plane4, float threshold, uint32_t* count) {
+  const uint32_t blocks = (n + 4 * kBlockThreads - 1) / (4 * kBlockThreads);
+  if (!blocks) return;
+  hipLaunchKernelGGL(plane_support_kernel, dim3(blocks), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), scene, n,
+                     static_cast<const float4*>(nullptr), 1u, threshold, count, make_float4(plane4[0], plane4[1], plane4[2], plane4[3]));
 }
 void launch_plane_moments(void* stream, const float* scene, uint32_t n, const float* plane4, float threshold, double* partials, uint32_t n_blocks) {
   if (!n_blocks) return;
