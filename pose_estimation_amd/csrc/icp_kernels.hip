@@ -898,9 +898,14 @@ __global__ __launch_bounds__(kBlockThreads) void overflow_tiles_kernel(
     int32_t* __restrict__ out_index, float* __restrict__ out_dist2, uint32_t* __restrict__ error_flag) {
   __shared__ unsigned long long smask[kBlockThreads / 64];
   __shared__ uint32_t sd[kBlockThreads / 64], sj[kBlockThreads / 64];
+  P2P_DIAG_BEGIN(blockIdx.x == 0 && threadIdx.x == 0);
   const JobDesc& J = jobs[blockIdx.y];
   const uint32_t n_listed = overflow_count[blockIdx.y];
-  if (blockIdx.x >= n_listed) return;
+  if (blockIdx.x >= n_listed) {
+    P2P_DIAG_STAMP_WAIT();  // 1: descriptor and count read: nothing listed for this workgroup
+    P2P_DIAG_END(5ull);
+    return;
+  }
   float pose[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
@@ -914,14 +919,24 @@ __global__ __launch_bounds__(kBlockThreads) void overflow_tiles_kernel(
   float best = d0;
   uint32_t best_j = static_cast<uint32_t>(out_index[J.out_off + local]);  // 0xFFFFFFFF = none yet
   const uint32_t n_tiles = J.tgt_tiles, tile_base = J.tgt_off / kTile, tid = threadIdx.x;
+  P2P_DIAG_STAMP_WAIT();  // 1: list entry, point, its upper bound
+#ifdef MI355_ICP_DIAG
+  unsigned long long diag_tiles = 0;
+#endif
   for (uint32_t t0 = 0; t0 < n_tiles; t0 += kBlockThreads) {
     const uint32_t t = t0 + tid;
     const bool reach = t < n_tiles && sphere_reachable(qx, qy, qz, 0.0f, ttable[tile_base + t], d0);
     const unsigned long long m = __builtin_amdgcn_ballot_w64(reach);
     if ((tid & 63u) == 0) smask[tid >> 6] = m;
     __syncthreads();
+    P2P_DIAG_STAMP();  // tile table tested
     for (uint32_t w = 0; w < kBlockThreads / 64; ++w) {
       unsigned long long todo = smask[w];
+#ifdef MI355_ICP_DIAG
+      diag_tiles += __builtin_popcountll(todo);
+#endif
+      // (Four tiles' loads in flight at once changed nothing: 6-8 reachable tiles cost ~1 us each either way - phase stamps,
+      // round 3; the tiles are 4 KB apart in four arrays, and what a tile waits for is not one round trip per load.)
       while (todo) {
         const uint32_t tile = t0 + w * 64 + static_cast<uint32_t>(__builtin_ctzll(todo));
         todo &= todo - 1;
@@ -944,6 +959,7 @@ __global__ __launch_bounds__(kBlockThreads) void overflow_tiles_kernel(
       }
     }
     __syncthreads();  // smask is rewritten by the next round
+    P2P_DIAG_STAMP_WAIT();  // reachable tiles scanned
   }
   const uint32_t wd = wave_min_u32(__float_as_uint(best));
   const uint32_t wj = wave_min_u32(__float_as_uint(best) == wd ? best_j : 0xFFFFFFFFu);
@@ -968,6 +984,7 @@ __global__ __launch_bounds__(kBlockThreads) void overflow_tiles_kernel(
     out_dist2[J.out_off + local] = __uint_as_float(d);
   }
   __syncthreads();  // sd / sj are rewritten by the next listed point
+  if (slot == blockIdx.x) P2P_DIAG_END(6ull | (static_cast<unsigned long long>(n_listed) << 8) | (diag_tiles << 40) | (static_cast<unsigned long long>(n_tiles) << 48));
   }
 }
 

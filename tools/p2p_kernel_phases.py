@@ -18,7 +18,9 @@ lib.mi355_icp_diag_p2p_read.argtypes = [C.c_void_p, C.c_void_p]
 names = {1: ("resolve_accumulate<sums>", ["descr + key/src loads issued", "chunks + products", "block sum", "end"]),
          2: ("resolve_accumulate<idx>", ["descr + key/src loads issued", "chunk", "end"]),
          3: ("nn_scan_kernel (block 0)", ["descr, transforms, tile 0", "tiles scanned", "keys out"]),
-         4: ("resolve_xfilter (wave 0 of every 16th block)", ["descr, key rows, transform", "first granules", "second granules", "end"])}
+         4: ("resolve_xfilter (wave 0 of every 16th block)", ["descr, key rows, transform", "first granules", "second granules", "end"]),
+         5: ("overflow_tiles (block 0 of a job, nothing listed)", ["descr + count", "end"]),
+         6: ("overflow_tiles (block 0 of a job, first listed point; n = listed)", ["entry, point, bound", "tile table", "tiles scanned", "reduce + store"])}
 
 
 def dump(title):
@@ -37,7 +39,7 @@ def dump(title):
         nm, ph = names[kid]
         d = np.median(np.stack([x for x, _ in recs]), axis=0)
         mx = np.max(np.stack([x for x, _ in recs]), axis=0)
-        more = f"  key rows {rows}, second-granule points per wave median {np.median([e for _, e in recs]):.0f} max {max(e for _, e in recs)}" if kid == 4 else ""
+        more = f"  key rows {rows}, second-granule points per wave median {np.median([e for _, e in recs]):.0f} max {max(e for _, e in recs)}" if kid == 4 else (f"  tiles {rows}, reachable median {np.median([e for _, e in recs]):.0f} max {max(e for _, e in recs)}" if kid == 6 else "")
         print(f"{nm:26s} n={npts:6d} x{len(recs):4d}  total {d.sum():6.2f} us (max {mx.sum():6.2f}) | " + "  ".join(f"{p} {x:5.2f} (max {m:5.2f})" for p, x, m in zip(ph, d, mx)) + more)
 
 
