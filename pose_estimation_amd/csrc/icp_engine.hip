@@ -248,6 +248,7 @@ struct mi355_icp_ctx {
   int scan_ppl = 0;                  // scan points-per-lane override (2, 4, 8); 0 = planner decides per call
   bool scan_sgpr = false;            // experimental scalar-load scan (MI355_ICP_SCAN_MODE=sgpr)
   uint32_t* xt_scratch = nullptr; size_t xt_scratch_cap = 0;  // Morton codes / indices while building the sorted target copy
+  float* xt_tile_box = nullptr; size_t xt_tile_box_cap = 0;   // ... and the tiles' bounding boxes between its two kernels (8 floats per tile)
   uint32_t* xt_meta_host = nullptr; size_t xt_meta_cap = 0; hipEvent_t xt_meta_event = nullptr; bool xt_meta_pending = false;  // pinned (offset, count) table of ensure_xcopy
   uint32_t* xt_box = nullptr;     size_t xt_box_cap = 0;  // per cloud: bounding box as order-preserving keys
   unsigned char* xt_temp = nullptr; size_t xt_temp_cap = 0;   // rocPRIM sort scratch
@@ -808,6 +809,7 @@ int ensure_xcopy(mi355_icp_ctx* c, DevicePlanes view, size_t stride, const std::
   if ((st = grow(c, c->xt_scratch, c->xt_scratch_cap, 4 * static_cast<size_t>(max_n) + 2 * static_cast<size_t>(n_clouds))) != MI355_ICP_OK) return st;
   if ((st = grow(c, c->xt_box, c->xt_box_cap, 6 * static_cast<size_t>(n_clouds))) != MI355_ICP_OK) return st;
   if ((st = grow(c, c->xt_temp, c->xt_temp_cap, temp_bytes + 16)) != MI355_ICP_OK) return st;
+  if ((st = grow(c, c->xt_tile_box, c->xt_tile_box_cap, 8 * (stride / kTile + 1))) != MI355_ICP_OK) return st;
   if ((st = alloc_xcopy(c, x, stride)) != MI355_ICP_OK) return st;
   uint32_t* code = c->xt_scratch;
   uint32_t* index = code + max_n;
@@ -820,7 +822,7 @@ int ensure_xcopy(mi355_icp_ctx* c, DevicePlanes view, size_t stride, const std::
   launch_bbox(c->stream, view, meta_dev, meta_dev + n_clouds, n_clouds, max_n, c->xt_box);
   for (int k = 0; k < n_clouds; ++k)
     if (xtarget_build_cloud(c->stream, view, clouds[k].off, clouds[k].n, c->xt_box + 6 * k, code, index, code2, order, c->xt_temp,
-                            temp_bytes, x.planes, stride, x.perm, x.table, x.bf, x.sub, x.bf_table) != 0)
+                            temp_bytes, x.planes, stride, x.perm, x.table, x.bf, x.sub, x.bf_table, c->xt_tile_box) != 0)
       return fail(c, MI355_ICP_ERR_HIP, "rocprim::radix_sort_pairs failed");
   launch_super_tiles(c->stream, x.table, static_cast<uint32_t>(stride / kTile), x.super);
   HIP_TRY(c, hipGetLastError());
@@ -1200,12 +1202,13 @@ int ensure_level_xcopy(mi355_icp_ctx* c, CloudSet& set, int level) {
   for (size_t k = 0; k < lv.clouds.size(); ++k)
     scratch = std::max(scratch, static_cast<size_t>(lv.clouds[k].n) + set.clouds[k].n / 4096 + 2);
   if ((st = grow(c, c->xt_scratch, c->xt_scratch_cap, scratch)) != MI355_ICP_OK) return st;
+  if ((st = grow(c, c->xt_tile_box, c->xt_tile_box_cap, 8 * (lv.stride / kTile + 1))) != MI355_ICP_OK) return st;
   if ((st = alloc_xcopy(c, lv.xt, lv.stride)) != MI355_ICP_OK) return st;
   const DevicePlanes view = lv.view();
   for (size_t k = 0; k < lv.clouds.size(); ++k)
     if (xtarget_build_cloud_from_parent(c->stream, view, lv.clouds[k].off, lv.clouds[k].n, set.xt.perm + set.clouds[k].off, set.clouds[k].n,
                                         lv.first[k], 1u << level, c->xt_scratch, lv.xt.planes, lv.stride, lv.xt.perm, lv.xt.table, lv.xt.bf,
-                                        lv.xt.sub, lv.xt.bf_table) != 0)
+                                        lv.xt.sub, lv.xt.bf_table, c->xt_tile_box) != 0)
       return fail(c, MI355_ICP_ERR_HIP, "deriving a pyramid level's sorted copy failed");
   launch_super_tiles(c->stream, lv.xt.table, static_cast<uint32_t>(lv.stride / kTile), lv.xt.super);
   HIP_TRY(c, hipGetLastError());
@@ -1563,6 +1566,7 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   (void)hipFree(c->scene_counters);
   if (c->scene_counters_host) (void)hipHostFree(c->scene_counters_host);
   (void)hipFree(c->xt_scratch);
+  (void)hipFree(c->xt_tile_box);
   (void)hipFree(c->xt_box);
   (void)hipFree(c->xt_temp);
   (void)hipFree(c->keys3);

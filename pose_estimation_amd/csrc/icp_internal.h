@@ -430,10 +430,10 @@ void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, 
 int xtarget_sort_temp_bytes(uint32_t n, size_t* bytes);
 int xtarget_build_cloud_from_parent(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const uint32_t* parent_perm,
                                     uint32_t n_parent, uint32_t first, uint32_t step, uint32_t* scratch, float* xt, size_t stride,
-                                    uint32_t* perm, float* table, void* bf_image, void* sub_table, float* bf_table);
+                                    uint32_t* perm, float* table, void* bf_image, void* sub_table, float* bf_table, float* tile_box);
 int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const uint32_t* box, uint32_t* code,
                         uint32_t* index, uint32_t* code2, uint32_t* order, void* temp, size_t temp_bytes, float* xt,
-                        size_t stride, uint32_t* perm, float* table, void* bf_image, void* sub_table, float* bf_table);
+                        size_t stride, uint32_t* perm, float* table, void* bf_image, void* sub_table, float* bf_table, float* tile_box);
 void launch_super_tiles(void* stream, const float* table, uint32_t n_tiles_total, float* super_table);
 void launch_bbox(void* stream, DevicePlanes planes, const uint32_t* cloud_off, const uint32_t* cloud_n, int n_clouds, uint32_t max_n,
                  uint32_t* box);

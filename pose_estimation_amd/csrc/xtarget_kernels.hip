@@ -7,6 +7,8 @@
 //   bbox_kernel      bounding box of every cloud (the Morton grid): strided workgroups, merged with integer atomics
 //   morton_kernel    30-bit code per point (10 bits per axis inside the box)
 //   <rocPRIM>        stable radix sort of (code, index)
+//   tile_gather_kernel  one workgroup per 1024-point tile: the tile's points in sorted order (the only gather of the build),
+//                    the sorted-position -> original-index table, the tile's bounding box
 //   centre_kernel    one workgroup per 1024-point tile: tile box -> centre c; tc = fl(t - c) (the float32 subtraction the
 //                    bound is written for), tt = fl(|tc|^2) from double, r^2 = max |tc|^2 rounded up; also the sorted
 //                    copy of the original coordinates, the sorted-position -> original-index table, and the bf16
@@ -121,45 +123,76 @@ __global__ __launch_bounds__(kBlockThreads) void morton_kernel(const float* __re
 }
 
 // grid = tiles of one cloud, block = 256 (4 points per thread).  order[]: sorted position -> index inside the cloud.
-__global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __restrict__ px, const float* __restrict__ py,
-                                                                const float* __restrict__ pz, uint32_t off, uint32_t n,
-                                                                const uint32_t* __restrict__ order, float* __restrict__ xt,
-                                                                size_t stride, uint32_t* __restrict__ perm,
-                                                                float* __restrict__ table, uint4* __restrict__ bf_image,
-                                                                float4* __restrict__ sub_table, float* __restrict__ bf_table) {
+// Writes the sorted copy of the original coordinates (planes 4-6 of xt), perm, the tile's box (tile_box: 8 floats per tile,
+// lo in 0-2, hi in 4-6) and clears the slot the group's r^2 is gathered in (bf_table row, word 3: centre_kernel).
+__global__ __launch_bounds__(kBlockThreads) void tile_gather_kernel(const float* __restrict__ px, const float* __restrict__ py,
+                                                                     const float* __restrict__ pz, uint32_t off, uint32_t n,
+                                                                     const uint32_t* __restrict__ order, float* __restrict__ xt,
+                                                                     size_t stride, uint32_t* __restrict__ perm,
+                                                                     float* __restrict__ tile_box, float* __restrict__ bf_table) {
   __shared__ float slo[4][3], shi[4][3];
-  __shared__ double sr2[4];
   const uint32_t t0 = blockIdx.x * kTile;
-  float x[4], y[4], z[4];
-  uint32_t src[4];
   float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  float* tcx = xt + off;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t s = t0 + k * kBlockThreads + threadIdx.x;
-    src[k] = 0xFFFFFFFFu;
     if (s < n) {
-      src[k] = order[s];
-      x[k] = px[off + src[k]];
-      y[k] = py[off + src[k]];
-      z[k] = pz[off + src[k]];
-      lo[0] = __builtin_fminf(lo[0], x[k]); hi[0] = __builtin_fmaxf(hi[0], x[k]);
-      lo[1] = __builtin_fminf(lo[1], y[k]); hi[1] = __builtin_fmaxf(hi[1], y[k]);
-      lo[2] = __builtin_fminf(lo[2], z[k]); hi[2] = __builtin_fmaxf(hi[2], z[k]);
+      const uint32_t src = order[s];
+      const float x = px[off + src], y = py[off + src], z = pz[off + src];
+      tcx[4 * stride + s] = x;
+      tcx[5 * stride + s] = y;
+      tcx[6 * stride + s] = z;
+      perm[off + s] = src;
+      lo[0] = __builtin_fminf(lo[0], x); hi[0] = __builtin_fmaxf(hi[0], x);
+      lo[1] = __builtin_fminf(lo[1], y); hi[1] = __builtin_fmaxf(hi[1], y);
+      lo[2] = __builtin_fminf(lo[2], z); hi[2] = __builtin_fmaxf(hi[2], z);
+    }
+  }
+  block_minmax<kBlockThreads>(lo, hi, slo, shi);
+  if (threadIdx.x == 0) {
+    const size_t tile = (off + t0) / kTile;
+    float* b = tile_box + 8 * tile;
+    b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2];
+    b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2];
+    bf_table[4 * tile + 3] = 0.0f;
+  }
+}
+
+// grid = tiles of one cloud, block = 256 (4 points per thread), after tile_gather_kernel on the same stream.
+__global__ __launch_bounds__(kBlockThreads) void centre_kernel(uint32_t off, uint32_t n, const float* __restrict__ tile_box,
+                                                                float* __restrict__ xt, size_t stride, float* __restrict__ table,
+                                                                uint4* __restrict__ bf_image, float4* __restrict__ sub_table,
+                                                                float* __restrict__ bf_table) {
+  __shared__ double sr2[4];
+  const uint32_t t0 = blockIdx.x * kTile;
+  float* tcx = xt + off;
+  float x[4], y[4], z[4];
+  bool here[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t s = t0 + k * kBlockThreads + threadIdx.x;
+    here[k] = s < n;
+    x[k] = y[k] = z[k] = 0.f;
+    if (here[k]) {
+      x[k] = tcx[4 * stride + s];
+      y[k] = tcx[5 * stride + s];
+      z[k] = tcx[6 * stride + s];
     }
   }
   // bounding spheres of the 64-point runs (a wave's lanes at one k hold 64 consecutive sorted positions): the pruned
   // k-NN scan skips runs no query of a wave can reach.  An empty run (padding only) sits at 3e38 with radius 0.
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const bool real = src[k] != 0xFFFFFFFFu;
+    const bool real = here[k];
     float blo[3] = {real ? x[k] : __builtin_inff(), real ? y[k] : __builtin_inff(), real ? z[k] : __builtin_inff()};
     float bhi[3] = {real ? x[k] : -__builtin_inff(), real ? y[k] : -__builtin_inff(), real ? z[k] : -__builtin_inff()};
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        blo[a] = __builtin_fminf(blo[a], __shfl_xor(blo[a], off, 64));
-        bhi[a] = __builtin_fmaxf(bhi[a], __shfl_xor(bhi[a], off, 64));
+      for (int off2 = 32; off2 >= 1; off2 >>= 1) {
+        blo[a] = __builtin_fminf(blo[a], __shfl_xor(blo[a], off2, 64));
+        bhi[a] = __builtin_fmaxf(bhi[a], __shfl_xor(bhi[a], off2, 64));
       }
     const bool any = blo[0] <= bhi[0];
     const float sx_ = any ? 0.5f * blo[0] + 0.5f * bhi[0] : kTargetPad, sy_ = any ? 0.5f * blo[1] + 0.5f * bhi[1] : kTargetPad,
@@ -170,8 +203,8 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __re
       rr = ex * ex + ey * ey + ez * ez;
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double other = __shfl_xor(rr, off, 64);
+    for (int off2 = 32; off2 >= 1; off2 >>= 1) {
+      const double other = __shfl_xor(rr, off2, 64);
       rr = other > rr ? other : rr;
     }
     if ((threadIdx.x & 63u) == 0) {
@@ -179,44 +212,25 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __re
       sub_table[static_cast<size_t>((off + t0) / 64) + k * 4 + (threadIdx.x >> 6)] = make_float4(sx_, sy_, sz_, any ? rf : 0.0f);
     }
   }
-  block_minmax<kBlockThreads>(lo, hi, slo, shi);
+  // this tile's box, and the box of its GROUP of kXbCentreGroup tiles (icp_internal.h) - the matrix-core operand image is
+  // centred per group: the union of the group's tile boxes (tile_gather_kernel), the same words in every workgroup of the group
+  const size_t own_tile = (off + t0) / kTile;
+  const uint32_t n_tiles = (n + kTile - 1) / kTile;
+  const float* ob = tile_box + 8 * own_tile;
+  const float lo[3] = {ob[0], ob[1], ob[2]}, hi[3] = {ob[4], ob[5], ob[6]};
   const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
-  // The matrix-core operand image is centred per GROUP of kXbCentreGroup tiles (icp_internal.h): every workgroup of a
-  // group reads the whole group's points, so all of them arrive at the same centre and the same r^2 without talking to
-  // each other.
-  const uint32_t group0 = (blockIdx.x / kXbCentreGroup) * kXbCentreGroup * kTile;   // first sorted position of the group
-  float gx_[kXbCentreGroup - 1][4], gy_[kXbCentreGroup - 1][4], gz_[kXbCentreGroup - 1][4];
-  bool greal[kXbCentreGroup - 1][4];
-  float glo[3] = {lo[0], lo[1], lo[2]}, ghi[3] = {hi[0], hi[1], hi[2]};   // this tile's box (block-wide), then the others' points
-  {
-    float plo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, phi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    int slot = 0;
+  const uint32_t group_first = (blockIdx.x / kXbCentreGroup) * kXbCentreGroup;   // first tile of the group, inside the cloud
+  float glo[3] = {lo[0], lo[1], lo[2]}, ghi[3] = {hi[0], hi[1], hi[2]};
 #pragma unroll
-    for (int g = 0; g < kXbCentreGroup; ++g) {
-      const uint32_t tg = group0 + g * kTile;
-      if (tg == t0) continue;
+  for (int g = 0; g < kXbCentreGroup; ++g) {
+    const uint32_t tg = group_first + g;
+    if (tg < n_tiles && tg != blockIdx.x) {
+      const float* gb = tile_box + 8 * (static_cast<size_t>(off / kTile) + tg);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t sp = tg + k * kBlockThreads + threadIdx.x;
-        greal[slot][k] = sp < n;
-        if (greal[slot][k]) {
-          const uint32_t sidx = order[sp];
-          gx_[slot][k] = px[off + sidx];
-          gy_[slot][k] = py[off + sidx];
-          gz_[slot][k] = pz[off + sidx];
-          plo[0] = __builtin_fminf(plo[0], gx_[slot][k]); phi[0] = __builtin_fmaxf(phi[0], gx_[slot][k]);
-          plo[1] = __builtin_fminf(plo[1], gy_[slot][k]); phi[1] = __builtin_fmaxf(phi[1], gy_[slot][k]);
-          plo[2] = __builtin_fminf(plo[2], gz_[slot][k]); phi[2] = __builtin_fmaxf(phi[2], gz_[slot][k]);
-        }
+      for (int a = 0; a < 3; ++a) {
+        glo[a] = __builtin_fminf(glo[a], gb[a]);
+        ghi[a] = __builtin_fmaxf(ghi[a], gb[4 + a]);
       }
-      ++slot;
-    }
-    __syncthreads();  // slo / shi are reused
-    block_minmax<kBlockThreads>(plo, phi, slo, shi);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      glo[a] = __builtin_fminf(glo[a], plo[a]);
-      ghi[a] = __builtin_fmaxf(ghi[a], phi[a]);
     }
   }
   const float bcx = 0.5f * glo[0] + 0.5f * ghi[0], bcy = 0.5f * glo[1] + 0.5f * ghi[1], bcz = 0.5f * glo[2] + 0.5f * ghi[2];
@@ -229,41 +243,18 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __re
                  qz = static_cast<double>(bf16_value(h[2])) + bf16_value(l[2]);
     return qx * qx + qy * qy + qz * qz;
   };
-  double br2 = 0.0;   // max over the GROUP of |tc|^2 and |tc'|^2 around the group centre
-  {
-    int slot = 0;
-#pragma unroll
-    for (int g = 0; g < kXbCentreGroup; ++g) {
-      if (group0 + g * kTile == t0) continue;
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (greal[slot][k]) {
-          uint32_t h[3], l[3];
-          float ddx, ddy, ddz;
-          const double n2q = quantise(gx_[slot][k], gy_[slot][k], gz_[slot][k], h, l, ddx, ddy, ddz);
-          const double n2 = static_cast<double>(ddx) * ddx + static_cast<double>(ddy) * ddy + static_cast<double>(ddz) * ddz;
-          br2 = n2 > br2 ? n2 : br2;
-          br2 = n2q > br2 ? n2q : br2;
-        }
-      ++slot;
-    }
-  }
+  double br2 = 0.0;   // max over THIS tile of |tc|^2 and |tc'|^2 around the group centre; the group's is gathered below
   double r2 = 0.0;
-  float* tcx = xt + off;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t s = t0 + k * kBlockThreads + threadIdx.x;
-    if (src[k] != 0xFFFFFFFFu) {
+    if (here[k]) {
       const float dx = x[k] - cx, dy = y[k] - cy, dz = z[k] - cz;  // the float32 subtractions the bound is written for
       const double n2 = static_cast<double>(dx) * dx + static_cast<double>(dy) * dy + static_cast<double>(dz) * dz;
       tcx[s] = dx;
       tcx[stride + s] = dy;
       tcx[2 * stride + s] = dz;
       tcx[3 * stride + s] = static_cast<float>(n2);
-      tcx[4 * stride + s] = x[k];
-      tcx[5 * stride + s] = y[k];
-      tcx[6 * stride + s] = z[k];
-      perm[off + s] = src[k];
       r2 = n2 > r2 ? n2 : r2;
       // matrix-core operand image.  Row slot of sorted position w inside its tile: chunk c = w / 256; the chunk's two
       // 128-target runs belong to the two halves of the wave (hh); within a run, 16 consecutive targets are the rows
@@ -316,8 +307,17 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(const float* __re
     double m = sr2[0];
     for (int w = 1; w < 4; ++w) m = sr2[w] > m ? sr2[w] : m;
     const float r = __uint_as_float(__float_as_uint(static_cast<float>(m)) + 1u);
-    float* row = bf_table + 4 * static_cast<size_t>((off + t0) / kTile);
-    row[0] = bcx; row[1] = bcy; row[2] = bcz; row[3] = r;
+    float* row = bf_table + 4 * own_tile;
+    row[0] = bcx; row[1] = bcy; row[2] = bcz;
+    // the group's r^2 = the largest of its tiles': every workgroup of the group raises the slot of EVERY tile of the group
+    // (cleared by tile_gather_kernel; non-negative floats order like their bits; rounding to float and the step up are
+    // monotone, so the largest rounded value is the rounded largest value - what one workgroup walking the whole group
+    // wrote in rounds 1-3)
+#pragma unroll
+    for (int g = 0; g < kXbCentreGroup; ++g) {
+      const uint32_t tg = group_first + g;
+      if (tg < n_tiles) atomicMax(reinterpret_cast<uint32_t*>(bf_table + 4 * (static_cast<size_t>(off / kTile) + tg) + 3), __float_as_uint(r));
+    }
   }
 }
 
@@ -466,11 +466,20 @@ __global__ __launch_bounds__(kBlockThreads) void level_order_write_kernel(const 
     if (flags & (1u << k)) order[at++] = li[k];
 }
 
+// the two launches that turn an order into the sorted copy: tile_box = 8 floats per tile of the whole set (scratch)
+static void launch_centre(hipStream_t st, DevicePlanes planes, uint32_t off, uint32_t n, const uint32_t* order, float* xt, size_t stride,
+                          uint32_t* perm, float* table, void* bf_image, void* sub_table, float* bf_table, float* tile_box) {
+  const dim3 grid((n + kTile - 1) / kTile), block(kBlockThreads);
+  hipLaunchKernelGGL(tile_gather_kernel, grid, block, 0, st, planes.x, planes.y, planes.z, off, n, order, xt, stride, perm, tile_box, bf_table);
+  hipLaunchKernelGGL(centre_kernel, grid, block, 0, st, off, n, tile_box, xt, stride, table, static_cast<uint4*>(bf_image),
+                     static_cast<float4*>(sub_table), bf_table);
+}
+
 // The level's copy from its parent's order: `parent_perm` = the level-0 sorted copy's table for this cloud (n_parent
 // entries), `first`/`step` = which level-0 rows the level holds.  scratch: n + ceil(n_parent / 4096) words.
 int xtarget_build_cloud_from_parent(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const uint32_t* parent_perm,
                                     uint32_t n_parent, uint32_t first, uint32_t step, uint32_t* scratch, float* xt, size_t stride,
-                                    uint32_t* perm, float* table, void* bf_image, void* sub_table, float* bf_table) {
+                                    uint32_t* perm, float* table, void* bf_image, void* sub_table, float* bf_table, float* tile_box) {
   if (!n) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const uint32_t blocks = (n_parent + kBlockThreads * kOrderItems - 1) / (kBlockThreads * kOrderItems);
@@ -478,22 +487,20 @@ int xtarget_build_cloud_from_parent(void* stream, DevicePlanes planes, uint32_t 
   uint32_t* counts = scratch + n;
   hipLaunchKernelGGL(level_order_count_kernel, dim3(blocks), dim3(kBlockThreads), 0, st, parent_perm, n_parent, first, step, n, counts);
   hipLaunchKernelGGL(level_order_write_kernel, dim3(blocks), dim3(kBlockThreads), 0, st, parent_perm, n_parent, first, step, n, counts, order);
-  hipLaunchKernelGGL(centre_kernel, dim3((n + kTile - 1) / kTile), dim3(kBlockThreads), 0, st, planes.x, planes.y, planes.z, off, n,
-                     order, xt, stride, perm, table, static_cast<uint4*>(bf_image), static_cast<float4*>(sub_table), bf_table);
+  launch_centre(st, planes, off, n, order, xt, stride, perm, table, bf_image, sub_table, bf_table, tile_box);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, const uint32_t* box, uint32_t* code,
                         uint32_t* index, uint32_t* code2, uint32_t* order, void* temp, size_t temp_bytes, float* xt,
-                        size_t stride, uint32_t* perm, float* table, void* bf_image, void* sub_table, float* bf_table) {
+                        size_t stride, uint32_t* perm, float* table, void* bf_image, void* sub_table, float* bf_table, float* tile_box) {
   if (!n) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(morton_kernel, dim3((n + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, st, planes.x, planes.y,
                      planes.z, off, n, box, code, index);
   size_t tb = temp_bytes;
   if (rocprim::radix_sort_pairs(temp, tb, code, code2, index, order, n, 0, 30, st, false) != hipSuccess) return 1;
-  hipLaunchKernelGGL(centre_kernel, dim3((n + kTile - 1) / kTile), dim3(kBlockThreads), 0, st, planes.x, planes.y, planes.z, off, n,
-                     order, xt, stride, perm, table, static_cast<uint4*>(bf_image), static_cast<float4*>(sub_table), bf_table);
+  launch_centre(st, planes, off, n, order, xt, stride, perm, table, bf_image, sub_table, bf_table, tile_box);
   return 0;
 }
 
