@@ -1146,11 +1146,20 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
     set.shard_begin = want_begin;
     set.shard_total = want_total;
   }
-  while (static_cast<int>(set.levels.size()) < level) {
-    const int l = static_cast<int>(set.levels.size()) + 1;
+  // every missing level up to `level` at once: reference mode starts at the coarsest level, so a new scene asks for all of
+  // them in its first call - one launch per cloud instead of one per cloud and level (7 small dependent launches per request)
+  const int have = static_cast<int>(set.levels.size());
+  if (have >= level) return MI355_ICP_OK;
+  std::vector<LevelPlanes> fresh;
+  auto give_back = [&]() {
+    for (auto& lv : fresh) {
+      c->pool.give(lv.rows);
+      c->pool.give(lv.planes);
+    }
+  };
+  for (int l = have + 1; l <= level; ++l) {
     const uint32_t step = 1u << l;
     LevelPlanes lv;
-    std::vector<uint32_t> first;
     uint64_t total = 0;
     for (size_t k = 0; k < set.clouds.size(); ++k) {
       const CloudEntry& e = set.clouds[k];
@@ -1160,30 +1169,36 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
       lv.clouds.push_back(CloudEntry{static_cast<uint32_t>(total), static_cast<uint32_t>(n), static_cast<uint32_t>(padded)});
       lv.index_base.push_back(static_cast<uint32_t>(base));
       lv.n_total.push_back(static_cast<uint32_t>(n_all));
-      first.push_back(static_cast<uint32_t>(f));
+      lv.first.push_back(static_cast<uint32_t>(f));
       total += padded;
     }
     lv.stride = static_cast<size_t>(std::max<uint64_t>(total, pad_multiple));
-    HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&lv.planes), 3 * lv.stride * sizeof(float)));
+    hipError_t e = c->pool.take(reinterpret_cast<void**>(&lv.planes), 3 * lv.stride * sizeof(float));
     // a set with normals (targets of reference mode): the level's target rows come out of the same launch (ensure_target_rows)
-    if (set.normals && c->pool.take(&lv.rows, lv.stride * 32) != hipSuccess) {
-      c->pool.give(lv.planes);
-      return fail(c, MI355_ICP_ERR_HIP, "building pyramid level: no memory for the target rows");
-    }
-    hipError_t e = hipSuccess;
-    if (total == 0) e = hipMemsetAsync(lv.planes, 0, 3 * lv.stride * sizeof(float), c->stream);
-    for (size_t k = 0; k < set.clouds.size() && e == hipSuccess; ++k)
-      launch_subsample(c->stream, set.planes, set.stride, set.clouds[k].off + first[k], lv.planes, lv.stride, lv.clouds[k].off,
-                       lv.clouds[k].n, lv.clouds[k].padded, step, pad_value, set.normals, lv.rows);
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e != hipSuccess) {  // the level is not adopted: give its planes back
-      c->pool.give(lv.rows);
-      c->pool.give(lv.planes);
+    if (e == hipSuccess && set.normals) e = c->pool.take(&lv.rows, lv.stride * 32);
+    if (e == hipSuccess && total == 0) e = hipMemsetAsync(lv.planes, 0, 3 * lv.stride * sizeof(float), c->stream);
+    fresh.push_back(lv);
+    if (e != hipSuccess) {
+      give_back();
       return fail(c, MI355_ICP_ERR_HIP, std::string("building pyramid level: ") + hipGetErrorString(e));
     }
-    lv.first = first;
-    set.levels.push_back(lv);
   }
+  for (size_t k = 0; k < set.clouds.size(); ++k)
+    for (size_t q0 = 0; q0 < fresh.size(); q0 += kSubsampleMaxLevels) {
+      SubsampleArgs A{};
+      A.n_levels = static_cast<int>(std::min<size_t>(kSubsampleMaxLevels, fresh.size() - q0));
+      for (int q = 0; q < A.n_levels; ++q) {
+        const LevelPlanes& lv = fresh[q0 + static_cast<size_t>(q)];
+        A.lv[q] = SubsampleLevel{lv.planes, lv.rows, static_cast<uint32_t>(lv.stride), lv.clouds[k].off, set.clouds[k].off + lv.first[k],
+                                 lv.clouds[k].n, lv.clouds[k].padded, static_cast<uint32_t>(have + 1 + static_cast<int>(q0) + q)};
+      }
+      launch_subsample_levels(c->stream, set.planes, set.stride, A, pad_value, set.normals);
+    }
+  if (const hipError_t e = hipGetLastError(); e != hipSuccess) {  // the levels are not adopted: give their planes back
+    give_back();
+    return fail(c, MI355_ICP_ERR_HIP, std::string("building pyramid levels: ") + hipGetErrorString(e));
+  }
+  for (auto& lv : fresh) set.levels.push_back(lv);
   return MI355_ICP_OK;
 }
 

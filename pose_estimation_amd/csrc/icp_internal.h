@@ -402,10 +402,19 @@ void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t 
 void launch_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums,
                          uint32_t* overflow_count, uint32_t overflow_cap);
 
-// normals + rows given: the level's target rows are written along (the normals share the planes' layout: same stride, same offsets)
-void launch_subsample(void* stream, const float* in, size_t in_stride, uint32_t in_off, float* out, size_t out_stride,
-                      uint32_t out_off, uint32_t n_level, uint32_t n_padded, uint32_t step, float pad, const float* normals = nullptr,
-                      void* rows = nullptr);
+// Pyramid levels of ONE cloud in one launch (a new scene builds seven): level q holds the level-0 rows in_off + i * 2^step_log2.
+// normals given: a level with `rows` also gets its target rows (the normals share the planes' layout: same stride, same offsets).
+struct SubsampleLevel {
+  float* out;        // the level's planes, x | y | z, each out_stride floats
+  void* rows;        // the level's target rows (32 bytes per point) or nullptr
+  uint32_t out_stride, out_off, in_off, n, padded, step_log2;
+};
+constexpr int kSubsampleMaxLevels = 8;
+struct SubsampleArgs {
+  SubsampleLevel lv[kSubsampleMaxLevels];
+  int n_levels;
+};
+void launch_subsample_levels(void* stream, const float* in, size_t in_stride, const SubsampleArgs& args, float pad, const float* normals);
 bool launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_n, const float* dist2, float scale,
                              float* thr, uint32_t* hists, uint32_t* states, const RefJobDesc* rjobs_dev = nullptr,
                              const int32_t* index = nullptr, unsigned long long* owner = nullptr);

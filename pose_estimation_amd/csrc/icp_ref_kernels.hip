@@ -6,7 +6,7 @@
 // compacted planes.  Arithmetic contract: oracle/icp_oracle.c, second half (bit-exact threshold, mask and
 // winners; sums in double).  Compile with -ffp-contract=off like icp_kernels.hip.
 //
-//   subsample_kernel          level planes:  out[i] = in[i * step], padded
+//   subsample_kernel          level planes:  out[i] = in[i * step], padded - every missing level of a cloud in one launch
 //   rejection_select_reg_kernel  per job, ONE workgroup, values in registers (jobs of up to 32k points): exact rank
 //                             select (11-bit radix digits from the highest bit that differs, LDS histograms, the last
 //                             <= 256 candidates ranked by counting) of d2, then of |d2 - med|  ->  threshold
@@ -74,25 +74,33 @@ __device__ __forceinline__ void transform_point(const float* __restrict__ m, flo
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-// normals != nullptr (targets uploaded with normals): the launch also writes the level's target rows (target_rows_kernel's
-// records: the level's coordinates with the normal of the level-0 row each point came from) - one launch less per level of a new scene.
-__global__ __launch_bounds__(kBlockThreads) void subsample_kernel(const float* __restrict__ in, size_t in_stride,
-                                                                   uint32_t in_off, float* __restrict__ out,
-                                                                   size_t out_stride, uint32_t out_off, uint32_t n_level,
-                                                                   uint32_t n_padded, uint32_t step, float pad,
-                                                                   const float* __restrict__ normals, float4* __restrict__ rows) {
-  const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
-  if (i >= n_padded) return;
-  float v[3];
+// Levels step_log2 = s0, s0 + 1, ... of one cloud in ONE launch: thread j stands for level-0 row j * 2^s0 (relative to the
+// level's first row) and writes it to every level whose stride divides it; the grid covers the longest padded level.
+// normals != nullptr (targets uploaded with normals): a level with `rows` also gets its target rows (target_rows_kernel's
+// records: the level's coordinates with the normal of the level-0 row each point came from).
+__global__ __launch_bounds__(kBlockThreads) void subsample_kernel(const float* __restrict__ in, size_t in_stride, SubsampleArgs A, float pad,
+                                                                   const float* __restrict__ normals) {
+  const uint32_t j = blockIdx.x * kBlockThreads + threadIdx.x;
+  const uint32_t s0 = A.lv[0].step_log2;
+#pragma unroll 1
+  for (int q = 0; q < A.n_levels; ++q) {
+    const SubsampleLevel& L = A.lv[q];
+    const uint32_t shift = L.step_log2 - s0;
+    if (j & ((1u << shift) - 1u)) break;  // levels are listed finest first: a row that is not on this one is on none of the coarser
+    const uint32_t i = j >> shift;
+    if (i >= L.padded) continue;
+    float v[3];
+    const size_t row = L.in_off + (static_cast<size_t>(i) << L.step_log2);
 #pragma unroll
-  for (int plane = 0; plane < 3; ++plane) {
-    v[plane] = i < n_level ? in[plane * in_stride + in_off + static_cast<size_t>(i) * step] : pad;
-    out[plane * out_stride + out_off + i] = v[plane];
-  }
-  if (normals && i < n_level) {
-    const size_t nj = in_off + static_cast<size_t>(i) * step;
-    rows[2 * static_cast<size_t>(out_off + i)] = make_float4(v[0], v[1], v[2], normals[nj]);
-    rows[2 * static_cast<size_t>(out_off + i) + 1] = make_float4(normals[in_stride + nj], normals[2 * in_stride + nj], 0.f, 0.f);
+    for (int plane = 0; plane < 3; ++plane) {
+      v[plane] = i < L.n ? in[plane * in_stride + row] : pad;
+      L.out[static_cast<size_t>(plane) * L.out_stride + L.out_off + i] = v[plane];
+    }
+    if (normals && L.rows && i < L.n) {
+      float4* rows = static_cast<float4*>(L.rows);
+      rows[2 * static_cast<size_t>(L.out_off + i)] = make_float4(v[0], v[1], v[2], normals[row]);
+      rows[2 * static_cast<size_t>(L.out_off + i) + 1] = make_float4(normals[in_stride + row], normals[2 * in_stride + row], 0.f, 0.f);
+    }
   }
 }
 
@@ -718,13 +726,12 @@ __global__ __launch_bounds__(kBlockThreads) void ref_final_reduce_kernel(const J
 }
 
 // ---------------------------------------------------------------------------------------------
-void launch_subsample(void* stream, const float* in, size_t in_stride, uint32_t in_off, float* out, size_t out_stride,
-                      uint32_t out_off, uint32_t n_level, uint32_t n_padded, uint32_t step, float pad, const float* normals,
-                      void* rows) {
-  if (!n_padded) return;
-  hipLaunchKernelGGL(subsample_kernel, dim3((n_padded + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0,
-                     static_cast<hipStream_t>(stream), in, in_stride, in_off, out, out_stride, out_off, n_level, n_padded,
-                     step, pad, rows ? normals : nullptr, static_cast<float4*>(rows));
+void launch_subsample_levels(void* stream, const float* in, size_t in_stride, const SubsampleArgs& args, float pad, const float* normals) {
+  uint32_t threads = 0;
+  for (int q = 0; q < args.n_levels; ++q) threads = std::max(threads, args.lv[q].padded << (args.lv[q].step_log2 - args.lv[0].step_log2));
+  if (!threads) return;
+  hipLaunchKernelGGL(subsample_kernel, dim3((threads + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0,
+                     static_cast<hipStream_t>(stream), in, in_stride, args, pad, normals);
 }
 
 // max_n: largest job of the launch.  hists / states: scratch zeroed once at allocation (the pick kernel leaves the
