@@ -2088,14 +2088,15 @@ int mi355_icp_scene_filter(mi355_icp_ctx* c, int n_filters, const mi355_scene_fi
   const uint32_t n_tiles = (n + kSceneTile - 1) / kSceneTile;
   if (n_tiles) {
     int st;
-    if ((st = grow(c, c->scene_state, c->scene_state_cap, static_cast<size_t>(n_tiles))) != MI355_ICP_OK) return st;
-    HIP_TRY(c, hipMemsetAsync(c->scene_state, 0, static_cast<size_t>(n_tiles) * sizeof(unsigned long long), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->scene_counters, 0, 4 * sizeof(uint32_t), c->stream));
+    // the tiles' look-back words and, behind them, this pass's counters (ticket, kept total, error bits): one clear for both
+    if ((st = grow(c, c->scene_state, c->scene_state_cap, static_cast<size_t>(n_tiles) + 2)) != MI355_ICP_OK) return st;
+    uint32_t* counters = reinterpret_cast<uint32_t*>(c->scene_state + n_tiles);
+    HIP_TRY(c, hipMemsetAsync(c->scene_state, 0, (static_cast<size_t>(n_tiles) + 2) * sizeof(unsigned long long), c->stream));
     if (c->profile_always) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-    launch_scene_compact(c->stream, c->scene[c->scene_cur], n, F, c->scene[c->scene_cur ^ 1], c->scene_state, c->scene_counters, n_tiles);
+    launch_scene_compact(c->stream, c->scene[c->scene_cur], n, F, c->scene[c->scene_cur ^ 1], c->scene_state, counters, n_tiles);
     if (c->profile_always) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->scene_counters_host, c->scene_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->scene_counters_host, counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->scene_counters_host[2] & 1u) return fail(c, MI355_ICP_ERR_INTERNAL, "scene_filter: look-back timed out");
     if (c->profile_always) {
@@ -2231,8 +2232,7 @@ int mi355_icp_scene_fit_plane(mi355_icp_ctx* c, const mi355_plane_fit_params* fp
   const float* planes = reinterpret_cast<const float*>(c->plane_host);
   const uint32_t* counts = reinterpret_cast<const uint32_t*>(c->plane_host + kHypBytes);
   const double* rows = reinterpret_cast<const double*>(c->plane_host + kHypBytes + kCountBytes);
-  HIP_TRY(c, hipMemsetAsync(c->plane_counts, 0, kCountBytes, c->stream));
-  launch_plane_hypotheses(c->stream, scene, n, fp->seed, n_hyp, c->plane_hyp);
+  launch_plane_hypotheses(c->stream, scene, n, fp->seed, n_hyp, c->plane_hyp, c->plane_counts);  // also clears the counters it will need
   launch_plane_support(c->stream, scene, n, c->plane_hyp, n_hyp, fp->distance_threshold, c->plane_counts);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(c->plane_host, c->plane_hyp, kHypBytes + kCountBytes, hipMemcpyDeviceToHost, c->stream));

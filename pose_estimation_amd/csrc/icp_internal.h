@@ -320,7 +320,9 @@ void launch_scene_compact(void* stream, const float* in, uint32_t n, const Scene
 // support counts in one pass, and the 10 moments (n, sum p, sum p p^T upper triangle) of one plane's inliers per 1024-point block
 constexpr int kPlaneMaxHypotheses = 1024;
 constexpr int kPlaneMoments = 10;
-void launch_plane_hypotheses(void* stream, const float* scene, uint32_t n, unsigned long long seed, uint32_t n_hyp, float* planes4);
+// counts: kPlaneMaxHypotheses + 1 support counters; the launch clears the first n_hyp and the last
+void launch_plane_hypotheses(void* stream, const float* scene, uint32_t n, unsigned long long seed, uint32_t n_hyp, float* planes4,
+                             uint32_t* counts);
 void launch_plane_support(void* stream, const float* scene, uint32_t n, const float* planes4, uint32_t n_hyp, float threshold, uint32_t* counts);
 // one plane, passed by value (host memory): its inlier count is ADDED to *count
 void launch_plane_support_one(void* stream, const float* scene, uint32_t n, const float* plane4, float threshold, uint32_t* count);

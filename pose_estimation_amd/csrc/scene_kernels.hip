@@ -309,10 +309,14 @@ __device__ __forceinline__ uint32_t plane_draw(unsigned long long seed, unsigned
 }  // namespace
 
 // one thread per hypothesis
+// Also clears the support counters of the fit: counts[h] for its hypothesis and the spare one behind the last possible
+// hypothesis (the refitted plane's), so that the fit needs no fill launch in front.
 __global__ void plane_hypotheses_kernel(const float* __restrict__ scene, uint32_t n, unsigned long long seed, uint32_t n_hyp,
-                                        float4* __restrict__ planes) {
+                                        float4* __restrict__ planes, uint32_t* __restrict__ counts) {
   const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h == 0) counts[kPlaneMaxHypotheses] = 0;
   if (h >= n_hyp) return;
+  counts[h] = 0;
   float4 out = make_float4(0.f, 0.f, 0.f, __builtin_nanf(""));
   for (uint32_t attempt = 0; attempt < 16; ++attempt) {
     const unsigned long long base = (static_cast<unsigned long long>(h) * 16ull + attempt) * 3ull;
@@ -422,9 +426,10 @@ __global__ __launch_bounds__(kBlockThreads) void plane_moments_kernel(const floa
   }
 }
 
-void launch_plane_hypotheses(void* stream, const float* scene, uint32_t n, unsigned long long seed, uint32_t n_hyp, float* planes4) {
+void launch_plane_hypotheses(void* stream, const float* scene, uint32_t n, unsigned long long seed, uint32_t n_hyp, float* planes4,
+                             uint32_t* counts) {
   hipLaunchKernelGGL(plane_hypotheses_kernel, dim3((n_hyp + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), scene, n, seed, n_hyp,
-                     reinterpret_cast<float4*>(planes4));
+                     reinterpret_cast<float4*>(planes4), counts);
 }
 void launch_plane_support(void* stream, const float* scene, uint32_t n, const float* planes4, uint32_t n_hyp, float threshold, uint32_t* counts) {
   const uint32_t blocks = (n + 4 * kBlockThreads - 1) / (4 * kBlockThreads);
