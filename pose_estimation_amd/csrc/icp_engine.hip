@@ -778,9 +778,7 @@ int alloc_xcopy(mi355_icp_ctx* c, XCopy& x, size_t stride) {
   if (!x.bf_table) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.bf_table), 4 * (stride / kTile) * sizeof(float)));
   if (!x.sub) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.sub), (stride / 64) * 4 * sizeof(float)));
   if (!x.super) HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&x.super), (stride / kTile / kSuperTiles + 1) * 4 * sizeof(float)));
-  launch_xt_fill(c->stream, x.planes, stride, x.perm, x.bf);
-  HIP_TRY(c, hipMemsetAsync(x.table, 0, 4 * (stride / kTile) * sizeof(float), c->stream));
-  HIP_TRY(c, hipMemsetAsync(x.bf_table, 0, 4 * (stride / kTile) * sizeof(float), c->stream));
+  launch_xt_fill(c->stream, x.planes, stride, x.perm, x.bf, x.table, x.bf_table);  // padding of every plane; both per-tile tables cleared
   return MI355_ICP_OK;
 }
 

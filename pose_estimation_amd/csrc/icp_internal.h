@@ -448,7 +448,7 @@ int xtarget_build_cloud(void* stream, DevicePlanes planes, uint32_t off, uint32_
 void launch_super_tiles(void* stream, const float* table, uint32_t n_tiles_total, float* super_table);
 void launch_bbox(void* stream, DevicePlanes planes, const uint32_t* cloud_off, const uint32_t* cloud_n, int n_clouds, uint32_t max_n,
                  uint32_t* box);
-void launch_xt_fill(void* stream, float* xt, size_t stride, uint32_t* perm, void* bf_image);
+void launch_xt_fill(void* stream, float* xt, size_t stride, uint32_t* perm, void* bf_image, float* table, float* bf_table);  // both tables: 4 floats per tile, cleared
 
 // ---- scene normals (normals_kernels.hip) ----
 constexpr int kMaxNormalNeighbors = 32;

@@ -322,10 +322,16 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(uint32_t off, uin
 }
 
 // fills the padding of all seven planes and the perm table before the per-cloud kernels run
+// ... and clears the two per-tile tables (four words per tile each: tiles the builder never writes stay r^2 = 0 at the origin)
 __global__ __launch_bounds__(kBlockThreads) void xt_fill_kernel(float* __restrict__ xt, size_t stride, uint32_t* __restrict__ perm,
-                                                                 uint4* __restrict__ bf_image) {
+                                                                 uint4* __restrict__ bf_image, float* __restrict__ table,
+                                                                 float* __restrict__ bf_table) {
   const size_t i = static_cast<size_t>(blockIdx.x) * kBlockThreads + threadIdx.x;
   if (i >= stride) return;
+  if (i < 4 * (stride / kTile)) {
+    table[i] = 0.f;
+    bf_table[i] = 0.f;
+  }
   // padding row of the matrix-core image: |tc'|^2 = +inf (bf16 0x7F80), everything else zero
   const size_t tile = i / kTile, slot = i % kTile;
   bf_image[tile * kXbTileVecs + slot] = make_uint4(0u, 0u, 0u, 0u);
@@ -514,9 +520,9 @@ void launch_bbox(void* stream, DevicePlanes planes, const uint32_t* cloud_off, c
                      cloud_off, cloud_n, box);
 }
 
-void launch_xt_fill(void* stream, float* xt, size_t stride, uint32_t* perm, void* bf_image) {
+void launch_xt_fill(void* stream, float* xt, size_t stride, uint32_t* perm, void* bf_image, float* table, float* bf_table) {
   hipLaunchKernelGGL(xt_fill_kernel, dim3(static_cast<uint32_t>((stride + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0,
-                     static_cast<hipStream_t>(stream), xt, stride, perm, static_cast<uint4*>(bf_image));
+                     static_cast<hipStream_t>(stream), xt, stride, perm, static_cast<uint4*>(bf_image), table, bf_table);
 }
 
 }  // namespace mi355
