@@ -17,11 +17,14 @@ import csv, glob, sys, collections
 out = sys.argv[1]
 for d in ("sq1", "sq2"):
     for f in glob.glob(f"{out}/{d}/**/*counter_collection.csv", recursive=True):
-        rows = [r for r in csv.DictReader(open(f)) if "knn_pruned" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if "knn_wave_kernel" in r["Kernel_Name"]]
         ids = sorted({int(r["Dispatch_Id"]) for r in rows})
-        last = ids[-1] if ids else None   # the 1M-point launch
-        print(d, "knn_pruned_kernel, last dispatch (1M points)")
-        for r in rows:
-            if int(r["Dispatch_Id"]) == last:
-                print(f"   {r['Counter_Name']:24s} {float(r['Counter_Value']):16.0f}")
+        # tools/bench_normals.py: 20k, 100k, 500k, 1M points, a warm-up launch and a timed one each
+        for tag, which in (("100k points", 3), ("1M points", len(ids) - 1)):
+            if which >= len(ids):
+                continue
+            print(d, "knn_wave_kernel,", tag)
+            for r in rows:
+                if int(r["Dispatch_Id"]) == ids[which]:
+                    print(f"   {r['Counter_Name']:24s} {float(r['Counter_Value']):16.0f}")
 PY
