@@ -609,6 +609,12 @@ __device__ __forceinline__ uint32_t min16(const f32x16& acc, uint32_t seed) {
 // (point, 128-target run) to dump[run * dump_stride + point position] - what the parity tests check the bound on.
 // kStaged: the launch is also the staging of a small pass (<= 8 jobs; see nn_scan_kernel): every workgroup reads its
 // descriptor from the kernel arguments and the first one writes the device tables for the launches behind it.
+#ifdef MI355_ICP_DIAG
+// Diagnostic build only (make diag): per-workgroup stamps of the matrix-core scan (100 MHz realtime counter):
+// [start, first tile in LDS, tiles walked, end, tiles << 48 | job << 40 | xcc << 32 | hw id] per workgroup (tools/xb_timeline.py)
+__device__ unsigned long long* g_diag_xb = nullptr;
+#endif
+
 template <int kSets, int kThreads, bool kDump = false, bool kStaged = false>
 __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDesc* __restrict__ jobs,
                                                                        const float* __restrict__ sx,
@@ -625,6 +631,9 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
   // blocks 31 and 32; block 32 does not exist and what is read there is never used: the tile's final step issues no MFMA for it)
   constexpr uint32_t kLdsPad = 96;
   __shared__ uint4 lds[2 * kXbTileVecs + kLdsPad];
+#ifdef MI355_ICP_DIAG
+  const unsigned long long diag_t0 = wall_clock64();
+#endif
   if constexpr (kStaged) {
     if (blockIdx.x == 0 && blockIdx.y == 0) {
       constexpr uint32_t kJ = sizeof(JobDesc) / 4, kR = sizeof(RefJobDesc) / 4;
@@ -674,6 +683,9 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
   for (int k = 0; k < kXbTileVecs / kThreads; ++k)
     lds[k * kThreads + tid] = image[static_cast<size_t>(tile0) * kXbTileVecs + k * kThreads + tid];
   __syncthreads();
+#ifdef MI355_ICP_DIAG
+  const unsigned long long diag_t1 = wall_clock64();
+#endif
   uint32_t cur = 0;
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint4 bq[kSets];
@@ -824,6 +836,9 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
     __syncthreads();
     cur ^= 1;
   }
+#ifdef MI355_ICP_DIAG
+  const unsigned long long diag_t2 = wall_clock64();
+#endif
   // each wave half publishes its own key row: rows 2 sp (lanes 0-31) and 2 sp + 1 (lanes 32-63)
   const size_t out = static_cast<size_t>(2 * sp + (hi ? 1u : 0u)) * key_stride + J.out_off + sb * kScanSrcPerBlock + src_local;
 #pragma unroll
@@ -834,7 +849,39 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
     keys4[rank_stride + o] = (static_cast<unsigned long long>(__float_as_uint(w2)) << 32) | c2[m];
     keys4[2 * static_cast<size_t>(rank_stride) + o] = (static_cast<unsigned long long>(__float_as_uint(w3)) << 32) | c3[m];
   }
+#ifdef MI355_ICP_DIAG
+  if (g_diag_xb && threadIdx.x == 0) {
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    const size_t slot = (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 5;
+    g_diag_xb[slot + 0] = diag_t0;
+    g_diag_xb[slot + 1] = diag_t1;
+    g_diag_xb[slot + 2] = diag_t2;
+    g_diag_xb[slot + 3] = wall_clock64();
+    g_diag_xb[slot + 4] = (static_cast<unsigned long long>(tile1 - tile0) << 48) | (static_cast<unsigned long long>(blockIdx.y & 0xffu) << 40) |
+                           (static_cast<unsigned long long>(xcc & 0xf) << 32) | hwid;
+  }
+#endif
 }
+
+#ifdef MI355_ICP_DIAG
+extern "C" int mi355_icp_diag_xb_begin(size_t n_slots) {
+  unsigned long long* buf = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&buf), n_slots * 5 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (hipMemset(buf, 0, n_slots * 5 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_xb), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+extern "C" int mi355_icp_diag_xb_read(unsigned long long* out, size_t n_slots) {
+  unsigned long long* buf = nullptr;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(&buf, HIP_SYMBOL(g_diag_xb), sizeof(buf)) != hipSuccess || !buf) return 1;
+  if (hipMemcpy(out, buf, n_slots * 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  unsigned long long* none = nullptr;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag_xb), &none, sizeof(none));  // later launches stamp nothing
+  return hipFree(buf) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // a workgroup spans 512 source points either way (the planner's 2 points per lane); shape 0 = <4 sets, 256 threads> (default),
 // 1 = <2 sets, 512 threads> (1.4 % slower: profiles/r02b_scan_ab_lds_dma.txt)
