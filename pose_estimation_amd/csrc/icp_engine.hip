@@ -137,6 +137,7 @@ struct Plan {
   int xkind = 0;               // 0 VALU kernel, 1 f32 MFMA kernel, 2 both side by side, 3 split-bf16 MFMA kernel
   bool pruned = false;         // OPTIONAL exact pruned scan (MI355_ICP_SCAN_MODE=pruned), never chosen by the planner
   bool merged_keys = false;    // small all-exact launches (JobDesc::sub_split): one atomically merged key row, cleared per pass
+  bool classed = false;        // one-round matrix-core launches: class-weighted runs of tiles (JobDesc::first_class)
   bool sorted_src = false;     // the matrix-core scan and its resolve walk the SOURCE cloud in Morton order too (below)
   uint32_t key_rows() const { return (xkind == 3 ? 2u : 1u) * max_split; }  // key rows per rank (wave halves publish separately)
   uint32_t key_ranks() const { return xfilter && xkind != 3 ? 4u : 3u; }       // the VALU expansion kernels also publish U
@@ -275,6 +276,7 @@ struct mi355_icp_ctx {
   int xbf16_shape = 0;               // 0: <4 sets, 256 threads> workgroups, 1: <2 sets, 512 threads> (MI355_ICP_XBF16_SHAPE)
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
   int resolve_wave_points = 0;       // MI355_ICP_RESOLVE_WAVE_POINTS=16|32|64: points per wave of the filter's resolve (0: by launch size)
+  bool class_split = true;           // MI355_ICP_CLASS_SPLIT=0: one-round matrix-core launches with equal runs of tiles (A/B)
   bool plan_debug = false;           // MI355_ICP_PLAN_DEBUG=1: one line per plan on stderr
   double split_model_pairs = 5e10;    // ... below this many pairs per launch (MI355_ICP_SPLIT_MODEL_PAIRS: A/B)
   bool split_model = true;           // small matrix-core launches: pick the split that fills whole rounds of resident workgroups (MI355_ICP_SPLIT_MODEL=0: A/B)
@@ -668,6 +670,19 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
       }
     }
   }
+  // One-round matrix-core launches of a uniform batch (a request's candidates): between one and two workgroups per CU.  The
+  // first round's workgroups are served first by every SIMD's arbiter and walk a tile in less than half the time of the ones
+  // that join them; give them 13/6 of the tiles (MI355_ICP_CLASS_SPLIT=0: equal runs, A/B).
+  if (model_split && c->class_split && n_jobs <= 8) {
+    const JobDesc& J0 = plan.jobs[0];
+    bool uniform = J0.n_split >= 2 && J0.tgt_tiles >= 4 * J0.n_split;
+    for (const JobDesc& J : plan.jobs) uniform = uniform && J.scan_blocks == J0.scan_blocks && J.n_split == J0.n_split && J.tgt_tiles == J0.tgt_tiles;
+    const uint64_t wgs = static_cast<uint64_t>(J0.scan_blocks) * J0.n_split * static_cast<uint64_t>(n_jobs);
+    if (uniform && wgs > c->scan_slots / 2 && wgs <= c->scan_slots) {
+      plan.classed = true;
+      for (JobDesc& J : plan.jobs) J.first_class = c->scan_slots / 2;
+    }
+  }
   if (plan.pruned)  // the pruned kernel keeps a bitmap of needed tiles in LDS
     for (const JobDesc& J : plan.jobs)
       if (J.tgt_tiles > kPrunedMaxTiles) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "MI355_ICP_SCAN_MODE=pruned: a target cloud has more than 16M points");
@@ -903,8 +918,14 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
     const size_t st = xstride;
     const int ppl = plan.scan_ppl == 2 ? 2 : 4;  // the MFMA kernel spans 128 * {4, 8} points per workgroup
     if (bx && plan.xkind == 3) {
+      // one-round launches: the class-weighted layout (JobDesc::first_class) needs the self-staged kernel and every active
+      // job to hold the plan's tag (the planner sets it on uniform batches only)
+      bool classed = self_staged && plan.classed;
+      for (int k = 0; k < n_active && classed; ++k) classed = staged->jobs[k].first_class != 0;
+      if (self_staged && !classed)
+        for (int k = 0; k < n_active; ++k) const_cast<StageArgs*>(staged)->jobs[k].first_class = 0;
       launch_nn_scan_xbf16(c->stream, c->jobs_dev, n_active, bx, Sscan, X.bf, X.bf_table, c->keys3, plan.out_total, rank_stride, c->xbf16_shape,
-                           self_staged ? staged : nullptr, c->jobs_dev, staged && staged->has_ref ? c->rjobs_dev : nullptr);
+                           self_staged ? staged : nullptr, c->jobs_dev, staged && staged->has_ref ? c->rjobs_dev : nullptr, classed);
     } else if (bx && plan.xkind == 0) {
       launch_nn_scan_xfilter(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, xp, xp + st, xp + 2 * st, xp + 3 * st,
                              X.table, c->keys3, plan.out_total, rank_stride);
@@ -1507,6 +1528,7 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   if (const char* v = std::getenv("MI355_ICP_SPLIT_MODEL")) c->split_model = std::atoi(v) != 0;
   if (const char* v = std::getenv("MI355_ICP_SPLIT_MODEL_PAIRS")) c->split_model_pairs = std::atof(v);
   c->plan_debug = env_u32("MI355_ICP_PLAN_DEBUG", 0) != 0;
+  if (const char* v = std::getenv("MI355_ICP_CLASS_SPLIT")) c->class_split = std::atoi(v) != 0;
   {
     const uint32_t wp = env_u32("MI355_ICP_RESOLVE_WAVE_POINTS", 0);
     if (wp == 16 || wp == 32 || wp == 64) c->resolve_wave_points = static_cast<int>(wp);

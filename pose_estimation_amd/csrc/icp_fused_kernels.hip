@@ -611,7 +611,8 @@ __device__ __forceinline__ uint32_t min16(const f32x16& acc, uint32_t seed) {
 // descriptor from the kernel arguments and the first one writes the device tables for the launches behind it.
 #ifdef MI355_ICP_DIAG
 // Diagnostic build only (make diag): per-workgroup stamps of the matrix-core scan (100 MHz realtime counter):
-// [start, first tile in LDS, tiles walked, end, tiles << 48 | job << 40 | xcc << 32 | hw id] per workgroup (tools/xb_timeline.py)
+// [start, first tile in LDS, tiles walked, end, tiles << 48 | job << 40 | xcc << 32 | hw id, the walk's three quarter points]
+// per workgroup (tools/xb_timeline.py)
 __device__ unsigned long long* g_diag_xb = nullptr;
 #endif
 
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
   const unsigned long long diag_t0 = wall_clock64();
 #endif
   if constexpr (kStaged) {
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
       constexpr uint32_t kJ = sizeof(JobDesc) / 4, kR = sizeof(RefJobDesc) / 4;
       const uint32_t* src_w = reinterpret_cast<const uint32_t*>(staged.jobs);
       uint32_t* dst_w = reinterpret_cast<uint32_t*>(jobs_out);
@@ -649,12 +650,29 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
   }
   const JobDesc& J = kStaged ? staged.jobs[blockIdx.y] : jobs[blockIdx.y];
   const uint32_t n_split = J.n_split;
-  const uint32_t sb = blockIdx.x / n_split;
-  const uint32_t sp = blockIdx.x - sb * n_split;
-  if (sb >= J.scan_blocks) return;
+  // One-round launches (JobDesc::first_class, self-staged kernel only): the split is the SLOW grid index, so that the
+  // workgroups of the launch's first round - one per CU, the older wave on every SIMD, which the SIMD's arbiter serves first -
+  // are whole planes of the grid, and a source block's runs of tiles are sized by the class of the workgroup that walks them:
+  // both workgroups of a CU then finish together instead of the younger one walking its last third alone (tools/xb_timeline.py)
+  const bool classed = kStaged && J.first_class != 0;
+  const uint32_t sb = classed ? blockIdx.x : blockIdx.x / n_split;
+  const uint32_t sp = classed ? blockIdx.z : blockIdx.x - sb * n_split;
+  if (sb >= J.scan_blocks || sp >= n_split) return;
   constexpr uint32_t kScanSrcPerBlock = (kThreads / 64) * 32 * kSets;
-  const uint32_t tile0 = sp * J.split_q + (sp < J.split_r ? sp : J.split_r);
-  const uint32_t tile1 = tile0 + J.split_q + (sp < J.split_r ? 1u : 0u);
+  uint32_t tile0 = sp * J.split_q + (sp < J.split_r ? sp : J.split_r);
+  uint32_t tile1 = tile0 + J.split_q + (sp < J.split_r ? 1u : 0u);
+  if (classed) {
+    const uint32_t plane = gridDim.x * gridDim.y, at = blockIdx.y * gridDim.x + blockIdx.x;
+    uint32_t before = 0, mine = 0, total = 0;
+    for (uint32_t k = 0; k < n_split; ++k) {
+      const uint32_t w = k * plane + at < J.first_class ? kClassFast : kClassSlow;
+      before += k < sp ? w : 0u;
+      mine = k == sp ? w : mine;
+      total += w;
+    }
+    tile0 = J.tgt_tiles * before / total;  // the planner keeps tgt_tiles >= 4 n_split: every run holds a tile
+    tile1 = J.tgt_tiles * (before + mine) / total;
+  }
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const bool hi = lane >= 32;
   float pose[12];
@@ -702,7 +720,18 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
     const float x = l3v * 1.001f + (eev - adjv);
     return __float_as_uint(x + x * 9.5367431640625e-07f);
   };
+#ifdef MI355_ICP_DIAG
+  unsigned long long diag_q[3] = {0, 0, 0};  // the walk's quarter points
+#endif
   for (uint32_t tile = tile0; tile < tile1; ++tile) {
+#ifdef MI355_ICP_DIAG
+    {
+      const uint32_t done = tile - tile0, all = tile1 - tile0;
+      if (done == all / 4) diag_q[0] = wall_clock64();
+      if (done == all / 2) diag_q[1] = wall_clock64();
+      if (done == all - all / 4) diag_q[2] = wall_clock64();
+    }
+#endif
     const bool more = tile + 1 < tile1;
     // The operand image of kXbCentreGroup consecutive tiles shares one centre and one r^2 (xtarget_kernels.hip): the
     // source points are re-split into bf16 pieces at the first tile of the walk and whenever a new group begins
@@ -854,11 +883,14 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
     unsigned xcc, hwid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    const size_t slot = (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 5;
+    const size_t slot = ((static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;  // grid order
     g_diag_xb[slot + 0] = diag_t0;
     g_diag_xb[slot + 1] = diag_t1;
     g_diag_xb[slot + 2] = diag_t2;
     g_diag_xb[slot + 3] = wall_clock64();
+    g_diag_xb[slot + 5] = diag_q[0];
+    g_diag_xb[slot + 6] = diag_q[1];
+    g_diag_xb[slot + 7] = diag_q[2];
     g_diag_xb[slot + 4] = (static_cast<unsigned long long>(tile1 - tile0) << 48) | (static_cast<unsigned long long>(blockIdx.y & 0xffu) << 40) |
                            (static_cast<unsigned long long>(xcc & 0xf) << 32) | hwid;
   }
@@ -868,15 +900,15 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
 #ifdef MI355_ICP_DIAG
 extern "C" int mi355_icp_diag_xb_begin(size_t n_slots) {
   unsigned long long* buf = nullptr;
-  if (hipMalloc(reinterpret_cast<void**>(&buf), n_slots * 5 * sizeof(unsigned long long)) != hipSuccess) return 1;
-  if (hipMemset(buf, 0, n_slots * 5 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (hipMalloc(reinterpret_cast<void**>(&buf), n_slots * 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (hipMemset(buf, 0, n_slots * 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_xb), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
 }
 extern "C" int mi355_icp_diag_xb_read(unsigned long long* out, size_t n_slots) {
   unsigned long long* buf = nullptr;
   if (hipDeviceSynchronize() != hipSuccess) return 1;
   if (hipMemcpyFromSymbol(&buf, HIP_SYMBOL(g_diag_xb), sizeof(buf)) != hipSuccess || !buf) return 1;
-  if (hipMemcpy(out, buf, n_slots * 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  if (hipMemcpy(out, buf, n_slots * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 1;
   unsigned long long* none = nullptr;
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag_xb), &none, sizeof(none));  // later launches stamp nothing
   return hipFree(buf) == hipSuccess ? 0 : 1;
@@ -887,9 +919,11 @@ extern "C" int mi355_icp_diag_xb_read(unsigned long long* out, size_t n_slots) {
 // 1 = <2 sets, 512 threads> (1.4 % slower: profiles/r02b_scan_ab_lds_dma.txt)
 void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
                           const void* bf_image, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
-                          uint32_t rank_stride, int shape, const StageArgs* staged, JobDesc* jobs_out, RefJobDesc* rjobs_out) {
+                          uint32_t rank_stride, int shape, const StageArgs* staged, JobDesc* jobs_out, RefJobDesc* rjobs_out, bool classed) {
   if (!max_blocks_x) return;
   dim3 grid(max_blocks_x, static_cast<uint32_t>(n_jobs));
+  if (staged && shape != 1 && classed)  // JobDesc::first_class: (source blocks, jobs, splits) - the same for every job of the launch
+    grid = dim3(staged->jobs[0].scan_blocks, static_cast<uint32_t>(n_jobs), staged->jobs[0].n_split);
   if (staged && shape != 1) {  // small passes: this launch stages the descriptors itself
     hipLaunchKernelGGL((nn_scan_xbf16_kernel<4, 256, false, true>), grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x,
                        src.y, src.z, static_cast<const uint4*>(bf_image), static_cast<const float4*>(tile_table), keys4, key_stride,

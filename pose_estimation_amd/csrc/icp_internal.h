@@ -111,8 +111,11 @@ struct JobDesc {
                              // targets x 512 source slots: tens of microseconds on one CU whatever the cloud holds, which is
                              // what a pass costs on the coarse pyramid levels of reference mode unless it is cut finer.
   uint32_t src_n_total;      // slab-sharded reference mode: points of the WHOLE level cloud over all ranks (0 = src_n)
-  uint32_t pad_;
+  uint32_t first_class;      // matrix-core scan of a ONE-ROUND launch (self-staged kernel only; 0 = off): the launch's grid is
+                             // (scan_blocks, jobs, n_split) and the first `first_class` workgroups in grid order - one per CU,
+                             // the older wave on every SIMD - get kClassFast / kClassSlow times the tiles of the later ones
 };
+constexpr uint32_t kClassFast = 13, kClassSlow = 6;  // tools/xb_timeline.py, round 3: 4.6 vs ~10 us per tile while both are resident
 static_assert(sizeof(JobDesc) == 112, "JobDesc layout");
 
 // ---- reference mode (point-to-plane / rejection / picky / pyramid): icp_ref_kernels.hip ----
@@ -370,7 +373,7 @@ void launch_nn_scan_xmfma(void* stream, int points_per_lane, const JobDesc* jobs
 void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
                           const void* bf_image, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
                           uint32_t rank_stride, int shape, const StageArgs* staged = nullptr, JobDesc* jobs_out = nullptr,
-                          RefJobDesc* rjobs_out = nullptr);
+                          RefJobDesc* rjobs_out = nullptr, bool classed = false);
 void launch_nn_scan_xbf16_dump(void* stream, const JobDesc* jobs_dev, uint32_t blocks_x, DevicePlanes src, const void* bf_image,
                                const void* tile_table, unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride,
                                float* dump, uint32_t dump_stride);

@@ -39,13 +39,15 @@ with pa.IcpEngine(0) as eng:
         eng.align_reference(inits, 250, 0.005, 2.5, a.levels)
     assert lib.mi355_icp_diag_xb_begin(NS) == 0
     eng.align_reference(inits, 250, 0.005, 2.5, a.levels)
-    buf = np.zeros((NS, 5), dtype=np.uint64)
+    buf = np.zeros((NS, 8), dtype=np.uint64)
     assert lib.mi355_icp_diag_xb_read(buf.ctypes.data, NS) == 0
-b = buf[buf[:, 3] != 0]
+used = buf[:, 3] != 0
 # slots keep the last launch that wrote them; a coarser level's launch has fewer workgroups, so the finest level's launch is
 # the set of slots with the latest stamps: keep the workgroups that started within 1 ms of the latest start
-t0 = b[:, 0].astype(np.int64)
-b = b[t0 > t0.max() - 100_000]
+t0_all = buf[:, 0].astype(np.int64)
+keep = used & (t0_all > t0_all[used].max() - 100_000)
+linear = np.nonzero(keep)[0]  # slot = blockIdx.y * gridDim.x + blockIdx.x: the order the dispatcher is expected to follow
+b = buf[keep]
 t0, t1, t2, t3 = (b[:, k].astype(np.int64) for k in range(4))
 base = t0.min()
 us = lambda t: (t - base) / 100.0
@@ -69,6 +71,20 @@ print(f"distinct CUs {len(per_cu)}; workgroups per CU min/mean/max {per_cu.min()
 for k in sorted(np.unique(per_cu)):
     sel = np.isin(cu_key, np.unique(cu_key)[per_cu == k])
     print(f"  workgroups on CUs holding {k}: per-tile walk median {np.median((walk / np.maximum(tiles, 1))[sel]):.2f} us, end median {np.median(us(t3)[sel]):.1f} max {us(t3)[sel].max():.1f}")
+first = linear < 256
+if first.any() and (~first).any():
+    print(f"workgroups 0-255 in grid order: {len(np.unique(cu_key[first]))} distinct CUs, start median {np.median(us(t0)[first]):.1f} us, per-tile walk median "
+          f"{np.median((walk / np.maximum(tiles, 1))[first]):.2f} us, end median {np.median(us(t3)[first]):.1f}; the others: start median {np.median(us(t0)[~first]):.1f}, "
+          f"per tile {np.median((walk / np.maximum(tiles, 1))[~first]):.2f}, end median {np.median(us(t3)[~first]):.1f}")
+q1, q2, q3 = (us(b[:, k].astype(np.int64)) for k in (5, 6, 7))
+quarters = np.stack([q1 - us(t1), q2 - q1, q3 - q2, us(t2) - q3], axis=1) / np.maximum(tiles[:, None] / 4.0, 1)
+for name, sel in (("first 256 in grid order", first), ("the others", ~first)):
+    if sel.any():
+        print(f"  {name}: per-tile walk by quarter of the walk, median us: " + " ".join(f"{np.median(quarters[sel, k]):.2f}" for k in range(4)))
+for jb in sorted(np.unique(job)):
+    for name, sel in (("first 256", first & (job == jb)), ("later", ~first & (job == jb))):
+        if sel.any():
+            print(f"  job {jb} {name:9s}: {int(sel.sum()):3d} workgroups, per-tile walk median {np.median((walk / np.maximum(tiles, 1))[sel]):.2f} us")
 T_end = us(t3).max()
 grid = np.linspace(0, T_end, 21)
 res = [(int(((us(t0) <= g) & (us(t3) > g)).sum())) for g in grid]
