@@ -79,6 +79,41 @@ def test_align_reference_matches_oracle_with_the_reference_parameters(engine):
     assert np.array_equal(p.pose, res.poses[0]) and p.residual == res.residual[0]
 
 
+def test_reference_request_shape_is_independent_of_the_launch_layout(engine):
+    """The reference's own request shape - 6 candidates of one 20k-point model against a 100k-point scene - is the uniform batch
+    whose matrix-core launches are one round of workgroups and get class-weighted runs of tiles (JobDesc::first_class).  Every
+    candidate against the oracle, and the whole result bit for bit against an engine with equal runs (MI355_ICP_CLASS_SPLIT=0)
+    and against one whose chip 'has' 48 resident workgroups (other cuts, other class boundary)."""
+    import pose_estimation_amd as pa
+    T = st.perturbation(-1)
+    tgt = st.synth_cloud_np(st.TARGET_SEED, 100_000, normals=True)
+    src = st.synth_cloud_np(st.SOURCE_SEED, 20_000, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T)
+    gt = np.linalg.inv(T)
+    inits = np.stack([np.eye(4)] + [st.rigid_transform(k, (0.2, 1, -0.4), (0.01, -0.02, 0.015)) @ gt for k in (1.0, 2.0, 3.0, 4.0, 5.0)])
+    engine.set_targets([tgt])
+    engine.set_sources([src])
+    res = engine.align_reference(inits, 250, 0.005, 2.5, 8)
+    for k in (0, 3, 5):
+        o = ora.icp_reference(src, tgt, inits[k], 250, 0.005, 2.5, 8, nthreads=ora.max_threads())
+        assert res.status[k] == 0 and res.passes[k] == o["passes"]
+        assert np.linalg.norm(res.poses[k] - o["pose"]) <= POSE_TOL and abs(res.residual[k] - o["residual"]) <= 1e-9
+    for env in ({"MI355_ICP_CLASS_SPLIT": "0"}, {"MI355_ICP_SCAN_SLOTS": "48"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            with pa.IcpEngine(0) as other:
+                other.set_targets([tgt])
+                other.set_sources([src])
+                res2 = other.align_reference(inits, 250, 0.005, 2.5, 8)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        assert np.array_equal(res2.poses, res.poses) and np.array_equal(res2.residual, res.residual) and np.array_equal(res2.passes, res.passes)
+
+
 def test_batched_candidates_and_mixed_objects(engine):
     pairs = [pair6(6000 + 500 * k, 5000 + 300 * k, k) for k in range(3)]
     engine.set_targets([p[1] for p in pairs])
