@@ -10,13 +10,21 @@ import sys
 tag = sys.argv[1]
 src = os.path.join("gpurun_out", f"prof_{tag}")
 os.makedirs("profiles", exist_ok=True)
-for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+
+
+def newest(pattern):
+    """gpurun merges every run's files into the same tree: a tag profiled twice leaves two files per pass - take the last run's."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
+for f in newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
     shutil.copy(f, os.path.join("profiles", f"{tag}_kernel_stats.csv"))
 lines = [f"rocprofv3 PMC summary, tag {tag}: per-kernel mean of each counter over its dispatches",
          "(separate --pmc passes; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them; on gfx950 FETCH_SIZE counts",
          " half of a wide coalesced read: double it before comparing with bytes - MI355X_MICROARCH.md HBM section)", ""]
 for name in ("pmc_sq", "pmc_sq2", "pmc_lds", "pmc_fetch", "pmc_write"):
-    for f in glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(src, name, "*", "*_counter_collection.csv")):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"].split("(")[0][-48:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -32,7 +40,7 @@ open(os.path.join("profiles", f"{tag}_pmc_summary.txt"), "w").write("\n".join(li
 import json
 fetch = write = None
 for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    for f in glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(src, name, "*", "*_counter_collection.csv")):
         rows = list(csv.DictReader(open(f)))
         dominant = "nn_scan_xbf16" if any("nn_scan_xbf16" in r["Kernel_Name"] for r in rows) else "nn_scan"
         vals = [float(r["Counter_Value"]) for r in rows if dominant in r["Kernel_Name"] and r["Counter_Name"] == key]
