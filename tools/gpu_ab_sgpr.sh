@@ -1,4 +1,5 @@
 #!/bin/bash
+# Round-1 A/B of the all-exact scan: scalar-load (s_load) target reads against LDS tiles, by register blocking and size (tools/scan_ab.py).
 set -u
 mkdir -p gpurun_out
 {

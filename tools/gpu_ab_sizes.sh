@@ -1,4 +1,5 @@
 #!/bin/bash
+# Round-1 A/B of the all-exact scan: register blocking (2/4/8 points per lane) and workgroup-count goal by launch size (tools/scan_ab.py).
 set -u
 mkdir -p gpurun_out
 {
