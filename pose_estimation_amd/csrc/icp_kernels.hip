@@ -890,14 +890,17 @@ __global__ __launch_bounds__(kTile) void overflow_exact_kernel(
 // (d2, original index)-lexicographic minimum over the reachable tiles is the all-exact answer.  Typically 2-10 of the
 // 1024 tiles of a 10^6-point scene: the pass costs microseconds at any target size, so the overflow points never need
 // the host (round 1 went through a host round trip + gathered all-exact scan above 262k targets).
-__global__ __launch_bounds__(kBlockThreads) void overflow_tiles_kernel(
+// 1024 threads: one target of a tile per thread.  (With 256 threads a wave was alone on its SIMD and walked four targets per
+// tile through ~100 dependent instructions each round: ~1 us per reachable tile whatever was in flight - phase stamps, round 3.)
+constexpr int kOverflowThreads = kTile;
+__global__ __launch_bounds__(kOverflowThreads) void overflow_tiles_kernel(
     const JobDesc* __restrict__ jobs, const float* __restrict__ sx, const float* __restrict__ sy,
     const float* __restrict__ sz, const float* __restrict__ sox, const float* __restrict__ soy,
     const float* __restrict__ soz, const uint32_t* __restrict__ tperm, const float4* __restrict__ ttable,
     const uint32_t* __restrict__ overflow_list, const uint32_t* __restrict__ overflow_count,
     int32_t* __restrict__ out_index, float* __restrict__ out_dist2, uint32_t* __restrict__ error_flag) {
-  __shared__ unsigned long long smask[kBlockThreads / 64];
-  __shared__ uint32_t sd[kBlockThreads / 64], sj[kBlockThreads / 64];
+  __shared__ unsigned long long smask[kOverflowThreads / 64];
+  __shared__ uint32_t sd[kOverflowThreads / 64], sj[kOverflowThreads / 64];
   P2P_DIAG_BEGIN(blockIdx.x == 0 && threadIdx.x == 0);
   const JobDesc& J = jobs[blockIdx.y];
   const uint32_t n_listed = overflow_count[blockIdx.y];
@@ -923,38 +926,29 @@ __global__ __launch_bounds__(kBlockThreads) void overflow_tiles_kernel(
 #ifdef MI355_ICP_DIAG
   unsigned long long diag_tiles = 0;
 #endif
-  for (uint32_t t0 = 0; t0 < n_tiles; t0 += kBlockThreads) {
+  for (uint32_t t0 = 0; t0 < n_tiles; t0 += kOverflowThreads) {
     const uint32_t t = t0 + tid;
     const bool reach = t < n_tiles && sphere_reachable(qx, qy, qz, 0.0f, ttable[tile_base + t], d0);
     const unsigned long long m = __builtin_amdgcn_ballot_w64(reach);
     if ((tid & 63u) == 0) smask[tid >> 6] = m;
     __syncthreads();
     P2P_DIAG_STAMP();  // tile table tested
-    for (uint32_t w = 0; w < kBlockThreads / 64; ++w) {
+    for (uint32_t w = 0; w < kOverflowThreads / 64; ++w) {
       unsigned long long todo = smask[w];
 #ifdef MI355_ICP_DIAG
       diag_tiles += __builtin_popcountll(todo);
 #endif
-      // (Four tiles' loads in flight at once changed nothing: 6-8 reachable tiles cost ~1 us each either way - phase stamps,
-      // round 3; the tiles are 4 KB apart in four arrays, and what a tile waits for is not one round trip per load.)
+      // (several tiles' loads in flight at once change nothing here either: 4.5 -> 4.1 us for ten tiles)
       while (todo) {
         const uint32_t tile = t0 + w * 64 + static_cast<uint32_t>(__builtin_ctzll(todo));
         todo &= todo - 1;
-        float d[kTile / kBlockThreads];
-        uint32_t pj[kTile / kBlockThreads];
-#pragma unroll
-        for (int k = 0; k < kTile / kBlockThreads; ++k) {
-          const uint32_t p = J.tgt_off + tile * kTile + k * kBlockThreads + tid;
-          d[k] = dist2(qx, qy, qz, sox[p], soy[p], soz[p]);
-          pj[k] = tperm[p];
-        }
-#pragma unroll
-        for (int k = 0; k < kTile / kBlockThreads; ++k) {
-          const bool real = tile * kTile + k * kBlockThreads + tid < J.tgt_n;  // padding slots sit at 3e38 with index 0
-          if (real && (d[k] < best || (d[k] == best && pj[k] < best_j))) {
-            best = d[k];
-            best_j = pj[k];
-          }
+        const uint32_t p = J.tgt_off + tile * kTile + tid;
+        const float d = dist2(qx, qy, qz, sox[p], soy[p], soz[p]);
+        const uint32_t pj = tperm[p];
+        const bool real = tile * kTile + tid < J.tgt_n;  // padding slots sit at 3e38 with index 0
+        if (real && (d < best || (d == best && pj < best_j))) {
+          best = d;
+          best_j = pj;
         }
       }
     }
@@ -968,20 +962,20 @@ __global__ __launch_bounds__(kBlockThreads) void overflow_tiles_kernel(
     sj[tid >> 6] = wj;
   }
   __syncthreads();
-  if (tid == 0) {
-    uint32_t d = sd[0], j = sj[0];
-    for (int w = 1; w < kBlockThreads / 64; ++w)
-      if (sd[w] < d || (sd[w] == d && sj[w] < j)) {
-        d = sd[w];
-        j = sj[w];
+  if (tid < 64) {  // the sixteen waves' results, one per lane: the same two wave minima once more
+    const bool has = tid < kOverflowThreads / 64;
+    const uint32_t md = has ? sd[tid] : 0xFFFFFFFFu, mj = has ? sj[tid] : 0xFFFFFFFFu;
+    uint32_t d = wave_min_u32(md);
+    uint32_t j = wave_min_u32(md == d ? mj : 0xFFFFFFFFu);
+    if (tid == 0) {
+      if (j == 0xFFFFFFFFu || j >= J.tgt_n) {  // nothing but NaN / +inf distances: the oracle's report for "nothing below +inf"
+        atomicOr(error_flag, 1u);
+        j = 0;
+        d = 0x7F800000u;
       }
-    if (j == 0xFFFFFFFFu || j >= J.tgt_n) {  // nothing but NaN / +inf distances: the oracle's report for "nothing below +inf"
-      atomicOr(error_flag, 1u);
-      j = 0;
-      d = 0x7F800000u;
+      out_index[J.out_off + local] = static_cast<int32_t>(j);
+      out_dist2[J.out_off + local] = __uint_as_float(d);
     }
-    out_index[J.out_off + local] = static_cast<int32_t>(j);
-    out_dist2[J.out_off + local] = __uint_as_float(d);
   }
   __syncthreads();  // sd / sj are rewritten by the next listed point
   if (slot == blockIdx.x) P2P_DIAG_END(6ull | (static_cast<unsigned long long>(n_listed) << 8) | (diag_tiles << 40) | (static_cast<unsigned long long>(n_tiles) << 48));
@@ -1470,7 +1464,7 @@ void launch_overflow_tiles(void* stream, const JobDesc* jobs_dev, int n_jobs, ui
                            int32_t* out_index, float* out_dist2, uint32_t* error_flag) {
   // `cap` listed points per job are settled on the device (more: the host path); the job's workgroups stride over its list
   const uint32_t per_job = std::min<uint32_t>(cap, std::max<uint32_t>(16u, std::min<uint32_t>(256u, 2048u / static_cast<uint32_t>(std::max(n_jobs, 1)))));
-  hipLaunchKernelGGL(overflow_tiles_kernel, dim3(per_job, static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(overflow_tiles_kernel, dim3(per_job, static_cast<uint32_t>(n_jobs)), dim3(kOverflowThreads), 0, static_cast<hipStream_t>(stream),
                      jobs_dev, src.x, src.y, src.z, sorted_tgt.x, sorted_tgt.y, sorted_tgt.z, tgt_perm, static_cast<const float4*>(tgt_table),
                      overflow_list, overflow_count, out_index, out_dist2, error_flag);
 }
