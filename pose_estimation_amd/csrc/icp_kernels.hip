@@ -365,9 +365,13 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
 
   P2P_DIAG_BEGIN(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0);
   const JobDesc& J = jobs[blockIdx.y];
-  const uint32_t sb = kSums ? blockIdx.x : blockIdx.x / kResolvePointsPerLane;
+  // kSums = false: a workgroup may be a single wave (blockDim.x = 64: the 256 points of a quarter block spread over four
+  // workgroups, i.e. over four CUs' load units - the chunk re-scan is bound by the issue of its scattered loads)
+  const uint32_t sub = kSums ? 1u : kBlockThreads / blockDim.x;
+  const uint32_t sb = kSums ? blockIdx.x : blockIdx.x / (kResolvePointsPerLane * sub);
   if (sb >= J.src_blocks) return;
   const uint32_t tid = threadIdx.x;
+  const uint32_t slot = kSums ? tid : (blockIdx.x % sub) * blockDim.x + tid;  // position inside the 256-point quarter block
   float pose[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
 #pragma unroll
   for (int k = 0; k < MI355_ICP_NSUMS; ++k) acc[k] = 0.0;
 
-  const int p_first = kSums ? 0 : static_cast<int>(blockIdx.x % kResolvePointsPerLane);
+  const int p_first = kSums ? 0 : static_cast<int>((blockIdx.x / sub) % kResolvePointsPerLane);
   constexpr int kPts = kSums ? kResolvePointsPerLane : 1;
   // A point is a chain of dependent reads: its key (one per split) -> the chunk the key names.  The keys and the source
   // coordinates of ALL the lane's points are read first, side by side - only the chunk reads are left to follow one another -
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
   float s0x_of[kPts], s0y_of[kPts], s0z_of[kPts];
 #pragma unroll
   for (int u = 0; u < kPts; ++u) {
-    const uint32_t local = sb * kSrcPerBlock + (p_first + u) * kBlockThreads + tid;
+    const uint32_t local = sb * kSrcPerBlock + (p_first + u) * kBlockThreads + slot;
     const bool there = local < J.src_n;
     unsigned long long key = ~0ull;
     for (uint32_t sp = 0; sp < n_split; ++sp) {
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
 #pragma unroll
   for (int u = 0; u < kPts; ++u) {
     const int p = p_first + u;
-    const uint32_t local = sb * kSrcPerBlock + p * kBlockThreads + tid;
+    const uint32_t local = sb * kSrcPerBlock + p * kBlockThreads + slot;
     // the scan's padding lanes merge keys as well: the whole span of this workgroup goes back cleared (a job's slots are
     // padded to kSrcPad, a multiple of this kernel's span and of the scan's)
     if (!kSums && J.sub_split > 1 && local >= J.src_n) keys[J.out_off + local] = ~0ull;
@@ -1382,8 +1386,10 @@ void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t 
                        jobs_dev, src.x, src.y, src.z, tgt.x, tgt.y, tgt.z, keys, key_stride, out_index, out_dist2,
                        partials, error_flag, tail);
   } else {
-    dim3 grid(max_src_blocks * kResolvePointsPerLane, static_cast<uint32_t>(n_jobs));
-    hipLaunchKernelGGL(resolve_accumulate_kernel<false>, grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
+    // one wave per workgroup: small launches (the coarse pyramid levels) spread over four times the CUs
+    constexpr uint32_t kThreads = 64;
+    dim3 grid(max_src_blocks * kResolvePointsPerLane * (kBlockThreads / kThreads), static_cast<uint32_t>(n_jobs));
+    hipLaunchKernelGGL(resolve_accumulate_kernel<false>, grid, dim3(kThreads), 0, static_cast<hipStream_t>(stream),
                        jobs_dev, src.x, src.y, src.z, tgt.x, tgt.y, tgt.z, keys, key_stride, out_index, out_dist2,
                        partials, error_flag, PassTail{});
   }
