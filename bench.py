@@ -39,7 +39,7 @@ SCAN_MODELS = {
               "Every pair is evaluated by one K=16 bf16 MFMA contraction (32 flop per pair: the expansion surrogate of "
               "points quantised to two bfloat16 pieces per coordinate) and one vector issue slot per 128 pairs per lane for "
               "the minimum (8 v_min3_u32 + the MFMA issue per 1024 pairs: the binding resource, see roofline_issue; a "
-              "register-only loop of that mix takes 44.8 cycles per MFMA, the kernel 49.1 - and issues no MFMA whose result is dropped: "
+              "register-only loop of that mix takes 44.8 cycles per MFMA, the kernel 49.5 - and issues no MFMA whose result is dropped: "
               "profiles/r03s_pmc_summary.txt; round 2: 49.7 per issued, 51.3 per useful MFMA); "
               "the exact unfused float32 formula then decides inside the one or two candidate granules, so indices and "
               "distances stay bit-identical to the oracle, and the filter's lower bound is itself a tested invariant "
