@@ -561,14 +561,20 @@ __global__ __launch_bounds__(kBlockThreads) void picky_scatter_kernel(const JobD
   const float t = thr[blockIdx.y];
   const RefJobDesc& RJ = rjobs[blockIdx.y];
   const uint32_t owner_off = RJ.owner_off;
+  // distances and indices of the lane's four points go out together (one round trip, not two per point one after the other)
+  float d[kResolvePointsPerLane];
+  uint32_t j[kResolvePointsPerLane];
 #pragma unroll
   for (int p = 0; p < kResolvePointsPerLane; ++p) {
     const uint32_t local = blockIdx.x * kSrcPerBlock + p * kBlockThreads + threadIdx.x;
-    if (local < J.src_n) {
-      const float d = dist2[J.out_off + local];
-      if (d < t)
-        atomicMin(&owner[owner_off + static_cast<uint32_t>(index[J.out_off + local])], picky_key(RJ.owner_prefix, d, RJ.src_index_base + local));
-    }
+    const uint32_t at = J.out_off + (local < J.src_n ? local : 0u);
+    d[p] = dist2[at];
+    j[p] = static_cast<uint32_t>(index[at]);
+  }
+#pragma unroll
+  for (int p = 0; p < kResolvePointsPerLane; ++p) {
+    const uint32_t local = blockIdx.x * kSrcPerBlock + p * kBlockThreads + threadIdx.x;
+    if (local < J.src_n && d[p] < t) atomicMin(&owner[owner_off + j[p]], picky_key(RJ.owner_prefix, d[p], RJ.src_index_base + local));
   }
 }
 
