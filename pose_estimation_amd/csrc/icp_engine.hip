@@ -276,6 +276,7 @@ struct mi355_icp_ctx {
   int xbf16_shape = 0;               // 0: <4 sets, 256 threads> workgroups, 1: <2 sets, 512 threads> (MI355_ICP_XBF16_SHAPE)
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
   int resolve_wave_points = 0;       // MI355_ICP_RESOLVE_WAVE_POINTS=16|32|64: points per wave of the filter's resolve (0: by launch size)
+  double filter_pairs = 2.5e8;        // launches from this many pairs on take the filter scan (MI355_ICP_FILTER_PAIRS: A/B)
   bool class_split = true;           // MI355_ICP_CLASS_SPLIT=0: one-round matrix-core launches with equal runs of tiles (A/B)
   bool plan_debug = false;           // MI355_ICP_PLAN_DEBUG=1: one line per plan on stderr
   double split_model_pairs = 5e10;    // ... below this many pairs per launch (MI355_ICP_SPLIT_MODEL_PAIRS: A/B)
@@ -550,7 +551,7 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   // scan dominates the pass; tiny launches keep the all-exact scan, which needs no sorted copy of the targets and no
   // overflow-count round trip to the host.  Threshold from profiles/r01o_planner_threshold.txt: with the matrix-core
   // filter the pass is already 23 % shorter at 16k<->16k (2.7e8 pairs), 42 % at 32k<->32k.
-  constexpr double kFilterPairs = 2.5e8;
+  const double kFilterPairs = c->filter_pairs;
   plan.fused = c->scan_fused < 0 ? total_pairs >= kFilterPairs : c->scan_fused >= 1;
   // The expansion filters need a sorted, tile-centred copy of the targets, built on the device once per upload
   // (~0.2 ms per 100k points): worth it as soon as the filter itself is.
@@ -1529,6 +1530,7 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   if (const char* v = std::getenv("MI355_ICP_SPLIT_MODEL_PAIRS")) c->split_model_pairs = std::atof(v);
   c->plan_debug = env_u32("MI355_ICP_PLAN_DEBUG", 0) != 0;
   if (const char* v = std::getenv("MI355_ICP_CLASS_SPLIT")) c->class_split = std::atoi(v) != 0;
+  if (const char* v = std::getenv("MI355_ICP_FILTER_PAIRS")) c->filter_pairs = std::atof(v);
   {
     const uint32_t wp = env_u32("MI355_ICP_RESOLVE_WAVE_POINTS", 0);
     if (wp == 16 || wp == 32 || wp == 64) c->resolve_wave_points = static_cast<int>(wp);
