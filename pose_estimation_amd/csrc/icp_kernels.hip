@@ -367,11 +367,14 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
   const JobDesc& J = jobs[blockIdx.y];
   // kSums = false: a workgroup may be a single wave (blockDim.x = 64: the 256 points of a quarter block spread over four
   // workgroups, i.e. over four CUs' load units - the chunk re-scan is bound by the issue of its scattered loads)
-  const uint32_t sub = kSums ? 1u : kBlockThreads / blockDim.x;
-  const uint32_t sb = kSums ? blockIdx.x : blockIdx.x / (kResolvePointsPerLane * sub);
+  // (shifts and masks: a division by a run-time block size expands into a float reciprocal, which the ISA check of this file
+  // would rightly refuse to tell from fused point arithmetic)
+  static_assert(kResolvePointsPerLane == 4 && kBlockThreads == 256, "the shifts below");
+  const uint32_t sub_log2 = (!kSums && blockDim.x == 64u) ? 2u : 0u;  // workgroups per 256-point quarter block: 4 or 1
+  const uint32_t sb = kSums ? blockIdx.x : blockIdx.x >> (2u + sub_log2);
   if (sb >= J.src_blocks) return;
   const uint32_t tid = threadIdx.x;
-  const uint32_t slot = kSums ? tid : (blockIdx.x % sub) * blockDim.x + tid;  // position inside the 256-point quarter block
+  const uint32_t slot = kSums ? tid : (blockIdx.x & ((1u << sub_log2) - 1u)) * blockDim.x + tid;  // position inside the 256-point quarter block
   float pose[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) pose[k] = J.pose[k];
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(kBlockThreads) void resolve_accumulate_kernel(
 #pragma unroll
   for (int k = 0; k < MI355_ICP_NSUMS; ++k) acc[k] = 0.0;
 
-  const int p_first = kSums ? 0 : static_cast<int>((blockIdx.x / sub) % kResolvePointsPerLane);
+  const int p_first = kSums ? 0 : static_cast<int>((blockIdx.x >> sub_log2) & 3u);
   constexpr int kPts = kSums ? kResolvePointsPerLane : 1;
   // A point is a chain of dependent reads: its key (one per split) -> the chunk the key names.  The keys and the source
   // coordinates of ALL the lane's points are read first, side by side - only the chunk reads are left to follow one another -
