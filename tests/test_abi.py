@@ -48,6 +48,18 @@ def test_library_has_gfx950_code_object_and_no_oracle_dependency():
     assert b"gfx950" in blob and b"nn_scan_kernel" in blob
 
 
+def test_kernels_hold_no_fused_float32_arithmetic():
+    """The Makefile's ISA check over the files whose float32 arithmetic is the parity contract (scan, resolve, reference-mode
+    kernels): no fma/mad/mac on float32 in the gfx950 assembly - a contracted multiply-add would change distance bits, and so
+    would anything the compiler expands into one (a division by a run-time integer did, in round 3, and broke the build)."""
+    csrc = os.path.join(ROOT, "pose_estimation_amd", "csrc")
+    asm = os.path.join(ROOT, "build", "csrc", "icp_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
+    if not os.path.exists(asm):
+        pytest.skip("the library was not built in this tree (build/csrc has no assembly): __graft_entry__.build() runs the check")
+    out = subprocess.run(["make", "-C", csrc, "check-isa"], capture_output=True, text=True)
+    assert out.returncode == 0 and "no fused f32 ops" in out.stdout, out.stdout + out.stderr
+
+
 def test_product_sources_never_touch_the_oracle():
     pkg = os.path.join(ROOT, "pose_estimation_amd")
     for dp, _, files in os.walk(pkg):
