@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kBlockThreads) void nn_scan_sgpr_kernel(const JobDe
 // N1 (index recovery) + N2 (accumulation).  grid = (max_j src_blocks_j, n_jobs), block = 256.
 // Same (block, lane, p) -> source point mapping as the scan.
 // kSums = false (reference mode: its sums are the point-to-plane ones of ref_accumulate_kernel) recovers the indices only,
-// on a grid of (kResolvePointsPerLane * max_j src_blocks_j, n_jobs) with ONE point per lane - the passes of the coarse
+// on a grid of (4 * kResolvePointsPerLane * max_j src_blocks_j, n_jobs) of ONE-WAVE workgroups with ONE point per lane - the passes of the coarse
 // pyramid levels are a chain of latency-bound launches, and four dependent points per lane is four times the latency -
 // and, where the scan merged its workgroups into one key row (sub_split), hands the row back cleared for the next pass.
 template <bool kSums>
