@@ -81,6 +81,11 @@ typedef struct mi355_icp_params {
                                         tile and run).  Off by default: the reference path this engine replaces is
                                         specified - and benchmarked - as brute force.  Worth it from ~100k points. */
 
+#define MI355_ICP_FLAG_UPSTREAM 4    /* mi355_icp_align_reference only: follow upstream cv::ppf_match_3d::ICP where the round 1-3
+                                        form of reference mode left its control flow (see mi355_icp_reference_params).
+                                        The host mirrors (mi355::cv_adapter::ICP, mi355::ppf_match_3d::ICP, Python ICP) set
+                                        it by default; needs the MODEL uploaded with normals too (N x 6 rows). */
+
 /* Kernel timing collected when MI355_ICP_FLAG_PROFILE is set; cumulative since
  * the last mi355_icp_reset_profile(). */
 typedef struct mi355_icp_profile {
@@ -160,6 +165,14 @@ int mi355_icp_slab_range(size_t n, int rank, int n_ranks, size_t* begin, size_t*
  * the level index of the first, and the size of the whole level.  Any output may be NULL.  [host] */
 int mi355_icp_level_slab(size_t n_total, size_t begin, size_t count, int level, size_t* first_local, size_t* n_level_local,
                          size_t* level_index_base, size_t* n_level_total);
+/* The same for a level that keeps every step-th point (global indices 0, step, 2 step, ..., n_total / step of them):
+ * the upstream-faithful variant samples with upstream's step, which is 2^level only for large models.  [host] */
+int mi355_icp_level_slab_step(size_t n_total, size_t begin, size_t count, size_t step, size_t* first_local,
+                              size_t* n_level_local, size_t* level_index_base, size_t* n_level_total);
+/* Upstream's sampling step of pyramid level `level` for a model of n_model rows: numSamples = cvRound(n / 2^level),
+ * sampleStep = cvRound(n / numSamples), round half to even (recalled from upstream; unverifiable offline).  Returns 0 when
+ * the level has no samples.  [host] */
+unsigned mi355_icp_upstream_step(size_t n_model, int level);
 
 /* ---- alignment ----------------------------------------------------------- */
 
@@ -233,12 +246,22 @@ typedef struct mi355_icp_reference_params {
   int32_t flags;           /* MI355_ICP_FLAG_* */
 } mi355_icp_reference_params;
 
-#define MI355_ICP_NREFSUMS 29 /* 21 upper-triangle A^T A (row-major), 6 A^T b, sum |p-q|^2, number of pairs */
+#define MI355_ICP_NREFSUMS 29    /* 21 upper-triangle A^T A (row-major), 6 A^T b, sum |p-q|^2, number of pairs */
+#define MI355_ICP_NREFSUMS_EX 30 /* those, then sum |n_p - n_q|^2 over the selected pairs (MI355_ICP_FLAG_UPSTREAM; else 0) */
 
-/* Batched like mi355_icp_align.  out_residual[k] is the smallest fval = sqrt(sum |p-q|^2)/n_level of the
- * finest level that ran (cloud units; upstream reports it in its pre-normalised units), out_passes[k] the
- * number of correspondence passes over all levels.  A job whose level ends early (< 6 pairs, degenerate
- * solve) keeps what it has, as upstream does.
+/* Batched like mi355_icp_align.  out_passes[k] is the number of correspondence passes over all levels.  A job whose
+ * level ends early (< 6 pairs, degenerate solve) keeps what it has, as upstream does.
+ *
+ * Two forms (numeric definition of both: oracle/icp_oracle.c, second half; the differences: INTEGRATION.md 4a):
+ *  - flags without MI355_ICP_FLAG_UPSTREAM (rounds 1-3): level step 2^l, plane equations about the cloud origin,
+ *    out_residual[k] = smallest fval = sqrt(sum |p-q|^2) / n_level of the finest level that ran, in cloud units;
+ *  - MI355_ICP_FLAG_UPSTREAM (what a cv::ppf_match_3d::ICP built from upstream's source does, as recalled): the model's
+ *    normals travel with it (the model must be uploaded as N x 6 rows, as the reference's is: opencv_surface_match.cpp:22),
+ *    upstream's pre-normalisation - joint-mean centre, scale n / mean distance - is applied algebraically (the plane
+ *    equations are written about that centre, the pose is composed in that frame and returned in cloud coordinates),
+ *    fval is the norm over all six columns of the matched rows in the normalised units, so out_residual[k] is the number
+ *    upstream's Pose3D::residual holds, the level step is cvRound(n / cvRound(n / 2^l)) of the MODEL size for both clouds,
+ *    and the pass limit rounds half to even.
  * Replaces: ICP::registerModelToScene(model, scene, poses) with the reference's parameters. */
 int mi355_icp_align_reference(mi355_icp_ctx* ctx, int n_jobs, const int* source_ids, const int* target_ids,
                               const double* init_poses, const mi355_icp_reference_params* params, double* out_poses,
@@ -251,6 +274,20 @@ int mi355_icp_align_reference(mi355_icp_ctx* ctx, int n_jobs, const int* source_
 int mi355_icp_reference_pass(mi355_icp_ctx* ctx, int source_id, int target_id, int level, const double* pose_start,
                              const double* pose_cur, float rejection_scale, int32_t* out_index, float* out_dist2,
                              uint8_t* out_selected, float* out_threshold, double* out_sums);
+
+/* One pass of either form on the level that keeps every step-th point of both clouds (step >= 1; upstream's steps are
+ * not always powers of two), for parity checks.  centre == NULL: the round 1-3 form (out_sums[29] = 0); centre given
+ * (3 floats): the upstream-faithful form - plane equations about centre, out_sums[29] = sum |n_p - n_q|^2 - which needs the
+ * source uploaded with normals.  Outputs are level-local (n_source / step entries); out_sums holds MI355_ICP_NREFSUMS_EX
+ * doubles.  Any output may be NULL. */
+int mi355_icp_reference_pass_ex(mi355_icp_ctx* ctx, int source_id, int target_id, unsigned step, const double* pose_start,
+                                const double* pose_cur, float rejection_scale, const float* centre, int32_t* out_index,
+                                float* out_dist2, uint8_t* out_selected, float* out_threshold, double* out_sums);
+
+/* Centre and scale of upstream's pre-normalisation for (source_id under `pose`, target_id), as MI355_ICP_FLAG_UPSTREAM
+ * computes them (for parity checks): out_centre 3 floats, out_scale one double. */
+int mi355_icp_upstream_normalisation(mi355_icp_ctx* ctx, int source_id, int target_id, const double* pose, float* out_centre,
+                                     double* out_scale);
 
 /* Minimum-norm least-squares solution x = (rx, ry, rz, tx, ty, tz) of the 6x6 normal equations packed in
  * sums (symmetric eigen-decomposition in double).  [host] */

@@ -565,8 +565,10 @@ int oracle_omp_max_threads(void) {
  *       symmetric-eigen pseudo-inverse); PoseX = [Rx(x0) Ry(x1) Rz(x2) | x3..5]
  *     fval = sqrt(sum |p - q|^2) / n_level
  *   after the level: pose = PoseX * pose, residual = smallest fval of the level
- * Deviations from upstream, on purpose: no pre-normalisation of the clouds (the iterates are
- * scale-invariant in exact arithmetic; the residual is therefore in cloud units), fval over xyz only.   */
+ * Deviations of THIS form from upstream (rounds 1-3; kept behind a flag since round 4): no pre-normalisation of the
+ * clouds (the residual is in cloud units, and the plane equations are linearised about the cloud origin, not about
+ * upstream's joint mean), fval over xyz only, step 2^l whatever the model size, round-half-up of the pass limit.  The
+ * UPSTREAM-FAITHFUL variant further down (oracle_icp_reference_upstream) restates those four as well.   */
 
 #define NREF 29 /* 21 upper-triangle A^T A, 6 A^T b, sum |p-q|^2, count */
 
@@ -789,6 +791,241 @@ int oracle_icp_reference(const float* src_xyz, size_t ns, const float* tgt6, siz
     free(s_l); free(t_l);
   }
   memcpy(out_pose, pose, sizeof(pose));
+  if (out_residual) *out_residual = residual;
+  if (out_passes) *out_passes = passes;
+  return OR_OK;
+}
+
+/* ======================================================================== */
+/* Reference mode, UPSTREAM-FAITHFUL variant (round 4; MI355_ICP_FLAG_UPSTREAM in the product).
+ *
+ * The form above leaves out four things upstream's cv::ppf_match_3d::ICP::registerModelToScene does that change its
+ * CONTROL FLOW (how many passes a level runs, hence the pose and the residual the reference's best-pose rule reads at
+ * opencv_surface_match.cpp:114-118).  This variant restates them.  Everything below is RECALLED from upstream's
+ * published source (opencv_contrib modules/surface_matching/src/icp.cpp, c_utils.hpp, ppf_helpers.cpp); that source is
+ * absent from /root/reference and from this image and cannot be checked offline - PARITY UNPINNED, as above.
+ *
+ *  (a) the model is N x 6 (opencv_surface_match.cpp:22): transformPCPose rotates and re-normalises its normals with the
+ *      cloud, and the matched rows carry them;
+ *  (b) fval = cv::norm(Src_Match, Dst_Match) / rows(level source): the L2 norm over ALL SIX columns of the selected
+ *      (level-start model row, scene row) pairs - position differences in the normalised units of (c) and the difference
+ *      of the rotated model normal and the scene normal;
+ *  (c) before the level loop: meanAvg = (mean(model') + mean(scene)) / 2 with model' = the model under the candidate pose;
+ *      both clouds minus (float)meanAvg; scale = n / ((sum |model'_i| + sum |scene_j|) / 2) over the centred clouds
+ *      (computeDistToOrigin returns the SUM of the distances, its comment notwithstanding), xyz columns times scale;
+ *      the level loop runs from the identity on those clouds; afterwards t <- t / scale + meanAvg - R meanAvg, and the
+ *      wrapper appends that pose to the candidate's (Pose3D::appendPose);
+ *  (d) level step: numSamples = cvRound(n / 2^level), sampleStep = cvRound(n / numSamples), n the MODEL's row count, used
+ *      for BOTH clouds (samplePCUniform: rows 0, step, 2 step, ..., rows / step of them); cvRound rounds half to even
+ *      (also in MaxIterationsPyr = cvRound(iterations / (level + 1)): 250 / 4 -> 62, where the form above takes 63).
+ *
+ * How (c) is restated: ALGEBRAICALLY.  Materialising upstream's clouds would mean one centred and scaled copy of the SCENE
+ * per candidate pose (meanAvg and scale depend on the candidate).  Instead the clouds stay as they are and the similarity
+ * x' = scale (x - c), c = (float)meanAvg, is carried through the formulas - exact in real arithmetic:
+ *   - nearest neighbours, the MAD threshold test and the picky winners are invariant under a common similarity;
+ *   - the plane equations are written for p - c and q - c (row [(p - c) x n, n], rhs (q - p).n): the linearisation of the
+ *     rotation is about upstream's origin, which is what makes the iterates differ from a solve about the camera origin
+ *     (second order in the rotation, times |c|); upstream's unknowns are (rpy, scale t), so x[3..5] here is its t / scale;
+ *   - poses live in the centred frame (PoseX_c, pose_c); the pose a pass is evaluated under in cloud coordinates is
+ *     Tr(c) X_c Tr(-c) T0 with T0 the candidate pose, which is also what is returned (upstream: appendPose of the
+ *     un-normalised pose);
+ *   - fval = sqrt(scale^2 sum |p - q|^2 + sum |n_p - n_q|^2) / n_level, the residual is upstream's number.
+ * What this cannot reproduce: the float32 roundings of upstream's intermediate clouds (it rounds the
+ * candidate-transformed, centred, scaled and level-start clouds to float32 one after the other; here the original float32
+ * model goes through ONE float32 transform by the composed pose, the contract of the header) - differences of a few
+ * 1e-7 relative in coordinates, which move a nearest neighbour or a threshold decision only at near-ties; FLANN's tie
+ * order; picky's indexing quirk (above).  tests/upstream_literal.py materialises upstream's clouds step by step in numpy
+ * and is compared with this restatement (tests/test_upstream_variant_cpu.py).
+ *
+ * Numeric definitions pinned here (the GPU path reproduces them):
+ *   mean(model') = R0 mean(model) + t0 in double (means: sequential double sums of the float32 coordinates / rows)
+ *   c = (float)(0.5 (mean(model') + mean(scene)))
+ *   |x - c| = sqrtf(((r0 r0) + (r1 r1)) + (r2 r2)), r = x - c in float32 (upstream's float expression), summed in double,
+ *     model' points = the float32 transform of the header under the candidate pose
+ *   rotated model normal: (R n) / |R n| with R the float32 rounding of the level-start pose in cloud coordinates, products
+ *     and sums in double (left to right), rounded to float32 like upstream's convertTo; zero if |R n| <= FLT_EPSILON     */
+
+#define NREFX 30 /* the 29 above + sum |n_p - n_q|^2 */
+
+/* cvRound: upstream rounds through cvtsd2si / lrint under the default rounding mode - half to even */
+static long cv_round(double v) { return lrint(v); }
+
+/* sampling step of pyramid level `level` for a model of n_model rows; 0: the level has no samples (n / 2^level rounds to 0;
+ * upstream would divide by zero there) */
+uint32_t oracle_upstream_step(size_t n_model, int level) {
+  const double div = pow(2.0, (double)level);
+  const long num = cv_round((double)n_model / div);
+  if (num < 1) return 0;
+  const long step = cv_round((double)n_model / (double)num);
+  return step < 1 ? 1u : (uint32_t)step;
+}
+
+int oracle_upstream_max_iterations(int iterations, int level) { return (int)cv_round((double)iterations / (double)(level + 1)); }
+
+/* pose in cloud coordinates of the centred-frame pose Xc: Tr(c) Xc Tr(-c) T0 */
+void oracle_from_centred(const double Xc[16], const float c[3], const double T0[16], double out[16]) {
+  double M[16];
+  memcpy(M, Xc, sizeof(M));
+  for (int i = 0; i < 3; ++i) {
+    double rc = Xc[4 * i] * (double)c[0] + Xc[4 * i + 1] * (double)c[1] + Xc[4 * i + 2] * (double)c[2];
+    M[4 * i + 3] = (Xc[4 * i + 3] + (double)c[i]) - rc;
+  }
+  mat4_mul(M, T0, out);
+}
+
+static double dist_to_centre(const float p[3], const float c[3]) {
+  float r0 = p[0] - c[0], r1 = p[1] - c[1], r2 = p[2] - c[2];
+  float a = r0 * r0, b = r1 * r1, e = r2 * r2;
+  a = a + b;
+  a = a + e;
+  return (double)sqrtf(a);
+}
+
+/* centre (float32) and scale of upstream's pre-normalisation for model src (rows of src_stride floats) under init_pose */
+void oracle_upstream_normalisation(const float* src, size_t ns, size_t src_stride, const float* tgt, size_t nt, size_t tgt_stride,
+                                   const double init_pose[16], float centre[3], double* scale) {
+  double ms[3] = {0, 0, 0}, mt[3] = {0, 0, 0};
+  for (size_t i = 0; i < ns; ++i)
+    for (int a = 0; a < 3; ++a) ms[a] += (double)src[i * src_stride + a];
+  for (size_t j = 0; j < nt; ++j)
+    for (int a = 0; a < 3; ++a) mt[a] += (double)tgt[j * tgt_stride + a];
+  for (int a = 0; a < 3; ++a) { ms[a] /= (double)ns; mt[a] /= (double)nt; }
+  for (int a = 0; a < 3; ++a) {
+    double m = ((init_pose[4 * a] * ms[0] + init_pose[4 * a + 1] * ms[1]) + init_pose[4 * a + 2] * ms[2]) + init_pose[4 * a + 3];
+    centre[a] = (float)(0.5 * (m + mt[a]));
+  }
+  float pf[12];
+  oracle_pose_to_f32(init_pose, pf);
+  double ds = 0.0, dt = 0.0;
+  for (size_t i = 0; i < ns; ++i) {
+    float p[3];
+    xform(pf, src[i * src_stride], src[i * src_stride + 1], src[i * src_stride + 2], &p[0], &p[1], &p[2]);
+    ds += dist_to_centre(p, centre);
+  }
+  for (size_t j = 0; j < nt; ++j) dt += dist_to_centre(&tgt[j * tgt_stride], centre);
+  *scale = (double)ns / ((ds + dt) * 0.5);
+}
+
+/* One pass on level clouds, both variants.  src: ns rows of src_stride floats (xyz, or xyz + normal when centre != NULL);
+ * centre == NULL: exactly oracle_ref_pass, sums[29] = 0.  centre != NULL: plane equations about centre, sums[29] = sum over
+ * the selected pairs of |n_p - n_q|^2 (n_p: the model normal under the level-start pose, as defined above). */
+size_t oracle_ref_pass_ex(const float* src, size_t ns, size_t src_stride, const float* tgt6, size_t nt, const double pose_start[16],
+                          const double pose_cur[16], float rejection_scale, const float* centre, int nthreads, double sums[NREFX],
+                          int32_t* out_idx, float* out_d2, uint8_t* out_selected, float* out_threshold) {
+  float *tgt_xyz = (float*)malloc(nt * 3 * sizeof(float)), *moved = (float*)malloc(ns * 3 * sizeof(float));
+  float* start = (float*)malloc(ns * 3 * sizeof(float));
+  float* sxyz = (float*)malloc(ns * 3 * sizeof(float));
+  int32_t* idx = (int32_t*)malloc(ns * sizeof(int32_t));
+  float* d2 = (float*)malloc(ns * sizeof(float));
+  for (size_t j = 0; j < nt; ++j) memcpy(&tgt_xyz[3 * j], &tgt6[6 * j], 3 * sizeof(float));
+  for (size_t i = 0; i < ns; ++i) memcpy(&sxyz[3 * i], &src[i * src_stride], 3 * sizeof(float));
+  float pf[12], ps[12];
+  oracle_pose_to_f32(pose_cur, pf);
+  oracle_transform(pf, sxyz, ns, moved);
+  oracle_pose_to_f32(pose_start, ps);
+  oracle_transform(ps, sxyz, ns, start);
+  oracle_kdtree* tree = oracle_kdtree_build(tgt_xyz, nt);
+  oracle_kdtree_query(tree, moved, ns, idx, d2, nthreads);
+  oracle_kdtree_free(tree);
+  float thr = INFINITY;
+  if (rejection_scale > 0.0f) thr = oracle_rejection_threshold(d2, ns, rejection_scale);
+  int32_t* owner = (int32_t*)malloc(nt * sizeof(int32_t));
+  for (size_t j = 0; j < nt; ++j) owner[j] = -1;
+  for (size_t i = 0; i < ns; ++i) {
+    if (!(d2[i] < thr)) continue;
+    int32_t j = idx[i];
+    if (owner[j] < 0 || d2[i] < d2[owner[j]]) owner[j] = (int32_t)i;
+  }
+  for (int k = 0; k < NREFX; ++k) sums[k] = 0.0;
+  const double C[3] = {centre ? (double)centre[0] : 0.0, centre ? (double)centre[1] : 0.0, centre ? (double)centre[2] : 0.0};
+  size_t nsel = 0;
+  for (size_t i = 0; i < ns; ++i) {
+    int sel = (d2[i] < thr) && owner[idx[i]] == (int32_t)i;
+    if (out_selected) out_selected[i] = (uint8_t)sel;
+    if (!sel) continue;
+    ++nsel;
+    const float* p = &start[3 * i];
+    const float* q = &tgt6[6 * (size_t)idx[i]];
+    double P[3] = {p[0], p[1], p[2]}, Q[3] = {q[0], q[1], q[2]}, Nn[3] = {q[3], q[4], q[5]};
+    double Pc[3] = {P[0] - C[0], P[1] - C[1], P[2] - C[2]};
+    double a[6] = {Pc[1] * Nn[2] - Pc[2] * Nn[1], Pc[2] * Nn[0] - Pc[0] * Nn[2], Pc[0] * Nn[1] - Pc[1] * Nn[0], Nn[0], Nn[1], Nn[2]};
+    double dx = Q[0] - P[0], dy = Q[1] - P[1], dz = Q[2] - P[2];
+    double b = dx * Nn[0] + dy * Nn[1] + dz * Nn[2];
+    int k = 0;
+    for (int r = 0; r < 6; ++r)
+      for (int c = r; c < 6; ++c) sums[k++] += a[r] * a[c];
+    for (int r = 0; r < 6; ++r) sums[21 + r] += a[r] * b;
+    sums[27] += dx * dx + dy * dy + dz * dz;
+    sums[28] += 1.0;
+    if (centre) {
+      const float* sn = &src[i * src_stride + 3];
+      double n2[3], np32[3];
+      for (int r = 0; r < 3; ++r)
+        n2[r] = ((double)ps[4 * r] * (double)sn[0] + (double)ps[4 * r + 1] * (double)sn[1]) + (double)ps[4 * r + 2] * (double)sn[2];
+      const double nn = sqrt((n2[0] * n2[0] + n2[1] * n2[1]) + n2[2] * n2[2]);
+      for (int r = 0; r < 3; ++r) np32[r] = nn > 1.192092896e-07 ? (double)(float)(n2[r] / nn) : 0.0;
+      const double ex = np32[0] - Nn[0], ey = np32[1] - Nn[1], ez = np32[2] - Nn[2];
+      sums[29] += (ex * ex + ey * ey) + ez * ez;
+    }
+  }
+  if (out_idx) memcpy(out_idx, idx, ns * sizeof(int32_t));
+  if (out_d2) memcpy(out_d2, d2, ns * sizeof(float));
+  if (out_threshold) *out_threshold = thr;
+  free(tgt_xyz); free(moved); free(start); free(sxyz); free(idx); free(d2); free(owner);
+  return nsel;
+}
+
+/* src6 / tgt6: N x 6 rows (xyz + normal).  out_centre (3 floats), out_scale, out_level_passes (num_levels ints, passes run on
+ * each level, index = level) may be NULL. */
+int oracle_icp_reference_upstream(const float* src6, size_t ns, const float* tgt6, size_t nt, const double init_pose[16],
+                                  const oracle_ref_params* rp, int nthreads, double out_pose[16], double* out_residual,
+                                  int* out_passes, float* out_centre, double* out_scale, int* out_level_passes) {
+  if (!rp || rp->iterations < 1 || rp->num_levels < 1 || !ns || !nt) return OR_INVALID;
+  float centre[3];
+  double scale;
+  oracle_upstream_normalisation(src6, ns, 6, tgt6, nt, 6, init_pose, centre, &scale);
+  if (out_centre) memcpy(out_centre, centre, sizeof(centre));
+  if (out_scale) *out_scale = scale;
+  double pose_c[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  double residual = 0.0;
+  int passes = 0;
+  for (int level = rp->num_levels - 1; level >= 0; --level) {
+    if (out_level_passes) out_level_passes[level] = 0;
+    const size_t step = oracle_upstream_step(ns, level);
+    if (!step) continue;
+    const size_t ns_l = ns / step, nt_l = nt / step;
+    if (ns_l < 6 || nt_l < 1) continue;
+    float* s_l = (float*)malloc(ns_l * 6 * sizeof(float));
+    float* t_l = (float*)malloc(nt_l * 6 * sizeof(float));
+    for (size_t i = 0; i < ns_l; ++i) memcpy(&s_l[6 * i], &src6[6 * i * step], 6 * sizeof(float));
+    for (size_t j = 0; j < nt_l; ++j) memcpy(&t_l[6 * j], &tgt6[6 * j * step], 6 * sizeof(float));
+    const double tolp = (double)rp->tolerance * (double)(level + 1) * (double)(level + 1);
+    const int maxit = oracle_upstream_max_iterations(rp->iterations, level);
+    double posex[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double fval_old = 9999999999.0, fval_perc = 0.0, fval_min = 9999999999.0;
+    int i = 0;
+    while (!(fval_perc < 1.0 + tolp && fval_perc > 1.0 - tolp) && i < maxit) {
+      double cur_c[16], start_o[16], cur_o[16], sums[NREFX], x[6];
+      mat4_mul(posex, pose_c, cur_c);
+      oracle_from_centred(pose_c, centre, init_pose, start_o);
+      oracle_from_centred(cur_c, centre, init_pose, cur_o);
+      size_t nsel = oracle_ref_pass_ex(s_l, ns_l, 6, t_l, nt_l, start_o, cur_o, rp->rejection_scale, centre, nthreads, sums, NULL, NULL, NULL, NULL);
+      ++passes;
+      if (out_level_passes) out_level_passes[level] += 1;
+      if (nsel < 6) break;
+      if (oracle_solve_point_to_plane(sums, x) != OR_OK) break;
+      oracle_euler_pose(x, posex);
+      double fval = sqrt(scale * scale * sums[27] + sums[29]) / (double)ns_l;
+      fval_perc = fval / fval_old;
+      fval_old = fval;
+      if (fval < fval_min) fval_min = fval;
+      ++i;
+    }
+    mat4_mul(posex, pose_c, pose_c);
+    residual = fval_min;
+    free(s_l); free(t_l);
+  }
+  oracle_from_centred(pose_c, centre, init_pose, out_pose);
   if (out_residual) *out_residual = residual;
   if (out_passes) *out_passes = passes;
   return OR_OK;

@@ -16,6 +16,7 @@ NSUMS = 17
 UNIQUE_ID_BYTES = 128
 FLAG_PROFILE = 1
 FLAG_PRUNED_SCAN = 2
+FLAG_UPSTREAM = 4
 
 OK = 0
 ERR_INVALID_ARGUMENT = 1
@@ -57,6 +58,7 @@ class ReferenceParams(C.Structure):
 
 
 NREFSUMS = 29
+NREFSUMS_EX = 30
 
 
 class Profile(C.Structure):
@@ -127,6 +129,12 @@ SIGNATURES = {
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355_icp_reference_pass": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                            C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_float), C.c_void_p]),
+    "mi355_icp_reference_pass_ex": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_float), C.c_void_p]),
+    "mi355_icp_upstream_normalisation": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, _P(C.c_double)]),
+    "mi355_icp_level_slab_step": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _P(C.c_size_t), _P(C.c_size_t),
+                                            _P(C.c_size_t), _P(C.c_size_t)]),
+    "mi355_icp_upstream_step": (C.c_uint, [C.c_size_t, C.c_int]),
     "mi355_icp_solve_point_to_plane": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi355_icp_solve_point_to_plane_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mi355_icp_scene_load": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_size_t]),

@@ -15,13 +15,12 @@
 
 namespace mi355 {
 
-// Which points of the slab [begin, begin + count) of a cloud of n_total points belong to pyramid level `level` of the WHOLE
-// cloud (its points are the global indices j * 2^level, j < n_total >> level): the first one's offset inside the slab,
-// how many, the level index j of the first, and the size of the whole level.
-void level_slab(uint64_t n_total, uint64_t begin, uint64_t count, int level, uint64_t* first_local, uint64_t* n_local, uint64_t* index_base,
+// Which points of the slab [begin, begin + count) of a cloud of n_total points belong to the pyramid level of the WHOLE
+// cloud that keeps every step-th point (the global indices j * step, j < n_total / step): the first one's offset inside the
+// slab, how many, the level index j of the first, and the size of the whole level.
+void level_slab(uint64_t n_total, uint64_t begin, uint64_t count, uint64_t step, uint64_t* first_local, uint64_t* n_local, uint64_t* index_base,
                 uint64_t* n_level_total) {
-  const uint64_t step = 1ull << level;
-  const uint64_t n_lvl = n_total >> level;
+  const uint64_t n_lvl = n_total / step;
   const uint64_t j_lo = (begin + step - 1) / step;
   uint64_t j_hi = (begin + count + step - 1) / step;  // first j with j * step >= begin + count
   if (j_hi > n_lvl) j_hi = n_lvl;
@@ -31,6 +30,19 @@ void level_slab(uint64_t n_total, uint64_t begin, uint64_t count, int level, uin
   *n_level_total = n_lvl;
 }
 
+
+// cvRound as upstream evaluates it (cvtsd2si / lrint under the default rounding mode): half to even.
+static long cv_round(double v) { return std::lrint(v); }
+
+uint32_t upstream_step(uint64_t n_model, int level) {
+  const double div = std::pow(2.0, static_cast<double>(level));
+  const long num = cv_round(static_cast<double>(n_model) / div);
+  if (num < 1) return 0;
+  const long step = cv_round(static_cast<double>(n_model) / static_cast<double>(num));
+  return step < 1 ? 1u : static_cast<uint32_t>(step);
+}
+
+int upstream_max_iterations(int iterations, int level) { return static_cast<int>(cv_round(static_cast<double>(iterations) / static_cast<double>(level + 1))); }
 
 // One-sided (Hestenes) Jacobi SVD of a 3x3: rotates column pairs of G = H V until
 // they are mutually orthogonal; then column norms are the singular values and
@@ -186,7 +198,7 @@ int host_update(const mi355_icp_params* p, const double* sums, int iteration, do
 // which is what cv::solve(A, b, x, DECOMP_SVD) returns for A^T A x = A^T b up to rounding (upstream solves the
 // tall system; reference call site opencv_surface_match.cpp:94).
 int solve_point_to_plane(const double* sums, double* x) {
-  for (int k = 0; k < kRefSums; ++k)
+  for (int k = 0; k < kRefSolveSums; ++k)
     if (!std::isfinite(sums[k])) return MI355_ICP_ERR_NUMERIC;
   constexpr int n = 6;
   double M[n][n], E[n][n], g[n];
@@ -269,17 +281,17 @@ __attribute__((always_inline)) inline bool any(vm8 m) {
 }  // namespace
 
 namespace {
-__attribute__((always_inline)) inline void solve_batch_body(const double* sums, int n, double* x, int* status) {
+__attribute__((always_inline)) inline void solve_batch_body(const double* sums, int n, double* x, int* status, size_t stride) {
   constexpr int N = 6;
   for (int base = 0; base < n; base += 8) {
     const int lanes = n - base < 8 ? n - base : 8;
     vd8 M[N][N], E[N][N], g[N];
     vm8 bad = vm8{0, 0, 0, 0, 0, 0, 0, 0};
     {
-      double in[kRefSums][8];
-      for (int k = 0; k < kRefSums; ++k)
-        for (int l = 0; l < 8; ++l) in[k][l] = l < lanes ? sums[static_cast<size_t>(base + l) * kRefSums + k] : (k == 0 || k == 6 || k == 11 || k == 15 || k == 18 || k == 20 ? 1.0 : 0.0);
-      for (int k = 0; k < kRefSums; ++k)
+      double in[kRefSolveSums][8];
+      for (int k = 0; k < kRefSolveSums; ++k)
+        for (int l = 0; l < 8; ++l) in[k][l] = l < lanes ? sums[static_cast<size_t>(base + l) * stride + k] : (k == 0 || k == 6 || k == 11 || k == 15 || k == 18 || k == 20 ? 1.0 : 0.0);
+      for (int k = 0; k < kRefSolveSums; ++k)
         for (int l = 0; l < 8; ++l)
           if (!std::isfinite(in[k][l])) bad[l] = -1;
       int k = 0;
@@ -354,16 +366,16 @@ __attribute__((always_inline)) inline void solve_batch_body(const double* sums, 
 }
 // The body is worth having with 512-bit registers only: GCC lowers its 64-byte vector compares and blends to scalar code on
 // AVX2 and below (measured: 3-8 x SLOWER than six scalar solves), so without AVX-512 the batch is the scalar loop.
-__attribute__((target("avx512f,avx512dq,avx512vl,avx512bw"))) void solve_batch_avx512(const double* sums, int n, double* x, int* status) {
-  solve_batch_body(sums, n, x, status);
+__attribute__((target("avx512f,avx512dq,avx512vl,avx512bw"))) void solve_batch_avx512(const double* sums, int n, double* x, int* status, size_t stride) {
+  solve_batch_body(sums, n, x, status, stride);
 }
-void solve_batch_scalar(const double* sums, int n, double* x, int* status) {
-  for (int k = 0; k < n; ++k) status[k] = solve_point_to_plane(sums + static_cast<size_t>(k) * kRefSums, x + static_cast<size_t>(k) * 6);
+void solve_batch_scalar(const double* sums, int n, double* x, int* status, size_t stride) {
+  for (int k = 0; k < n; ++k) status[k] = solve_point_to_plane(sums + static_cast<size_t>(k) * stride, x + static_cast<size_t>(k) * 6);
 }
 }  // namespace
 
-void solve_point_to_plane_batch(const double* sums, int n, double* x, int* status) {
-  static void (*const impl)(const double*, int, double*, int*) = [] {
+void solve_point_to_plane_batch(const double* sums, int n, double* x, int* status, size_t stride) {
+  static void (*const impl)(const double*, int, double*, int*, size_t) = [] {
     __builtin_cpu_init();
     const char* want = std::getenv("MI355_ICP_SOLVE_ISA");  // "scalar": one system at a time whatever the CPU has (A/B, tests)
     if (want && std::string(want) == "scalar") return &solve_batch_scalar;
@@ -372,7 +384,7 @@ void solve_point_to_plane_batch(const double* sums, int n, double* x, int* statu
       return &solve_batch_avx512;
     return &solve_batch_scalar;
   }();
-  impl(sums, n, x, status);
+  impl(sums, n, x, status, stride);
 }
 
 // ---- RANSAC plane fit, host half (mi355_icp_scene_fit_plane; reference pose_estimation.cpp:285-297) ----------------
@@ -534,13 +546,24 @@ int mi355_icp_slab_range(size_t n, int rank, int n_ranks, size_t* begin, size_t*
 int mi355_icp_level_slab(size_t n_total, size_t begin, size_t count, int level, size_t* first_local, size_t* n_level_local,
                          size_t* level_index_base, size_t* n_level_total) {
   if (level < 0 || level > 31 || begin > n_total || count > n_total - begin) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  return mi355_icp_level_slab_step(n_total, begin, count, static_cast<size_t>(1) << level, first_local, n_level_local, level_index_base, n_level_total);
+}
+
+int mi355_icp_level_slab_step(size_t n_total, size_t begin, size_t count, size_t step, size_t* first_local, size_t* n_level_local,
+                              size_t* level_index_base, size_t* n_level_total) {
+  if (step < 1 || begin > n_total || count > n_total - begin) return MI355_ICP_ERR_INVALID_ARGUMENT;
   uint64_t f = 0, n = 0, base = 0, all = 0;
-  mi355::level_slab(n_total, begin, count, level, &f, &n, &base, &all);
+  mi355::level_slab(n_total, begin, count, step, &f, &n, &base, &all);
   if (first_local) *first_local = static_cast<size_t>(f);
   if (n_level_local) *n_level_local = static_cast<size_t>(n);
   if (level_index_base) *level_index_base = static_cast<size_t>(base);
   if (n_level_total) *n_level_total = static_cast<size_t>(all);
   return MI355_ICP_OK;
+}
+
+unsigned mi355_icp_upstream_step(size_t n_model, int level) {
+  if (level < 0 || level > 62) return 0;
+  return mi355::upstream_step(n_model, level);
 }
 
 int mi355_icp_solve_rigid(const double sums[MI355_ICP_NSUMS], double out_pose[16]) {

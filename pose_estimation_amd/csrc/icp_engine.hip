@@ -97,7 +97,8 @@ struct XCopy {
   bool valid = false;
 };
 
-struct LevelPlanes {  // compacted copy of every cloud of a set at pyramid level l >= 1 (rows 0, step, 2*step, ...)
+struct LevelPlanes {  // compacted copy of every cloud of a set that keeps every step-th point (rows 0, step, 2*step, ...), step >= 2
+  uint32_t step = 0;   // 2^l in the round 1-3 form; cvRound(n / cvRound(n / 2^l)) of the model size in the upstream-faithful one
   float* planes = nullptr;
   size_t stride = 0;
   std::vector<CloudEntry> clouds;
@@ -105,7 +106,8 @@ struct LevelPlanes {  // compacted copy of every cloud of a set at pyramid level
   std::vector<uint32_t> index_base;  // per cloud: index, in the WHOLE level cloud, of this rank's first level point (0 unless sharded)
   std::vector<uint32_t> n_total;     // per cloud: points of the whole level cloud over all ranks (= clouds[k].n unless sharded)
   XCopy xt;  // targets only
-  void* rows = nullptr;  // targets only: the records the point-to-plane accumulate gathers (launch_target_rows), built on demand
+  void* rows = nullptr;  // sets with normals: the 32-byte records (x, y, z, nx | ny, nz, 0, 0) the point-to-plane accumulate reads -
+                         // the target's always, the source's in the upstream-faithful variant (its normals enter fval)
   DevicePlanes view() const { return DevicePlanes{planes, planes + stride, planes + 2 * stride}; }
 };
 
@@ -114,12 +116,15 @@ struct CloudSet {
   float* normals = nullptr;  // nx | ny | nz in the same layout, only when uploaded with rows of >= 6 floats
   size_t stride = 0;
   std::vector<CloudEntry> clouds;
-  std::vector<LevelPlanes> levels;  // levels[l - 1] = level l, built on demand by reference mode
+  std::vector<LevelPlanes> levels;  // subsampled copies by step, built on demand by reference mode; "slot" 0 is the set itself
+                                    // (step 1), slot k + 1 is levels[k]
+  std::vector<double> sum_xyz;      // per cloud: sum of x, y, z over its points (this rank's slab), taken at upload - the
+                                    // means of upstream's pre-normalisation (MI355_ICP_FLAG_UPSTREAM)
   // slab-sharded reference mode: the slab this rank holds of every cloud - [begin, begin + n) of `total` points - which
   // decides WHICH of its points belong to a pyramid level (global indices 0, step, 2 step, ...).  Empty = not sharded.
   std::vector<uint64_t> shard_begin, shard_total;
   XCopy xt;  // level-0 expansion-filter copy (targets only)
-  void* rows = nullptr;  // level-0 records for the point-to-plane accumulate (targets with normals only; built on demand)
+  void* rows = nullptr;  // level-0 records for the point-to-plane accumulate (sets with normals; built on demand)
   DevicePlanes view() const { return DevicePlanes{planes, planes + stride, planes + 2 * stride}; }
   DevicePlanes normal_view() const { return DevicePlanes{normals, normals + stride, normals + 2 * stride}; }
 };
@@ -239,6 +244,13 @@ struct mi355_icp_ctx {
   unsigned char* plane_host = nullptr; size_t plane_host_cap = 0;
   uint32_t* scene_counters = nullptr;       // device: ticket, kept total, error bits
   uint32_t* scene_counters_host = nullptr;  // pinned
+
+  // upstream's pre-normalisation (MI355_ICP_FLAG_UPSTREAM): chunk sums of a cloud's coordinates at upload, and per call the
+  // candidates' distance sums (upstream_kernels.hip), read back into pinned memory behind an event
+  double* cloud_sum_dev = nullptr; size_t cloud_sum_cap = 0;
+  double* norm_dev = nullptr; double* norm_host = nullptr; size_t norm_cap = 0;  // [job][model | scene][kCloudSumBlocks]
+  hipEvent_t norm_event = nullptr;
+  double scene_sum[3] = {0, 0, 0}; bool scene_sum_valid = false;  // coordinate sums of the scene mi355_icp_scene_normals laid out
 
   CommState comm;  // slab-sharded runs: the cross-rank exchange (comm.hip); not attached = single GPU
 
@@ -377,7 +389,28 @@ void release_cloud_buffers(mi355_icp_ctx* c, CloudSet& set) {
   set.levels.clear();
   set.shard_begin.clear();
   set.shard_total.clear();
+  set.sum_xyz.clear();
   free_xcopy(c->pool, set.xt);
+}
+
+// Coordinate sums of clouds laid out in `view` (upstream's computeMeanCols, times the row count): every cloud's kCloudSumBlocks
+// chunk sums are enqueued into `host` (3 * kCloudSumBlocks doubles per cloud); the caller synchronises the stream - every
+// upload path does anyway - and then adds the chunks up in chunk order with finish_cloud_sums.
+int enqueue_cloud_sums(mi355_icp_ctx* c, DevicePlanes view, const std::vector<CloudEntry>& clouds, std::vector<double>& host) {
+  const size_t per = 3 * static_cast<size_t>(kCloudSumBlocks);
+  host.assign(per * clouds.size(), 0.0);
+  if (clouds.empty()) return MI355_ICP_OK;
+  if (const int st = grow(c, c->cloud_sum_dev, c->cloud_sum_cap, per * clouds.size()); st != MI355_ICP_OK) return st;
+  for (size_t k = 0; k < clouds.size(); ++k) launch_cloud_sums(c->stream, view, clouds[k].off, clouds[k].n, c->cloud_sum_dev + per * k);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(host.data(), c->cloud_sum_dev, host.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  return MI355_ICP_OK;
+}
+void finish_cloud_sums(const std::vector<double>& host, size_t n_clouds, std::vector<double>& sum_xyz) {
+  sum_xyz.assign(3 * n_clouds, 0.0);
+  for (size_t k = 0; k < n_clouds; ++k)
+    for (int b = 0; b < kCloudSumBlocks; ++b)
+      for (int a = 0; a < 3; ++a) sum_xyz[3 * k + a] += host[(k * kCloudSumBlocks + static_cast<size_t>(b)) * 3 + a];
 }
 
 int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* const* xyz, const size_t* n_points,
@@ -429,7 +462,9 @@ int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* co
                           pad_value, c->upload_flags, static_cast<uint32_t>(k));
   }
   std::vector<uint32_t> flags(static_cast<size_t>(n_clouds), 0u);
+  std::vector<double> sum_chunks;
   ok = ok && hipGetLastError() == hipSuccess &&
+       enqueue_cloud_sums(c, DevicePlanes{planes, planes + stride, planes + 2 * stride}, entries, sum_chunks) == MI355_ICP_OK &&
        hipMemcpyAsync(flags.data(), c->upload_flags, flags.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
        hipStreamSynchronize(c->stream) == hipSuccess;
   if (!ok) {
@@ -447,6 +482,7 @@ int upload_clouds(mi355_icp_ctx* c, CloudSet& set, int n_clouds, const float* co
   set.normals = normals;
   set.stride = stride;
   set.clouds = std::move(entries);
+  finish_cloud_sums(sum_chunks, set.clouds.size(), set.sum_xyz);
   return MI355_ICP_OK;
 }
 
@@ -1149,10 +1185,18 @@ int reset_error_flag(mi355_icp_ctx* c) {
 // =====================================================================================================
 // Reference mode: pyramid + MAD rejection + picky + point-to-plane, batched over jobs.
 
-// Builds (once per upload, and again when the sharding changes) the compacted planes of pyramid level `level` >= 1 for
-// every cloud of `set`.  shard_begin / shard_total: this rank's slab of every cloud (nullptr = the clouds are whole).
-int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multiple, float pad_value,
-                 const std::vector<uint64_t>* shard_begin = nullptr, const std::vector<uint64_t>* shard_total = nullptr) {
+// slot of the copy of `set` that keeps every step-th point: 0 = the set itself (step 1), k + 1 = set.levels[k], -1 = not built
+int level_slot(const CloudSet& set, uint32_t step) {
+  if (step == 1) return 0;
+  for (size_t k = 0; k < set.levels.size(); ++k)
+    if (set.levels[k].step == step) return static_cast<int>(k) + 1;
+  return -1;
+}
+
+// Builds (once per upload, and again when the sharding changes) the subsampled planes of every cloud of `set` for each step of
+// `steps` that is missing.  shard_begin / shard_total: this rank's slab of every cloud (nullptr = the clouds are whole).
+int ensure_levels(mi355_icp_ctx* c, CloudSet& set, const std::vector<uint32_t>& steps, uint32_t pad_multiple, float pad_value,
+                  const std::vector<uint64_t>* shard_begin = nullptr, const std::vector<uint64_t>* shard_total = nullptr) {
   const std::vector<uint64_t> none;
   const std::vector<uint64_t>& want_begin = shard_begin ? *shard_begin : none;
   const std::vector<uint64_t>& want_total = shard_total ? *shard_total : none;
@@ -1166,10 +1210,13 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
     set.shard_begin = want_begin;
     set.shard_total = want_total;
   }
-  // every missing level up to `level` at once: reference mode starts at the coarsest level, so a new scene asks for all of
-  // them in its first call - one launch per cloud instead of one per cloud and level (7 small dependent launches per request)
-  const int have = static_cast<int>(set.levels.size());
-  if (have >= level) return MI355_ICP_OK;
+  // every missing level at once: reference mode starts at the coarsest level, so a new scene asks for all of them in its
+  // first call - one launch per cloud instead of one per cloud and level (7 small dependent launches per request)
+  std::vector<uint32_t> missing;
+  for (const uint32_t step : steps)
+    if (step > 1 && level_slot(set, step) < 0 && std::find(missing.begin(), missing.end(), step) == missing.end()) missing.push_back(step);
+  if (missing.empty()) return MI355_ICP_OK;
+  std::sort(missing.begin(), missing.end());
   std::vector<LevelPlanes> fresh;
   auto give_back = [&]() {
     for (auto& lv : fresh) {
@@ -1177,14 +1224,14 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
       c->pool.give(lv.planes);
     }
   };
-  for (int l = have + 1; l <= level; ++l) {
-    const uint32_t step = 1u << l;
+  for (const uint32_t step : missing) {
     LevelPlanes lv;
+    lv.step = step;
     uint64_t total = 0;
     for (size_t k = 0; k < set.clouds.size(); ++k) {
       const CloudEntry& e = set.clouds[k];
       uint64_t f = 0, n = e.n / step, base = 0, n_all = e.n / step;
-      if (!set.shard_begin.empty()) level_slab(set.shard_total[k], set.shard_begin[k], e.n, l, &f, &n, &base, &n_all);
+      if (!set.shard_begin.empty()) level_slab(set.shard_total[k], set.shard_begin[k], e.n, step, &f, &n, &base, &n_all);
       const uint64_t padded = (n + pad_multiple - 1) / pad_multiple * pad_multiple;
       lv.clouds.push_back(CloudEntry{static_cast<uint32_t>(total), static_cast<uint32_t>(n), static_cast<uint32_t>(padded)});
       lv.index_base.push_back(static_cast<uint32_t>(base));
@@ -1194,7 +1241,7 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
     }
     lv.stride = static_cast<size_t>(std::max<uint64_t>(total, pad_multiple));
     hipError_t e = c->pool.take(reinterpret_cast<void**>(&lv.planes), 3 * lv.stride * sizeof(float));
-    // a set with normals (targets of reference mode): the level's target rows come out of the same launch (ensure_target_rows)
+    // a set with normals: the level's rows (coordinates + normal, what the point-to-plane accumulate reads) come out of the same launch
     if (e == hipSuccess && set.normals) e = c->pool.take(&lv.rows, lv.stride * 32);
     if (e == hipSuccess && total == 0) e = hipMemsetAsync(lv.planes, 0, 3 * lv.stride * sizeof(float), c->stream);
     fresh.push_back(lv);
@@ -1210,7 +1257,7 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
       for (int q = 0; q < A.n_levels; ++q) {
         const LevelPlanes& lv = fresh[q0 + static_cast<size_t>(q)];
         A.lv[q] = SubsampleLevel{lv.planes, lv.rows, static_cast<uint32_t>(lv.stride), lv.clouds[k].off, set.clouds[k].off + lv.first[k],
-                                 lv.clouds[k].n, lv.clouds[k].padded, static_cast<uint32_t>(have + 1 + static_cast<int>(q0) + q)};
+                                 lv.clouds[k].n, lv.clouds[k].padded, lv.step};
       }
       launch_subsample_levels(c->stream, set.planes, set.stride, A, pad_value, set.normals);
     }
@@ -1222,13 +1269,13 @@ int ensure_level(mi355_icp_ctx* c, CloudSet& set, int level, uint32_t pad_multip
   return MI355_ICP_OK;
 }
 
-// the expansion-filter copy of pyramid level `level` of the targets (level 0: the uploaded clouds), built once per upload
+// the expansion-filter copy of slot `slot` of the targets (slot 0: the uploaded clouds), built once per upload
 // The sorted copy of a pyramid level is DERIVED from the level-0 copy (xtarget_build_cloud_from_parent: the level's points in
 // the parent's Morton order, an order-preserving compaction instead of a radix sort) - MI355_ICP_LEVEL_SORT=1 sorts each
 // level by itself as rounds 1-2 did (A/B; same results either way, the order of a sorted copy never reaches an output).
-int ensure_level_xcopy(mi355_icp_ctx* c, CloudSet& set, int level) {
-  if (level == 0) return ensure_xtarget(c, set);
-  LevelPlanes& lv = set.levels[static_cast<size_t>(level) - 1];
+int ensure_level_xcopy(mi355_icp_ctx* c, CloudSet& set, int slot) {
+  if (slot == 0) return ensure_xtarget(c, set);
+  LevelPlanes& lv = set.levels[static_cast<size_t>(slot) - 1];
   if (lv.xt.valid) return MI355_ICP_OK;
   if (c->level_sort) return ensure_xcopy(c, lv.view(), lv.stride, lv.clouds, lv.xt);
   int st = ensure_xtarget(c, set);
@@ -1242,7 +1289,7 @@ int ensure_level_xcopy(mi355_icp_ctx* c, CloudSet& set, int level) {
   const DevicePlanes view = lv.view();
   for (size_t k = 0; k < lv.clouds.size(); ++k)
     if (xtarget_build_cloud_from_parent(c->stream, view, lv.clouds[k].off, lv.clouds[k].n, set.xt.perm + set.clouds[k].off, set.clouds[k].n,
-                                        lv.first[k], 1u << level, c->xt_scratch, lv.xt.planes, lv.stride, lv.xt.perm, lv.xt.table, lv.xt.bf,
+                                        lv.first[k], lv.step, c->xt_scratch, lv.xt.planes, lv.stride, lv.xt.perm, lv.xt.table, lv.xt.bf,
                                         lv.xt.sub, lv.xt.bf_table, c->xt_tile_box) != 0)
       return fail(c, MI355_ICP_ERR_HIP, "deriving a pyramid level's sorted copy failed");
   launch_super_tiles(c->stream, lv.xt.table, static_cast<uint32_t>(lv.stride / kTile), lv.xt.super);
@@ -1251,24 +1298,26 @@ int ensure_level_xcopy(mi355_icp_ctx* c, CloudSet& set, int level) {
   return MI355_ICP_OK;
 }
 
-// The records the point-to-plane accumulate gathers for pyramid level `level` of the targets (ensure_level has run): built once
-// per upload from the level's planes and the level-0 normals.
-int ensure_target_rows(mi355_icp_ctx* c, CloudSet& set, int level, const void** rows_out) {
-  void*& rows = level ? set.levels[static_cast<size_t>(level) - 1].rows : set.rows;
+// The 32-byte records (coordinates + normal) of slot `slot` of a set uploaded with normals (ensure_levels has run): what the
+// point-to-plane accumulate gathers per pair from the targets and - upstream-faithful variant - reads per point from the sources.
+// Built once per upload from the level's planes and the level-0 normals (levels get theirs from the subsample launch).
+int ensure_rows(mi355_icp_ctx* c, CloudSet& set, int slot, const void** rows_out) {
+  void*& rows = slot ? set.levels[static_cast<size_t>(slot) - 1].rows : set.rows;
   if (!rows) {
-    const size_t stride = level ? set.levels[static_cast<size_t>(level) - 1].stride : set.stride;
-    const std::vector<CloudEntry>& clouds = level ? set.levels[static_cast<size_t>(level) - 1].clouds : set.clouds;
-    const DevicePlanes view = level ? set.levels[static_cast<size_t>(level) - 1].view() : set.view();
+    const size_t stride = slot ? set.levels[static_cast<size_t>(slot) - 1].stride : set.stride;
+    const std::vector<CloudEntry>& clouds = slot ? set.levels[static_cast<size_t>(slot) - 1].clouds : set.clouds;
+    const DevicePlanes view = slot ? set.levels[static_cast<size_t>(slot) - 1].view() : set.view();
+    const uint32_t step = slot ? set.levels[static_cast<size_t>(slot) - 1].step : 1u;
     void* fresh = nullptr;
     HIP_TRY(c, c->pool.take(&fresh, std::max<size_t>(stride, 1) * 32));
     for (size_t k = 0; k < clouds.size(); ++k) {
-      const uint32_t first = level ? set.levels[static_cast<size_t>(level) - 1].first[k] : 0u;
-      launch_target_rows(c->stream, view, clouds[k].off, clouds[k].n, set.normal_view(), set.clouds[k].off + first, 1u << level, fresh);
+      const uint32_t first = slot ? set.levels[static_cast<size_t>(slot) - 1].first[k] : 0u;
+      launch_target_rows(c->stream, view, clouds[k].off, clouds[k].n, set.normal_view(), set.clouds[k].off + first, step, fresh);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
       c->pool.give(fresh);
-      return fail(c, MI355_ICP_ERR_HIP, std::string("building the target rows: ") + hipGetErrorString(e));
+      return fail(c, MI355_ICP_ERR_HIP, std::string("building the point rows: ") + hipGetErrorString(e));
     }
     rows = fresh;
   }
@@ -1276,8 +1325,14 @@ int ensure_target_rows(mi355_icp_ctx* c, CloudSet& set, int level, const void** 
   return MI355_ICP_OK;
 }
 
-const std::vector<CloudEntry>& level_clouds(const CloudSet& set, int level) { return level ? set.levels[level - 1].clouds : set.clouds; }
-DevicePlanes level_view(const CloudSet& set, int level) { return level ? set.levels[level - 1].view() : set.view(); }
+const std::vector<CloudEntry>& level_clouds(const CloudSet& set, int slot) { return slot ? set.levels[slot - 1].clouds : set.clouds; }
+DevicePlanes level_view(const CloudSet& set, int slot) { return slot ? set.levels[slot - 1].view() : set.view(); }
+
+// Which copies of the two cloud sets a reference-mode pass runs on, and in which form.
+struct RefLevel {
+  int sslot = 0, tslot = 0;  // level_slot of the sources / of the targets for the level's step
+  bool upstream = false;     // MI355_ICP_FLAG_UPSTREAM: model rows with normals, plane equations about RefJobDesc::centre
+};
 
 int ensure_ref_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs, size_t owner_total) {
   int st;
@@ -1323,10 +1378,10 @@ int ensure_ref_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs, size_t
 
 // One reference-mode pass for the first n_active descriptors of jobs_host / rjobs_host on pyramid level `level`.
 // Leaves the 29 sums per job in ref_sums_host and the thresholds in thr_host (synchronises the stream).
-int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, float rejection_scale, size_t owner_total,
+int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, const RefLevel& level, int n_active, float rejection_scale, size_t owner_total,
                       bool profile, bool defer, bool* retry);
 
-int run_ref_pass(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, float rejection_scale, size_t owner_total,
+int run_ref_pass(mi355_icp_ctx* c, const Plan& plan, const RefLevel& level, int n_active, float rejection_scale, size_t owner_total,
                  bool profile) {
   bool retry = false;
   int st = run_ref_pass_once(c, plan, level, n_active, rejection_scale, owner_total, profile, plan.fused && defer_pays(c, plan, n_active), &retry);
@@ -1334,7 +1389,7 @@ int run_ref_pass(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, fl
   return st;
 }
 
-int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_active, float rejection_scale, size_t owner_total,
+int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, const RefLevel& level, int n_active, float rejection_scale, size_t owner_total,
                       bool profile, bool defer, bool* retry) {
   *retry = false;
   // this pass's tag of the owner keys: one smaller prefix per pass, the table cleared once per 63 passes (picky_key)
@@ -1360,9 +1415,11 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
   const bool mfma_path = plan.fused && plan.xfilter && plan.xkind == 3 && !plan.pruned && pairs < 5e10;
   const bool self_staged = (exact_path || mfma_path) && all_scan && fill_stage_args(c->jobs_host, c->rjobs_host, n_active, &staged);
   if (!self_staged && stage_jobs(c->stream, c->jobs_host, c->rjobs_host, n_active, c->jobs_dev, c->rjobs_dev) != MI355_ICP_OK) return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
-  const DevicePlanes S = level_view(c->sources, level), T = level_view(c->targets, level);
-  const void* target_rows = nullptr;  // built by the level's first pass after an upload
-  if (const int rst = ensure_target_rows(c, c->targets, level, &target_rows); rst != MI355_ICP_OK) return rst;
+  const DevicePlanes S = level_view(c->sources, level.sslot), T = level_view(c->targets, level.tslot);
+  const void *target_rows = nullptr, *source_rows = nullptr;  // built by the level's first pass after an upload
+  if (const int rst = ensure_rows(c, c->targets, level.tslot, &target_rows); rst != MI355_ICP_OK) return rst;
+  if (level.upstream)
+    if (const int rst = ensure_rows(c, c->sources, level.sslot, &source_rows); rst != MI355_ICP_OK) return rst;
   const size_t ref_key_need = static_cast<size_t>(plan.fused ? plan.key_rows() : plan.max_split) * plan.out_total;
   if ((plan.pruned ? false : plan.fused ? (plan.key_ranks() * ref_key_need > c->keys3_cap || plan.out_total > c->overflow_list_cap) : ref_key_need > c->keys_cap) ||
       plan.out_total > c->out_cap || plan.out_total > c->selected_cap || owner_total > c->owner_cap ||
@@ -1422,7 +1479,7 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, int level, int n_activ
       const int cst = comm_min_u64(c->comm, c->owner, std::max<size_t>(owner_total, 1), c->stream, &why);
       if (cst != MI355_ICP_OK) return fail(c, cst, std::string("cross-rank owner table: ") + (why ? why : "?"));
     }
-    if (sbx) launch_ref_accumulate(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, S, target_rows, c->out_index,
+    if (sbx) launch_ref_accumulate(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, S, source_rows, target_rows, c->out_index,
                                    c->out_dist2, c->thr_dev, c->owner, c->want_selected ? c->selected : nullptr, c->ref_partials, tail);
   }
   // the pass result, ref_sums_dev or (PassTail) ref_sums_host directly: [n x 29 sums][n overflow-excess flags][n thresholds][n overflow counts]
@@ -1473,6 +1530,125 @@ int check_reference_inputs(mi355_icp_ctx* c, int n_jobs, const int* source_ids, 
     if (s < 0 || static_cast<size_t>(s) >= c->sources.clouds.size()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "source id out of range");
     if (t < 0 || static_cast<size_t>(t) >= c->targets.clouds.size()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "target id out of range");
   }
+  return MI355_ICP_OK;
+}
+
+// ---- upstream's pre-normalisation (MI355_ICP_FLAG_UPSTREAM): centre and scale per candidate ------------------------------
+// pose in cloud coordinates of the centred-frame pose Xc: Tr(c) Xc Tr(-c) T0 (oracle_from_centred)
+void from_centred(const double* Xc, const float* centre, const double* T0, double* out) {
+  double M[16];
+  std::memcpy(M, Xc, sizeof(M));
+  for (int i = 0; i < 3; ++i) {
+    const double rc = Xc[4 * i] * static_cast<double>(centre[0]) + Xc[4 * i + 1] * static_cast<double>(centre[1]) + Xc[4 * i + 2] * static_cast<double>(centre[2]);
+    M[4 * i + 3] = (Xc[4 * i + 3] + static_cast<double>(centre[i])) - rc;
+  }
+  mat4_mul(M, T0, out);
+}
+
+struct Normalisation {
+  std::vector<float> centre;     // 3 per job: (float)meanAvg
+  std::vector<double> scale;     // per job, valid after finish()
+  std::vector<uint64_t> n_model; // per job: rows of the WHOLE model (all ranks)
+  bool pending = false;
+};
+
+// Enqueues what the candidates' centres and scales need: centres on the host at once (cloud sums were taken at upload), the
+// distance sums as one small launch per 8 jobs whose partial rows come back behind an event (normalisation_finish).
+int normalisation_begin(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* target_ids, const double* poses, Normalisation& N) {
+  const size_t n_src_clouds = c->sources.clouds.size();
+  if (c->sources.sum_xyz.size() != 3 * n_src_clouds || c->targets.sum_xyz.size() != 3 * c->targets.clouds.size())
+    return fail(c, MI355_ICP_ERR_INTERNAL, "upstream normalisation: cloud sums missing");
+  // model sums and sizes over ALL ranks (slab-sharded: every rank holds a slab of each model)
+  std::vector<double> msum(c->sources.sum_xyz);
+  std::vector<uint64_t> mrows(n_src_clouds);
+  for (size_t k = 0; k < n_src_clouds; ++k) mrows[k] = c->sources.clouds[k].n;
+  if (c->comm.attached()) {
+    std::vector<double> mine(4 * n_src_clouds), all(4 * n_src_clouds * static_cast<size_t>(c->comm.size));
+    for (size_t k = 0; k < n_src_clouds; ++k) {
+      for (int a = 0; a < 3; ++a) mine[4 * k + a] = c->sources.sum_xyz[3 * k + a];
+      mine[4 * k + 3] = static_cast<double>(c->sources.clouds[k].n);
+    }
+    const char* why = nullptr;
+    const int cst = comm_allgather_host(c->comm, mine.data(), all.data(), mine.size() * sizeof(double), c->stream, &why);
+    if (cst != MI355_ICP_OK) return fail(c, cst, std::string("upstream normalisation: exchanging the model sums: ") + (why ? why : "?"));
+    for (size_t k = 0; k < n_src_clouds; ++k) {
+      double acc[4] = {0, 0, 0, 0};
+      for (int r = 0; r < c->comm.size; ++r)  // rank order: identical bits on every rank
+        for (int a = 0; a < 4; ++a) acc[a] += all[static_cast<size_t>(r) * 4 * n_src_clouds + 4 * k + a];
+      for (int a = 0; a < 3; ++a) msum[3 * k + a] = acc[a];
+      mrows[k] = static_cast<uint64_t>(acc[3]);
+    }
+  }
+  N.centre.assign(3 * static_cast<size_t>(n_jobs), 0.f);
+  N.scale.assign(static_cast<size_t>(n_jobs), 0.0);
+  N.n_model.assign(static_cast<size_t>(n_jobs), 0);
+  const size_t per_job = 2 * static_cast<size_t>(kCloudSumBlocks);
+  if (per_job * static_cast<size_t>(n_jobs) > c->norm_cap) {
+    if (c->norm_dev) { HIP_TRY(c, hipFree(c->norm_dev)); c->norm_dev = nullptr; }
+    if (c->norm_host) { HIP_TRY(c, hipHostFree(c->norm_host)); c->norm_host = nullptr; }
+    c->norm_cap = 0;
+    const size_t want = per_job * std::max<size_t>(static_cast<size_t>(n_jobs), 8) * 2;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->norm_dev), want * sizeof(double)));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->norm_host), want * sizeof(double), hipHostMallocDefault));
+    c->norm_cap = want;
+  }
+  if (!c->norm_event) HIP_TRY(c, hipEventCreateWithFlags(&c->norm_event, hipEventDisableTiming));
+  const DevicePlanes S = c->sources.view(), T = c->targets.view();
+  for (int first = 0; first < n_jobs; first += 8) {
+    NormArgs A{};
+    A.n = static_cast<uint32_t>(std::min(8, n_jobs - first));
+    A.first = static_cast<uint32_t>(first);
+    for (uint32_t q = 0; q < A.n; ++q) {
+      const int k = first + static_cast<int>(q);
+      const int s = source_ids ? source_ids[k] : 0, t = target_ids ? target_ids[k] : 0;
+      const double* P = poses + 16 * static_cast<size_t>(k);
+      const CloudEntry& SE = c->sources.clouds[static_cast<size_t>(s)];
+      const CloudEntry& TE = c->targets.clouds[static_cast<size_t>(t)];
+      N.n_model[static_cast<size_t>(k)] = mrows[static_cast<size_t>(s)];
+      if (mrows[static_cast<size_t>(s)] == 0 || TE.n == 0) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "upstream normalisation: empty cloud");
+      NormJob& J = A.jobs[q];
+      for (int a = 0; a < 3; ++a) {
+        const double ms[3] = {msum[3 * s] / static_cast<double>(mrows[s]), msum[3 * s + 1] / static_cast<double>(mrows[s]), msum[3 * s + 2] / static_cast<double>(mrows[s])};
+        const double m = ((P[4 * a] * ms[0] + P[4 * a + 1] * ms[1]) + P[4 * a + 2] * ms[2]) + P[4 * a + 3];
+        const double mt = c->targets.sum_xyz[3 * static_cast<size_t>(t) + a] / static_cast<double>(TE.n);
+        N.centre[3 * static_cast<size_t>(k) + a] = static_cast<float>(0.5 * (m + mt));
+        J.centre[a] = N.centre[3 * static_cast<size_t>(k) + a];
+      }
+      if (!pose_to_f32(P, J.pose)) return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "upstream normalisation: non-finite pose");
+      J.src_off = SE.off; J.src_n = SE.n; J.tgt_off = TE.off; J.tgt_n = TE.n;
+    }
+    launch_centre_dists(c->stream, A, S, T, c->norm_dev);
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(c->norm_host, c->norm_dev, per_job * static_cast<size_t>(n_jobs) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipEventRecord(c->norm_event, c->stream));
+  N.pending = true;
+  return MI355_ICP_OK;
+}
+
+// scale = n / ((sum |model'_i - c| + sum |scene_j - c|) / 2); the chunk sums are added in chunk order, the ranks' in rank order
+int normalisation_finish(mi355_icp_ctx* c, int n_jobs, Normalisation& N) {
+  if (!N.pending) return MI355_ICP_OK;
+  HIP_TRY(c, hipEventSynchronize(c->norm_event));
+  N.pending = false;
+  std::vector<double> ds(static_cast<size_t>(n_jobs), 0.0), dt(static_cast<size_t>(n_jobs), 0.0);
+  for (int k = 0; k < n_jobs; ++k)
+    for (int b = 0; b < kCloudSumBlocks; ++b) {
+      ds[k] += c->norm_host[(static_cast<size_t>(k) * 2) * kCloudSumBlocks + b];
+      dt[k] += c->norm_host[(static_cast<size_t>(k) * 2 + 1) * kCloudSumBlocks + b];
+    }
+  if (c->comm.attached()) {  // the model is sharded, the scene replicated
+    std::vector<double> all(static_cast<size_t>(n_jobs) * static_cast<size_t>(c->comm.size));
+    const char* why = nullptr;
+    const int cst = comm_allgather_host(c->comm, ds.data(), all.data(), ds.size() * sizeof(double), c->stream, &why);
+    if (cst != MI355_ICP_OK) return fail(c, cst, std::string("upstream normalisation: exchanging the distance sums: ") + (why ? why : "?"));
+    for (int k = 0; k < n_jobs; ++k) {
+      double acc = 0.0;
+      for (int r = 0; r < c->comm.size; ++r) acc += all[static_cast<size_t>(r) * n_jobs + k];
+      ds[k] = acc;
+    }
+  }
+  for (int k = 0; k < n_jobs; ++k) N.scale[k] = static_cast<double>(N.n_model[k]) / ((ds[k] + dt[k]) * 0.5);
   return MI355_ICP_OK;
 }
 
@@ -1587,6 +1763,10 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   (void)hipFree(c->scene_planes);
   (void)hipFree(c->upload_raw);
   (void)hipFree(c->upload_flags);
+  (void)hipFree(c->cloud_sum_dev);
+  (void)hipFree(c->norm_dev);
+  if (c->norm_host) (void)hipHostFree(c->norm_host);
+  if (c->norm_event) (void)hipEventDestroy(c->norm_event);
   free_xcopy(c->pool, c->scene_xt);
   c->pool.release_all();  // the stream was drained above
   if (c->xt_meta_host) (void)hipHostFree(c->xt_meta_host);
@@ -1810,6 +1990,23 @@ int mi355_icp_debug_filter_bounds(mi355_icp_ctx* c, int source_id, int target_id
   return finish(MI355_ICP_OK);
 }
 
+int mi355_icp_upstream_normalisation(mi355_icp_ctx* c, int source_id, int target_id, const double* pose, float* out_centre, double* out_scale) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  c->err.clear();
+  if (!pose) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "upstream_normalisation: bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (c->targets.clouds.empty() || c->sources.clouds.empty()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "upstream_normalisation: upload clouds first");
+  if (source_id < 0 || static_cast<size_t>(source_id) >= c->sources.clouds.size() || target_id < 0 || static_cast<size_t>(target_id) >= c->targets.clouds.size())
+    return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "upstream_normalisation: cloud id out of range");
+  Normalisation N;
+  int st = normalisation_begin(c, 1, &source_id, &target_id, pose, N);
+  if (st == MI355_ICP_OK) st = normalisation_finish(c, 1, N);
+  if (st != MI355_ICP_OK) return st;
+  if (out_centre) std::memcpy(out_centre, N.centre.data(), 3 * sizeof(float));
+  if (out_scale) *out_scale = N.scale[0];
+  return MI355_ICP_OK;
+}
+
 int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const int* target_ids,
                               const double* init_poses, const mi355_icp_reference_params* rp, double* out_poses,
                               double* out_residual, int* out_passes, int* out_status) {
@@ -1820,6 +2017,13 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
   HIP_TRY(c, hipSetDevice(c->device));
   int st = check_reference_inputs(c, n_jobs, source_ids, target_ids);
   if (st != MI355_ICP_OK) return st;
+  // MI355_ICP_FLAG_UPSTREAM: what upstream's cv::ppf_match_3d::ICP does where the round 1-3 form left its control flow (model
+  // normals in fval, pre-normalisation, cvRound sampling step and pass limit): oracle/icp_oracle.c, "UPSTREAM-FAITHFUL variant"
+  const bool upstream = (rp->flags & MI355_ICP_FLAG_UPSTREAM) != 0;
+  if (upstream && !c->sources.normals)
+    return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT,
+                "align_reference: MI355_ICP_FLAG_UPSTREAM needs the model's normals: upload the sources as rows of >= 6 float32 (xyz + normal, "
+                "as the reference's models are: opencv_surface_match.cpp:22), or drop the flag for the round 1-3 form");
   // Slab-sharded (a communicator is attached): every rank holds a contiguous slab of each source cloud.  The ranks tell
   // each other their slab sizes once per call; from them every rank knows where its slab begins in the whole cloud,
   // hence which of its points belong to a pyramid level (global indices 0, step, 2 step, ...) and their global level
@@ -1848,59 +2052,95 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
     for (size_t k = 0; k < n_clouds; ++k)
       if (shard_total[k] >= (1ull << 32)) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: a sharded source cloud has 2^32 points or more");
   }
-  // points of the whole (all ranks) source cloud `s` on pyramid level `level`, and this rank's part of it
-  auto level_total = [&](int s, int level) -> uint64_t {
-    return (sharded ? shard_total[static_cast<size_t>(s)] : c->sources.clouds[static_cast<size_t>(s)].n) >> level;
-  };
+  auto sid = [&](int k) { return source_ids ? source_ids[k] : 0; };
+  auto tid = [&](int k) { return target_ids ? target_ids[k] : 0; };
+  // rows of the whole (all ranks) source cloud `s`, and the step with which pyramid level `level` samples BOTH clouds of a job
+  // on that model (0 = the level does not exist for it)
+  auto model_rows = [&](int s) -> uint64_t { return sharded ? shard_total[static_cast<size_t>(s)] : c->sources.clouds[static_cast<size_t>(s)].n; };
+  auto step_of = [&](int s, int level) -> uint32_t { return upstream ? upstream_step(model_rows(s), level) : (1u << level); };
   if (const int est = reset_error_flag(c); est != MI355_ICP_OK) return est;
   c->error_word_known = false;
   // Slab-sharded: the picky pass tags restart with every call (table cleared at its first pass) - a function of the call's pass
   // sequence only, hence the same on every rank whatever the ranks' engines did before.  One GPU: the tags simply run on across
   // calls (a key of ANY later pass beats the keys of earlier ones), so the 4.8 MB table of a request's six candidates is cleared
-  // once per 63 passes - every third or fourth request - instead of at the start of each.
+  // once per 63 passes - every third or fourth request - instead of at the start of each.  Whoever replaces or grows c->owner
+  // clears it (ensure_ref_buffers); whoever resets owner_epoch to 0 gets it cleared by the next pass (run_ref_pass_once).
   if (sharded) c->owner_epoch = 0;
   c->call_pruned = (rp->flags & MI355_ICP_FLAG_PRUNED_SCAN) != 0;
   const bool profile = c->profile_always || (rp->flags & MI355_ICP_FLAG_PROFILE) != 0;
 
   std::vector<double> solve_x;
   std::vector<int> solve_st;
-  struct JobState { double pose[16]; double residual = 0.0; int passes = 0; int status = MI355_ICP_OK; };
+  // frame: the pose composed so far in the frame the level loop works in - cloud coordinates starting from the candidate pose
+  // (round 1-3 form), or upstream's centred frame starting from the identity (the candidate pose is applied first, as
+  // upstream's wrapper does with transformPCPose, and the result is appended to it)
+  struct JobState { double init[16]; double frame[16]; double residual = 0.0; int passes = 0; int status = MI355_ICP_OK; };
   struct LevelState { double posex[16]; double start[16]; double fval_old, fval_perc, fval_min; int i; bool done; };
   std::vector<JobState> js(static_cast<size_t>(n_jobs));
+  const double I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   for (int k = 0; k < n_jobs; ++k) {
-    std::memcpy(js[k].pose, init_poses + 16 * static_cast<size_t>(k), sizeof(js[k].pose));
+    std::memcpy(js[k].init, init_poses + 16 * static_cast<size_t>(k), sizeof(js[k].init));
+    std::memcpy(js[k].frame, upstream ? I16 : js[k].init, sizeof(js[k].frame));
     float tmp[12];
-    if (!pose_to_f32(js[k].pose, tmp)) return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "align_reference: non-finite initial pose");
+    if (!pose_to_f32(js[k].init, tmp)) return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "align_reference: non-finite initial pose");
   }
-  auto sid = [&](int k) { return source_ids ? source_ids[k] : 0; };
-  auto tid = [&](int k) { return target_ids ? target_ids[k] : 0; };
+  Normalisation norm;
+  if (upstream && (st = normalisation_begin(c, n_jobs, source_ids, target_ids, init_poses, norm)) != MI355_ICP_OK) return st;
+  // the pose in cloud coordinates of a pose X of job k's working frame
+  auto to_cloud = [&](int k, const double* X, double* out) {
+    if (upstream) from_centred(X, norm.centre.data() + 3 * static_cast<size_t>(k), js[k].init, out);
+    else std::memcpy(out, X, 16 * sizeof(double));
+  };
+
+  // every subsampled copy the call will need, built in one go (a new scene: all of its levels from one launch)
+  auto level_runs = [&](int k, int level, uint32_t* step_out) {
+    const uint32_t step = step_of(sid(k), level);
+    *step_out = step;
+    if (!step) return false;
+    return model_rows(sid(k)) / step >= 6 && c->targets.clouds[tid(k)].n / step >= 1;  // decided on the WHOLE cloud: every rank keeps the same jobs
+  };
+  {
+    std::vector<uint32_t> steps;
+    for (int level = 0; level < rp->num_levels; ++level)
+      for (int k = 0; k < n_jobs; ++k) {
+        uint32_t step = 0;
+        if (level_runs(k, level, &step) && std::find(steps.begin(), steps.end(), step) == steps.end()) steps.push_back(step);
+      }
+    if ((st = ensure_levels(c, c->sources, steps, kSrcPad, 0.0f, sharded ? &shard_begin : nullptr, sharded ? &shard_total : nullptr)) != MI355_ICP_OK) return st;
+    if ((st = ensure_levels(c, c->targets, steps, kTile, kTargetPad)) != MI355_ICP_OK) return st;
+  }
 
   bool select_cleared = false, overflow_cleared = false;
   for (int level = rp->num_levels - 1; level >= 0; --level) {
-    const uint32_t step = 1u << level;
-    std::vector<int> part, psid, ptid;
+    // the jobs of this level by sampling step (one group in the round 1-3 form, and whenever the candidates share a model)
+    std::map<uint32_t, std::vector<int>> groups;
     for (int k = 0; k < n_jobs; ++k) {
       if (js[k].status != MI355_ICP_OK) continue;
-      const uint64_t ns_l = level_total(sid(k), level);
-      const uint32_t nt_l = c->targets.clouds[tid(k)].n / step;
-      if (ns_l < 6 || nt_l < 1) continue;  // decided on the WHOLE cloud: every rank keeps the same jobs
-      if (ns_l >= (1ull << kPickyIndexBits)) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: more than 2^27 model points on a level (picky owner keys hold 27 index bits)");
-      part.push_back(k);
-      psid.push_back(sid(k));
-      ptid.push_back(tid(k));
+      uint32_t step = 0;
+      if (!level_runs(k, level, &step)) continue;
+      if (model_rows(sid(k)) / step >= (1ull << kPickyIndexBits)) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: more than 2^27 model points on a level (picky owner keys hold 27 index bits)");
+      groups[step].push_back(k);
     }
-    if (part.empty()) continue;
-    if ((st = ensure_level(c, c->sources, level, kSrcPad, 0.0f, sharded ? &shard_begin : nullptr, sharded ? &shard_total : nullptr)) != MI355_ICP_OK) return st;
-    if ((st = ensure_level(c, c->targets, level, kTile, kTargetPad)) != MI355_ICP_OK) return st;
+   for (const auto& group : groups) {
+    const uint32_t step = group.first;
+    const std::vector<int>& part = group.second;
+    std::vector<int> psid, ptid;
+    for (const int k : part) { psid.push_back(sid(k)); ptid.push_back(tid(k)); }
+    RefLevel lvl;
+    lvl.sslot = level_slot(c->sources, step);
+    lvl.tslot = level_slot(c->targets, step);
+    lvl.upstream = upstream;
+    if (lvl.sslot < 0 || lvl.tslot < 0) return fail(c, MI355_ICP_ERR_INTERNAL, "align_reference: a pyramid level is missing");
+    auto level_total = [&](int s) -> uint64_t { return model_rows(s) / step; };  // points of the whole (all ranks) level cloud
     Plan plan;
     const int np = static_cast<int>(part.size());
-    if ((st = make_plan_on(c, level_clouds(c->sources, level), level_clouds(c->targets, level), np, psid.data(), ptid.data(), 0.0f, plan)) != MI355_ICP_OK) return st;
+    if ((st = make_plan_on(c, level_clouds(c->sources, lvl.sslot), level_clouds(c->targets, lvl.tslot), np, psid.data(), ptid.data(), 0.0f, plan)) != MI355_ICP_OK) return st;
     if ((st = ensure_buffers(c, plan, static_cast<size_t>(np), &overflow_cleared)) != MI355_ICP_OK) return st;
     std::vector<uint32_t> owner_off(static_cast<size_t>(np));
     size_t owner_total = 0;
     for (int a = 0; a < np; ++a) {
       owner_off[a] = static_cast<uint32_t>(owner_total);
-      owner_total += level_clouds(c->targets, level)[ptid[a]].padded;
+      owner_total += level_clouds(c->targets, lvl.tslot)[ptid[a]].padded;
     }
     if ((st = ensure_ref_buffers(c, plan, static_cast<size_t>(np), owner_total)) != MI355_ICP_OK) return st;
     // the selection histograms are left clear by every completed pass; make that true whatever an earlier call left behind
@@ -1910,16 +2150,16 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
       HIP_TRY(c, hipMemsetAsync(c->select_work, 0, c->ref_jobs_cap * (2048 + 4) * sizeof(uint32_t), c->stream));
       select_cleared = true;
     }
-    if ((plan.xfilter || plan.pruned) && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
-    if ((plan.pruned || plan.sorted_src) && (st = ensure_level_xcopy(c, c->sources, level)) != MI355_ICP_OK) return st;
+    if ((plan.xfilter || plan.pruned) && (st = ensure_level_xcopy(c, c->targets, lvl.tslot)) != MI355_ICP_OK) return st;
+    if ((plan.pruned || plan.sorted_src) && (st = ensure_level_xcopy(c, c->sources, lvl.sslot)) != MI355_ICP_OK) return st;
 
     const double tolp = static_cast<double>(rp->tolerance) * static_cast<double>(level + 1) * static_cast<double>(level + 1);
-    const int maxit = static_cast<int>(std::floor(static_cast<double>(rp->iterations) / static_cast<double>(level + 1) + 0.5));
+    const int maxit = upstream ? upstream_max_iterations(rp->iterations, level)
+                               : static_cast<int>(std::floor(static_cast<double>(rp->iterations) / static_cast<double>(level + 1) + 0.5));
     std::vector<LevelState> ls(static_cast<size_t>(np));
     for (int a = 0; a < np; ++a) {
-      const double I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-      std::memcpy(ls[a].posex, I, sizeof(I));
-      std::memcpy(ls[a].start, js[part[a]].pose, sizeof(I));
+      std::memcpy(ls[a].posex, I16, sizeof(I16));
+      std::memcpy(ls[a].start, js[part[a]].frame, sizeof(I16));
       ls[a].fval_old = 9999999999.0;
       ls[a].fval_perc = 0.0;
       ls[a].fval_min = 9999999999.0;
@@ -1937,26 +2177,31 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
       for (size_t q = 0; q < active.size(); ++q) {
         const int a = active[q];
         JobDesc J = plan.jobs[static_cast<size_t>(a)];
-        double cur[16];
+        double cur[16], cur_cloud[16], start_cloud[16];
         mat4_mul(ls[a].posex, ls[a].start, cur);
+        to_cloud(part[a], cur, cur_cloud);
+        to_cloud(part[a], ls[a].start, start_cloud);
         RefJobDesc R{};
-        if (!pose_to_f32(cur, J.pose) || !pose_to_f32(ls[a].start, R.pose_start)) return fail(c, MI355_ICP_ERR_NUMERIC, "align_reference: pose overflowed float32");
+        if (!pose_to_f32(cur_cloud, J.pose) || !pose_to_f32(start_cloud, R.pose_start)) return fail(c, MI355_ICP_ERR_NUMERIC, "align_reference: pose overflowed float32");
         R.owner_off = owner_off[a];
         R.normal_off = c->targets.clouds[ptid[a]].off;
         R.step = step;
-        if (sharded) {  // global level indices and counts (level 0: the slab itself)
-          J.src_n_total = static_cast<uint32_t>(level_total(psid[a], level));
-          R.src_index_base = level ? c->sources.levels[static_cast<size_t>(level) - 1].index_base[static_cast<size_t>(psid[a])]
-                                   : static_cast<uint32_t>(shard_begin[static_cast<size_t>(psid[a])]);
+        if (upstream) std::memcpy(R.centre, norm.centre.data() + 3 * static_cast<size_t>(part[a]), sizeof(R.centre));
+        if (sharded) {  // global level indices and counts (step 1: the slab itself)
+          J.src_n_total = static_cast<uint32_t>(level_total(psid[a]));
+          R.src_index_base = lvl.sslot ? c->sources.levels[static_cast<size_t>(lvl.sslot) - 1].index_base[static_cast<size_t>(psid[a])]
+                                       : static_cast<uint32_t>(shard_begin[static_cast<size_t>(psid[a])]);
         }
         c->jobs_host[q] = J;
         c->rjobs_host[q] = R;
       }
-      if ((st = run_ref_pass(c, plan, level, static_cast<int>(active.size()), rp->rejection_scale, owner_total, profile)) != MI355_ICP_OK) return st;
+      if ((st = run_ref_pass(c, plan, lvl, static_cast<int>(active.size()), rp->rejection_scale, owner_total, profile)) != MI355_ICP_OK) return st;
+      // the distance sums behind the candidates' scales were enqueued in front of the call's first pass: there by now
+      if (upstream && (st = normalisation_finish(c, n_jobs, norm)) != MI355_ICP_OK) return st;
       // the candidates' 6x6 systems in one SIMD pass (lane for lane the scalar solve's bits): the device idles meanwhile
       solve_x.resize(6 * active.size());
       solve_st.resize(active.size());
-      solve_point_to_plane_batch(c->ref_sums_host, static_cast<int>(active.size()), solve_x.data(), solve_st.data());
+      solve_point_to_plane_batch(c->ref_sums_host, static_cast<int>(active.size()), solve_x.data(), solve_st.data(), kRefSums);
       for (size_t q = 0; q < active.size(); ++q) {
         const int a = active[q];
         LevelState& L = ls[a];
@@ -1968,7 +2213,11 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
           continue;
         }
         euler_pose(x, L.posex);
-        const double fval = std::sqrt(sums[27]) / static_cast<double>(level_total(psid[a], level));  // all ranks' points of the level
+        // all ranks' points of the level.  Upstream: the norm over all six columns of the matched rows, positions in its
+        // normalised units (x scale) beside the difference of the normals
+        const double scale = upstream ? norm.scale[static_cast<size_t>(part[a])] : 1.0;
+        const double sq = upstream ? scale * scale * sums[27] + sums[29] : sums[27];
+        const double fval = std::sqrt(sq) / static_cast<double>(level_total(psid[a]));
         L.fval_perc = fval / L.fval_old;
         L.fval_old = fval;
         if (fval < L.fval_min) L.fval_min = fval;
@@ -1977,13 +2226,15 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
     }
     for (int a = 0; a < np; ++a) {
       JobState& S = js[part[a]];
-      mat4_mul(ls[a].posex, ls[a].start, S.pose);
+      mat4_mul(ls[a].posex, ls[a].start, S.frame);
       S.residual = ls[a].fval_min;
     }
+   }
   }
+  if (upstream && (st = normalisation_finish(c, n_jobs, norm)) != MI355_ICP_OK) return st;  // a call whose every level was skipped
   if ((st = check_error_flag(c)) != MI355_ICP_OK) return st;
   for (int k = 0; k < n_jobs; ++k) {
-    if (out_poses) std::memcpy(out_poses + 16 * static_cast<size_t>(k), js[k].pose, sizeof(js[k].pose));
+    if (out_poses) to_cloud(k, js[k].frame, out_poses + 16 * static_cast<size_t>(k));
     if (out_residual) out_residual[k] = js[k].residual;
     if (out_passes) out_passes[k] = js[k].passes;
     if (out_status) out_status[k] = js[k].status;
@@ -1991,27 +2242,33 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
   return MI355_ICP_OK;
 }
 
-int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int level, const double* pose_start,
-                             const double* pose_cur, float rejection_scale, int32_t* out_index, float* out_dist2,
-                             uint8_t* out_selected, float* out_threshold, double* out_sums) {
+int mi355_icp_reference_pass_ex(mi355_icp_ctx* c, int source_id, int target_id, unsigned step, const double* pose_start,
+                                const double* pose_cur, float rejection_scale, const float* centre, int32_t* out_index,
+                                float* out_dist2, uint8_t* out_selected, float* out_threshold, double* out_sums) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   c->err.clear();
   c->call_pruned = false;
-  if (!pose_start || !pose_cur || level < 0 || level > 23) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: bad arguments");
+  if (!pose_start || !pose_cur || step < 1) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: bad arguments");
   if (c->comm.attached()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: a single-context diagnostic; detach the communicator (mi355_icp_align_reference is the slab-sharded entry point)");
   HIP_TRY(c, hipSetDevice(c->device));
   int st = check_reference_inputs(c, 1, &source_id, &target_id);
   if (st != MI355_ICP_OK) return st;
-  if ((st = ensure_level(c, c->sources, level, kSrcPad, 0.0f)) != MI355_ICP_OK) return st;
-  if ((st = ensure_level(c, c->targets, level, kTile, kTargetPad)) != MI355_ICP_OK) return st;
+  if (centre && !c->sources.normals) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: the upstream-faithful form needs the source uploaded with normals");
+  const std::vector<uint32_t> steps{step};
+  if ((st = ensure_levels(c, c->sources, steps, kSrcPad, 0.0f)) != MI355_ICP_OK) return st;
+  if ((st = ensure_levels(c, c->targets, steps, kTile, kTargetPad)) != MI355_ICP_OK) return st;
+  RefLevel lvl;
+  lvl.sslot = level_slot(c->sources, step);
+  lvl.tslot = level_slot(c->targets, step);
+  lvl.upstream = centre != nullptr;
   Plan plan;
-  if ((st = make_plan_on(c, level_clouds(c->sources, level), level_clouds(c->targets, level), 1, &source_id, &target_id, 0.0f, plan)) != MI355_ICP_OK) return st;
+  if ((st = make_plan_on(c, level_clouds(c->sources, lvl.sslot), level_clouds(c->targets, lvl.tslot), 1, &source_id, &target_id, 0.0f, plan)) != MI355_ICP_OK) return st;
   if (plan.jobs[0].tgt_n < 1) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: the level has no target points");
   if ((st = ensure_buffers(c, plan, 1)) != MI355_ICP_OK) return st;
-  const size_t owner_total = level_clouds(c->targets, level)[target_id].padded;
+  const size_t owner_total = level_clouds(c->targets, lvl.tslot)[target_id].padded;
   if ((st = ensure_ref_buffers(c, plan, 1, owner_total)) != MI355_ICP_OK) return st;
-  if ((plan.xfilter || plan.pruned) && (st = ensure_level_xcopy(c, c->targets, level)) != MI355_ICP_OK) return st;
-  if ((plan.pruned || plan.sorted_src) && (st = ensure_level_xcopy(c, c->sources, level)) != MI355_ICP_OK) return st;
+  if ((plan.xfilter || plan.pruned) && (st = ensure_level_xcopy(c, c->targets, lvl.tslot)) != MI355_ICP_OK) return st;
+  if ((plan.pruned || plan.sorted_src) && (st = ensure_level_xcopy(c, c->sources, lvl.sslot)) != MI355_ICP_OK) return st;
   if (const int est = reset_error_flag(c); est != MI355_ICP_OK) return est;
   c->error_word_known = false;
   c->owner_epoch = 0;
@@ -2020,11 +2277,12 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
   if (!pose_to_f32(pose_cur, J.pose) || !pose_to_f32(pose_start, R.pose_start)) return fail(c, MI355_ICP_ERR_NONFINITE_INPUT, "reference_pass: non-finite pose");
   R.owner_off = 0;
   R.normal_off = c->targets.clouds[target_id].off;
-  R.step = 1u << level;
+  R.step = step;
+  if (centre) std::memcpy(R.centre, centre, sizeof(R.centre));
   c->jobs_host[0] = J;
   c->rjobs_host[0] = R;
   c->want_selected = out_selected != nullptr;
-  st = run_ref_pass(c, plan, level, 1, rejection_scale, owner_total, c->profile_always);
+  st = run_ref_pass(c, plan, lvl, 1, rejection_scale, owner_total, c->profile_always);
   c->want_selected = false;
   if (st != MI355_ICP_OK) return st;
   if (out_sums) std::memcpy(out_sums, c->ref_sums_host, kRefSums * sizeof(double));
@@ -2041,9 +2299,21 @@ int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int
   return check_error_flag(c);
 }
 
+int mi355_icp_reference_pass(mi355_icp_ctx* c, int source_id, int target_id, int level, const double* pose_start,
+                             const double* pose_cur, float rejection_scale, int32_t* out_index, float* out_dist2,
+                             uint8_t* out_selected, float* out_threshold, double* out_sums) {
+  if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  if (level < 0 || level > 23) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: bad arguments");
+  double sums[kRefSums];
+  const int st = mi355_icp_reference_pass_ex(c, source_id, target_id, 1u << level, pose_start, pose_cur, rejection_scale, nullptr, out_index, out_dist2,
+                                             out_selected, out_threshold, out_sums ? sums : nullptr);
+  if (st == MI355_ICP_OK && out_sums) std::memcpy(out_sums, sums, kRefSolveSums * sizeof(double));
+  return st;
+}
+
 int mi355_icp_solve_point_to_plane_batch(const double* sums29, int n, double* out_x, int* out_status) {
   if (!sums29 || n < 0 || !out_x || !out_status) return MI355_ICP_ERR_INVALID_ARGUMENT;
-  solve_point_to_plane_batch(sums29, n, out_x, out_status);
+  solve_point_to_plane_batch(sums29, n, out_x, out_status, kRefSolveSums);
   return MI355_ICP_OK;
 }
 
@@ -2091,6 +2361,7 @@ int mi355_icp_scene_load(mi355_icp_ctx* c, const float* xyz, size_t n_points, si
   c->scene_cur = 0;
   c->scene_loaded = true;
   c->scene_normals_valid = false;
+  c->scene_sum_valid = false;
   return MI355_ICP_OK;
 }
 
@@ -2132,6 +2403,7 @@ int mi355_icp_scene_filter(mi355_icp_ctx* c, int n_filters, const mi355_scene_fi
     c->scene_n = c->scene_counters_host[1];
     c->scene_cur ^= 1;
     c->scene_normals_valid = false;
+    c->scene_sum_valid = false;
   }
   if (out_n_points) *out_n_points = c->scene_n;
   return MI355_ICP_OK;
@@ -2211,7 +2483,18 @@ int mi355_icp_scene_normals(mi355_icp_ctx* c, int k, int flip_viewpoint, const f
                  c->scene_normal_planes, padded, out_neighbors ? c->knn_out : nullptr);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   HIP_TRY(c, hipGetLastError());
+  // the coordinate sums of this scene (upstream's pre-normalisation needs the scene's mean): they ride on the synchronisation
+  // below and go along when the scene is committed as the ICP target
+  std::vector<double> sum_chunks;
+  c->scene_sum_valid = false;
+  if ((st = enqueue_cloud_sums(c, P, std::vector<CloudEntry>{CloudEntry{0, n, padded}}, sum_chunks)) != MI355_ICP_OK) return st;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  {
+    std::vector<double> sums;
+    finish_cloud_sums(sum_chunks, 1, sums);
+    std::memcpy(c->scene_sum, sums.data(), sizeof(c->scene_sum));
+    c->scene_sum_valid = true;
+  }
   if (profile) {
     float ms = 0.f;
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->prof.knn_scan_ms += ms;
@@ -2301,7 +2584,8 @@ int mi355_icp_scene_commit_target(mi355_icp_ctx* c) {
   const size_t plane_bytes = 3 * static_cast<size_t>(padded) * sizeof(float);
   // scene_normals left, for exactly this scene: its padded SoA planes (checked finite), the normal planes and - pruned
   // k-NN - the Morton-sorted copy with the tile tables and the operand image of the matrix-core scan
-  const bool fresh = c->scene_normals_valid && c->scene_normals_padded == padded;
+  const bool fresh = c->scene_normals_valid && c->scene_normals_padded == padded && c->scene_sum_valid;
+  std::vector<double> commit_sum_chunks;
   float* planes = nullptr;
   HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&planes), plane_bytes));
   if (fresh) {
@@ -2312,6 +2596,8 @@ int mi355_icp_scene_commit_target(mi355_icp_ctx* c) {
   } else {
     bool ok = hipMemsetAsync(c->scene_counters, 0, 4 * sizeof(uint32_t), c->stream) == hipSuccess;
     launch_scene_to_planes(c->stream, c->scene[c->scene_cur], n, planes, padded, 0, padded, kTargetPad, c->scene_counters);
+    ok = ok && enqueue_cloud_sums(c, DevicePlanes{planes, planes + padded, planes + 2 * static_cast<size_t>(padded)},
+                                  std::vector<CloudEntry>{CloudEntry{0, n, padded}}, commit_sum_chunks) == MI355_ICP_OK;
     ok = ok && hipMemcpyAsync(c->scene_counters_host, c->scene_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
          hipStreamSynchronize(c->stream) == hipSuccess;
     if (!ok) {
@@ -2327,6 +2613,8 @@ int mi355_icp_scene_commit_target(mi355_icp_ctx* c) {
   set.planes = planes;
   set.stride = padded;
   set.clouds.assign(1, CloudEntry{0, n, padded});
+  if (fresh) set.sum_xyz.assign(c->scene_sum, c->scene_sum + 3);
+  else finish_cloud_sums(commit_sum_chunks, 1, set.sum_xyz);
   if (fresh) {  // normals of exactly this scene: they go along
     HIP_TRY(c, c->pool.take(reinterpret_cast<void**>(&set.normals), plane_bytes));
     HIP_TRY(c, hipMemcpyAsync(set.normals, c->scene_normal_planes, plane_bytes, hipMemcpyDeviceToDevice, c->stream));

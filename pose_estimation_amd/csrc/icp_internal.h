@@ -146,6 +146,11 @@ __device__ __forceinline__ double pass_block_sum(double (&v)[NV], double (*scrat
   constexpr int kWaves = kBlockThreads / 64;
   constexpr int kRow = 65;
   static_assert(kWaves * NV <= kBlockThreads, "one thread per (wave, value)");
+  // static LDS of a workgroup is capped at 64 KiB: the parked values, the caller's scratch[kWaves][NV] and a few words.
+  // NV = 30 (reference mode) is 62,400 + 960 bytes - two workgroups per CU; a 31st sum would need the values parked in
+  // two halves (same chains, same bits).  The order of these chains is part of the bit contract of the sums since round 3
+  // (rounds 1-2: a shuffle tree) - nothing pins the bits of a sum except run-to-run equality; parity is rtol 1e-10.
+  static_assert(sizeof(double) * (kWaves * NV * kRow + kWaves * NV) + 64 <= 64 * 1024, "pass_block_sum: parked values exceed the static LDS limit");
   __shared__ double parked[kWaves * NV * kRow];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -256,14 +261,17 @@ __device__ __forceinline__ uint32_t publish_overflow(const PassTail& tail, uint3
 }
 #endif
 
-constexpr int kRefSums = 29;  // 21 upper-triangle A^T A + 6 A^T b + sum |p-q|^2 + count
+constexpr int kRefSolveSums = MI355_ICP_NREFSUMS;  // what the 6x6 solve reads: 21 upper-triangle A^T A + 6 A^T b + sum |p-q|^2 + count
+constexpr int kRefSums = MI355_ICP_NREFSUMS_EX;    // a pass's row: those 29 + sum |n_p - n_q|^2 (upstream-faithful variant; 0 otherwise)
+static_assert(kRefSolveSums == 29 && kRefSums == 30, "reference-mode row layout");
 struct RefJobDesc {
   uint32_t owner_off;    // first slot of this job's target in the picky owner table
   uint32_t normal_off;   // first point of the job's target cloud in the LEVEL-0 normal planes
   uint32_t step;         // level stride: level point j is level-0 point j * step
   uint32_t owner_prefix; // this pass's tag in the owner keys (picky_key): smaller in every later pass
   uint32_t src_index_base;  // index, in the WHOLE level cloud, of this rank's first level point (0 unless slab-sharded)
-  uint32_t pad_[3];
+  float centre[3];       // upstream-faithful variant: (float)meanAvg of upstream's pre-normalisation - the plane equations are
+                         // written for p - centre (oracle/icp_oracle.c, "UPSTREAM-FAITHFUL variant"); unused otherwise
   float pose_start[12];  // float32 pose the level started from (defines the point the plane equation is written for)
 };
 static_assert(sizeof(RefJobDesc) == 80, "RefJobDesc layout");
@@ -292,7 +300,8 @@ __device__ __forceinline__ unsigned long long picky_key(uint32_t prefix, float d
 
 int solve_point_to_plane(const double* sums29, double* x6);
 // n systems at once, 8 per SIMD pass; x: n x 6, status: n (MI355_ICP_OK / MI355_ICP_ERR_NUMERIC).  Lane for lane the bits of solve_point_to_plane.
-void solve_point_to_plane_batch(const double* sums29, int n, double* x6, int* status);
+// System k starts at sums + k * stride (stride >= kRefSolveSums doubles; the engine's own rows are kRefSums wide).
+void solve_point_to_plane_batch(const double* sums, int n, double* x6, int* status, size_t stride = kRefSolveSums);
 void euler_pose(const double* x6, double* pose16);
 void mat4_mul(const double* a, const double* b, double* c);
 
@@ -339,8 +348,12 @@ void launch_scene_to_planes(void* stream, const float* in, uint32_t n, float* pl
                             uint32_t n_padded, float pad, uint32_t* counters);
 
 // ---- host math (host_math.cpp) ----
-void level_slab(uint64_t n_total, uint64_t begin, uint64_t count, int level, uint64_t* first_local, uint64_t* n_local, uint64_t* index_base,
+void level_slab(uint64_t n_total, uint64_t begin, uint64_t count, uint64_t step, uint64_t* first_local, uint64_t* n_local, uint64_t* index_base,
                 uint64_t* n_level_total);
+// upstream's sampling step of pyramid level `level` for a model of n_model rows: cvRound(n / cvRound(n / 2^level)), half to
+// even; 0 = the level has no samples.  And its pass limit cvRound(iterations / (level + 1)).
+uint32_t upstream_step(uint64_t n_model, int level);
+int upstream_max_iterations(int iterations, int level);
 int solve_rigid(const double* sums, double* pose16);
 int host_update(const mi355_icp_params* p, const double* sums, int iteration, double* pose16, double* prev_mse,
                 int* out_done, int* out_converged);
@@ -407,12 +420,12 @@ void launch_resolve(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t 
 void launch_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums,
                          uint32_t* overflow_count, uint32_t overflow_cap);
 
-// Pyramid levels of ONE cloud in one launch (a new scene builds seven): level q holds the level-0 rows in_off + i * 2^step_log2.
-// normals given: a level with `rows` also gets its target rows (the normals share the planes' layout: same stride, same offsets).
+// Pyramid levels of ONE cloud in one launch (a new scene builds seven): level q holds the level-0 rows in_off + i * step.
+// normals given: a level with `rows` also gets its rows (the normals share the planes' layout: same stride, same offsets).
 struct SubsampleLevel {
   float* out;        // the level's planes, x | y | z, each out_stride floats
-  void* rows;        // the level's target rows (32 bytes per point) or nullptr
-  uint32_t out_stride, out_off, in_off, n, padded, step_log2;
+  void* rows;        // the level's rows (32 bytes per point: x, y, z, nx | ny, nz, 0, 0) or nullptr
+  uint32_t out_stride, out_off, in_off, n, padded, step;
 };
 constexpr int kSubsampleMaxLevels = 8;
 struct SubsampleArgs {
@@ -433,10 +446,30 @@ void launch_picky_scatter(void* stream, const JobDesc* jobs_dev, const RefJobDes
 // rows: 32 bytes per point of a pyramid level, (x, y, z, nx | ny, nz, 0, 0); normal of level-0 row normal_off + j * step
 void launch_target_rows(void* stream, DevicePlanes level, uint32_t level_off, uint32_t n, DevicePlanes normals, uint32_t normal_off,
                         uint32_t step, void* rows);
+// source_rows != nullptr: the upstream-faithful variant (model rows with normals, plane equations about RefJobDesc::centre,
+// sum 29 = sum |n_p - n_q|^2); nullptr: the round 1-3 form from the source planes (sum 29 = 0)
 void launch_ref_accumulate(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
-                           uint32_t max_src_blocks, DevicePlanes src, const void* target_rows,
+                           uint32_t max_src_blocks, DevicePlanes src, const void* source_rows, const void* target_rows,
                            const int32_t* index, const float* dist2, const float* thr, const unsigned long long* owner,
                            uint8_t* selected, double* partials, const PassTail& tail);
+
+// ---- upstream's pre-normalisation (upstream_kernels.hip) ----
+// coordinate sums of a cloud in kCloudSumBlocks fixed chunks: partials[b][3] doubles, added up by the host in block order
+constexpr int kCloudSumBlocks = 32;
+void launch_cloud_sums(void* stream, DevicePlanes planes, uint32_t off, uint32_t n, double* partials);
+// per job: sum over the model of |T0 s - c| and over the scene of |q - c| (float32 expression of upstream's
+// computeDistToOrigin, summed in double): partials[job][which][kCloudSumBlocks], which = 0 model, 1 scene
+struct NormJob {
+  float pose[12];   // float32 candidate pose
+  float centre[3];
+  uint32_t src_off, src_n, tgt_off, tgt_n;
+  uint32_t pad_;
+};
+struct NormArgs {
+  uint32_t n, first, pad_[2];
+  NormJob jobs[8];
+};
+void launch_centre_dists(void* stream, const NormArgs& args, DevicePlanes src, DevicePlanes tgt, double* partials);
 void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums, const float* thr,
                              uint32_t* overflow_count, uint32_t overflow_cap);
 

@@ -74,23 +74,20 @@ __device__ __forceinline__ void transform_point(const float* __restrict__ m, flo
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-// Levels step_log2 = s0, s0 + 1, ... of one cloud in ONE launch: thread j stands for level-0 row j * 2^s0 (relative to the
-// level's first row) and writes it to every level whose stride divides it; the grid covers the longest padded level.
-// normals != nullptr (targets uploaded with normals): a level with `rows` also gets its target rows (target_rows_kernel's
-// records: the level's coordinates with the normal of the level-0 row each point came from).
+// Several pyramid levels of one cloud in ONE launch: level q keeps the level-0 rows in_off + i * step_q (any step >= 1: the
+// round 1-3 form samples with 2^l, the upstream-faithful one with cvRound(n / cvRound(n / 2^l)) of the model size); thread i
+// writes point i of every level that has one; the grid covers the longest padded level.
+// normals != nullptr (clouds uploaded with normals): a level with `rows` also gets its rows (target_rows_kernel's records:
+// the level's coordinates with the normal of the level-0 row each point came from).
 __global__ __launch_bounds__(kBlockThreads) void subsample_kernel(const float* __restrict__ in, size_t in_stride, SubsampleArgs A, float pad,
                                                                    const float* __restrict__ normals) {
-  const uint32_t j = blockIdx.x * kBlockThreads + threadIdx.x;
-  const uint32_t s0 = A.lv[0].step_log2;
+  const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
 #pragma unroll 1
   for (int q = 0; q < A.n_levels; ++q) {
     const SubsampleLevel& L = A.lv[q];
-    const uint32_t shift = L.step_log2 - s0;
-    if (j & ((1u << shift) - 1u)) break;  // levels are listed finest first: a row that is not on this one is on none of the coarser
-    const uint32_t i = j >> shift;
     if (i >= L.padded) continue;
     float v[3];
-    const size_t row = L.in_off + (static_cast<size_t>(i) << L.step_log2);
+    const size_t row = L.in_off + static_cast<size_t>(i) * L.step;
 #pragma unroll
     for (int plane = 0; plane < 3; ++plane) {
       v[plane] = i < L.n ? in[plane * in_stride + row] : pad;
@@ -609,9 +606,15 @@ __global__ __launch_bounds__(kBlockThreads) void target_rows_kernel(const float*
 
 // grid = (max src_blocks, n_jobs).  src are the LEVEL planes, rows the level's target records (target_rows_kernel).
 // With tail.done set the launch also ENDS the pass (single-GPU reference mode): finish_pass, icp_internal.h.
+// kUpstream (MI355_ICP_FLAG_UPSTREAM; oracle/icp_oracle.c, "UPSTREAM-FAITHFUL variant"): the model point comes with its normal
+// from the level's SOURCE rows (srows: one 32-byte record, the same layout as the target's), the plane equations are written for
+// p - centre, and sum 29 collects |n_p - n_q|^2 with n_p the model normal under the level-start rotation, re-normalised and
+// rounded to float32 the way upstream's transformPCPose leaves it.  Otherwise sum 29 stays 0.
+template <bool kUpstream>
 __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
     const JobDesc* __restrict__ jobs, const RefJobDesc* __restrict__ rjobs, const float* __restrict__ sx,
-    const float* __restrict__ sy, const float* __restrict__ sz, const float4* __restrict__ rows, const int32_t* __restrict__ index,
+    const float* __restrict__ sy, const float* __restrict__ sz, const float4* __restrict__ srows, const float4* __restrict__ rows,
+    const int32_t* __restrict__ index,
     const float* __restrict__ dist2, const float* __restrict__ thr, const unsigned long long* __restrict__ owner,
     uint8_t* __restrict__ selected, double* partials, PassTail tail) {
   __shared__ double scratch[kBlockThreads / 64][kRefSums];
@@ -651,15 +654,25 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
   unsigned long long own[kP];
   bool near[kP];
   float S0[kP], S1[kP], S2[kP], Qx[kP], Qy[kP], Qz[kP], Nx[kP], Ny[kP], Nz[kP];
+  float M0[kP], M1[kP], M2[kP];  // kUpstream: the model point's normal
 #pragma unroll
   for (int p = 0; p < kP; ++p) {
     near[p] = live[p] && (dd[p] < t);
     own[p] = 0ull;
     S0[p] = S1[p] = S2[p] = Qx[p] = Qy[p] = Qz[p] = Nx[p] = Ny[p] = Nz[p] = 0.f;
+    M0[p] = M1[p] = M2[p] = 0.f;
     if (near[p]) {
       own[p] = owner[RJ.owner_off + jt[p]];
       const uint32_t i = J.src_off + local[p];
-      S0[p] = sx[i]; S1[p] = sy[i]; S2[p] = sz[i];
+      if constexpr (kUpstream) {
+        const float4* srec = srows + 2 * static_cast<size_t>(i);
+        const float4 sa = srec[0];
+        const float2 sb2 = *reinterpret_cast<const float2*>(srec + 1);
+        S0[p] = sa.x; S1[p] = sa.y; S2[p] = sa.z;
+        M0[p] = sa.w; M1[p] = sb2.x; M2[p] = sb2.y;
+      } else {
+        S0[p] = sx[i]; S1[p] = sy[i]; S2[p] = sz[i];
+      }
       const float4* rec = rows + 2 * static_cast<size_t>(J.tgt_off + jt[p]);
       const float4 a = rec[0];
       const float2 b = *reinterpret_cast<const float2*>(rec + 1);
@@ -680,7 +693,11 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
       transform_point(pose, S0[p], S1[p], S2[p], px, py, pz);  // the level-start point
       const double P0 = px, P1 = py, P2 = pz, Q0 = Qx[p], Q1 = Qy[p], Q2 = Qz[p];
       const double N0 = Nx[p], N1 = Ny[p], N2 = Nz[p];
-      const double a[6] = {P1 * N2 - P2 * N1, P2 * N0 - P0 * N2, P0 * N1 - P1 * N0, N0, N1, N2};
+      // the point the cross product is taken with: p itself, or p - centre (upstream linearises the rotation about its joint mean)
+      const double C0 = kUpstream ? P0 - static_cast<double>(RJ.centre[0]) : P0;
+      const double C1 = kUpstream ? P1 - static_cast<double>(RJ.centre[1]) : P1;
+      const double C2 = kUpstream ? P2 - static_cast<double>(RJ.centre[2]) : P2;
+      const double a[6] = {C1 * N2 - C2 * N1, C2 * N0 - C0 * N2, C0 * N1 - C1 * N0, N0, N1, N2};
       const double dx = Q0 - P0, dy = Q1 - P1, dz = Q2 - P2;
       const double b = dx * N0 + dy * N1 + dz * N2;
       int k = 0;
@@ -692,6 +709,19 @@ __global__ __launch_bounds__(kBlockThreads) void ref_accumulate_kernel(
       for (int r = 0; r < 6; ++r) acc[21 + r] += a[r] * b;
       acc[27] += dx * dx + dy * dy + dz * dz;
       acc[28] += 1.0;
+      if constexpr (kUpstream) {
+        // n_p = (R n) / |R n|, R the float32 level-start pose, products and sums in double, rounded to float32; zero below FLT_EPSILON
+        const double m0 = M0[p], m1 = M1[p], m2 = M2[p];
+        const double r0 = (static_cast<double>(pose[0]) * m0 + static_cast<double>(pose[1]) * m1) + static_cast<double>(pose[2]) * m2;
+        const double r1 = (static_cast<double>(pose[4]) * m0 + static_cast<double>(pose[5]) * m1) + static_cast<double>(pose[6]) * m2;
+        const double r2 = (static_cast<double>(pose[8]) * m0 + static_cast<double>(pose[9]) * m1) + static_cast<double>(pose[10]) * m2;
+        const double nn = __builtin_sqrt((r0 * r0 + r1 * r1) + r2 * r2);
+        const bool ok = nn > 1.192092896e-07;
+        const double e0 = (ok ? static_cast<double>(static_cast<float>(r0 / nn)) : 0.0) - N0;
+        const double e1 = (ok ? static_cast<double>(static_cast<float>(r1 / nn)) : 0.0) - N1;
+        const double e2 = (ok ? static_cast<double>(static_cast<float>(r2 / nn)) : 0.0) - N2;
+        acc[29] += (e0 * e0 + e1 * e1) + e2 * e2;
+      }
     }
   }
   REF_DIAG_STAMP();  // 4: products accumulated (gathers arrived)
@@ -734,7 +764,7 @@ __global__ __launch_bounds__(kBlockThreads) void ref_final_reduce_kernel(const J
 // ---------------------------------------------------------------------------------------------
 void launch_subsample_levels(void* stream, const float* in, size_t in_stride, const SubsampleArgs& args, float pad, const float* normals) {
   uint32_t threads = 0;
-  for (int q = 0; q < args.n_levels; ++q) threads = std::max(threads, args.lv[q].padded << (args.lv[q].step_log2 - args.lv[0].step_log2));
+  for (int q = 0; q < args.n_levels; ++q) threads = std::max(threads, args.lv[q].padded);
   if (!threads) return;
   hipLaunchKernelGGL(subsample_kernel, dim3((threads + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0,
                      static_cast<hipStream_t>(stream), in, in_stride, args, pad, normals);
@@ -807,12 +837,16 @@ void launch_target_rows(void* stream, DevicePlanes level, uint32_t level_off, ui
 }
 
 void launch_ref_accumulate(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
-                           uint32_t max_src_blocks, DevicePlanes src, const void* target_rows,
+                           uint32_t max_src_blocks, DevicePlanes src, const void* source_rows, const void* target_rows,
                            const int32_t* index, const float* dist2, const float* thr, const unsigned long long* owner,
                            uint8_t* selected, double* partials, const PassTail& tail) {
-  hipLaunchKernelGGL(ref_accumulate_kernel, dim3(max_src_blocks, static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0,
-                     static_cast<hipStream_t>(stream), jobs_dev, rjobs_dev, src.x, src.y, src.z, static_cast<const float4*>(target_rows),
-                     index, dist2, thr, owner, selected, partials, tail);
+  auto go = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(max_src_blocks, static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0,
+                       static_cast<hipStream_t>(stream), jobs_dev, rjobs_dev, src.x, src.y, src.z, static_cast<const float4*>(source_rows),
+                       static_cast<const float4*>(target_rows), index, dist2, thr, owner, selected, partials, tail);
+  };
+  if (source_rows) go(ref_accumulate_kernel<true>);
+  else go(ref_accumulate_kernel<false>);
 }
 
 void launch_ref_final_reduce(void* stream, const JobDesc* jobs_dev, int n_jobs, const double* partials, double* sums, const float* thr,

@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import lib, Params, Profile, ReferenceParams, NSUMS, NREFSUMS
+from ._lib import lib, Params, Profile, ReferenceParams, NSUMS, NREFSUMS, NREFSUMS_EX
 
 
 class IcpError(RuntimeError):
@@ -57,6 +57,20 @@ def level_slab(n_total: int, begin: int, count: int, level: int) -> tuple[int, i
     if st != _lib.OK:
         raise IcpError(st, "level_slab")
     return f.value, n.value, b.value, t.value
+
+
+def level_slab_step(n_total: int, begin: int, count: int, step: int) -> tuple[int, int, int, int]:
+    """The same for a level that keeps every step-th point (mi355_icp_level_slab_step)."""
+    f, n, b, t = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+    st = lib.mi355_icp_level_slab_step(n_total, begin, count, step, C.byref(f), C.byref(n), C.byref(b), C.byref(t))
+    if st != _lib.OK:
+        raise IcpError(st, "level_slab_step")
+    return f.value, n.value, b.value, t.value
+
+
+def upstream_step(n_model: int, level: int) -> int:
+    """Upstream's sampling step of pyramid level `level` for a model of n_model rows (0: the level has no samples)."""
+    return int(lib.mi355_icp_upstream_step(n_model, level))
 
 
 def solve_rigid(sums: np.ndarray) -> np.ndarray:
@@ -130,7 +144,8 @@ def synth_cloud(seed: int, count: int, first_index: int = 0, noise_seed: int = 0
 @dataclass
 class ReferenceResult:
     poses: np.ndarray     # [n_jobs, 4, 4]
-    residual: np.ndarray  # [n_jobs] smallest fval of the finest level that ran (cloud units)
+    residual: np.ndarray  # [n_jobs] smallest fval of the finest level that ran (cloud units; upstream's normalised units
+                          # with FLAG_UPSTREAM)
     passes: np.ndarray    # [n_jobs] correspondence passes over all pyramid levels
     status: np.ndarray    # [n_jobs]
 
@@ -303,6 +318,32 @@ class IcpEngine:
                                                  float(rejection_scale), idx.ctypes.data, d2.ctypes.data, sel.ctypes.data,
                                                  C.byref(thr), sums.ctypes.data))
         return idx, d2, sel.astype(bool), thr.value, sums
+
+    def reference_pass_ex(self, pose_start: np.ndarray, pose_cur: np.ndarray, step: int = 1, rejection_scale: float = 2.5,
+                          centre=None, source_id: int = 0, target_id: int = 0):
+        """One pass of either form on the level that keeps every step-th point: (index, dist2, selected mask, threshold,
+        sums[30]).  centre=None: the round 1-3 form; centre (3 floats): the upstream-faithful form."""
+        n = self._source_sizes[source_id] // step
+        ps = np.ascontiguousarray(pose_start, dtype=np.float64).reshape(16)
+        pc = np.ascontiguousarray(pose_cur, dtype=np.float64).reshape(16)
+        cc = None if centre is None else np.ascontiguousarray(centre, dtype=np.float32).reshape(3)
+        idx = np.empty(n, dtype=np.int32)
+        d2 = np.empty(n, dtype=np.float32)
+        sel = np.empty(n, dtype=np.uint8)
+        thr = C.c_float()
+        sums = np.empty(NREFSUMS_EX, dtype=np.float64)
+        self._check(lib.mi355_icp_reference_pass_ex(self._h, source_id, target_id, step, ps.ctypes.data, pc.ctypes.data,
+                                                    float(rejection_scale), None if cc is None else cc.ctypes.data,
+                                                    idx.ctypes.data, d2.ctypes.data, sel.ctypes.data, C.byref(thr), sums.ctypes.data))
+        return idx, d2, sel.astype(bool), thr.value, sums
+
+    def upstream_normalisation(self, pose: np.ndarray, source_id: int = 0, target_id: int = 0):
+        """(centre float32[3], scale) of upstream's pre-normalisation for the model under `pose` against the scene."""
+        p = np.ascontiguousarray(pose, dtype=np.float64).reshape(16)
+        centre = np.empty(3, dtype=np.float32)
+        scale = C.c_double()
+        self._check(lib.mi355_icp_upstream_normalisation(self._h, source_id, target_id, p.ctypes.data, centre.ctypes.data, C.byref(scale)))
+        return centre, scale.value
 
     # -- scene preparation (the reference's point filters as one-pass stream compaction)
     def scene_load(self, xyz: np.ndarray):

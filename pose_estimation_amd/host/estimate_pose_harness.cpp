@@ -4,7 +4,7 @@
 // driving the refine half through the C++ mirror.  PPF matching is not part of this path, so candidate
 // poses are synthesised around the known alignment the way PPF votes would deliver them.
 //
-//   estimate_pose_harness <n_model> <n_scene> [n_candidates] [reference|pipeline] [pruned]
+//   estimate_pose_harness <n_model> <n_scene> [n_candidates] [reference|pipeline] [pruned] [legacy]
 //     prints the 7-float pose and per-candidate results; "reference" selects Mode::Reference (scene with normals);
 //     "pipeline" starts from a raw camera-like frame (NaN dropouts + a table plane) and runs the whole
 //     create_surface_match_pc -> computeNormalsPC3d -> ICP chain on the device: NaN removal, plane band, k = 20
@@ -50,21 +50,26 @@ int main(int argc, char** argv) {
   const bool pipeline = argc > 4 && std::string(argv[4]) == "pipeline";
   const bool reference_mode = pipeline || (argc > 4 && std::string(argv[4]) == "reference");
   const bool pruned = argc > 5 && std::string(argv[5]) == "pruned";  // MI355_ICP_FLAG_PRUNED_SCAN for the ICP
+  const bool legacy = (argc > 5 && std::string(argv[5]) == "legacy") || (argc > 6 && std::string(argv[6]) == "legacy");  // the round 1-3 form of reference mode
   EstimatePoseRequest req;
   req.object = "bumpy_sphere";
   EstimatePoseResponse resp;
   try {
     // scene = target sample; model = independent noisy sample moved by a known 5 degree perturbation
     const mi355::Pose T = rotation_about(1, 2, 3, 5.0, 0.02, -0.01, 0.03);
-    const size_t scene_cols = reference_mode ? 6 : 3;
-    std::vector<float> scene(scene_cols * n_scene), model(3 * n_model);
+    // reference mode: both clouds as N x 6 rows (xyz + normal), the layout of the reference's models
+    // (opencv_surface_match.cpp:22) and of the scene it hands to the ICP (:57-59)
+    const size_t scene_cols = reference_mode ? 6 : 3, model_cols = scene_cols;
+    std::vector<float> scene(scene_cols * n_scene), model(model_cols * n_model);
     if (reference_mode) mi355_icp_synth_cloud6(0x5EED0001ull, 0, 0.0, nullptr, 0, n_scene, scene.data());
     else mi355_icp_synth_cloud(0x5EED0001ull, 0, 0.0, nullptr, 0, n_scene, scene.data());
-    mi355_icp_synth_cloud(0x5EED0002ull, 0x5EED0003ull, 1e-3, T.data(), 0, n_model, model.data());
+    if (reference_mode) mi355_icp_synth_cloud6(0x5EED0002ull, 0x5EED0003ull, 1e-3, T.data(), 0, n_model, model.data());
+    else mi355_icp_synth_cloud(0x5EED0002ull, 0x5EED0003ull, 1e-3, T.data(), 0, n_model, model.data());
 
     using mi355::ppf_match_3d::ICP;
     ICP icp(250, 0.005f, 2.5f, 8, 0, reference_mode ? ICP::Mode::Reference : ICP::Mode::PointToPoint);  // the reference's arguments
     icp.setPrunedScan(pruned);
+    icp.setUpstreamFaithful(!legacy);
     std::vector<mi355::ppf_match_3d::Pose3DPtr> results;
     const size_t votes[] = {300, 900, 500, 450, 100, 420, 50, 10};
     for (int k = 0; k < n_cand; ++k) {
@@ -91,7 +96,7 @@ int main(int argc, char** argv) {
       mi355::Engine& eng = icp.engine();
       // the object model goes up once, like the reference's (load_models at start-up keeps it in the detector:
       // pose_estimation.cpp, opencv_surface_match.cpp:load_model); a request brings a new scene only
-      eng.set_sources({mi355::CloudView{model.data(), n_model, 12}});
+      eng.set_sources({mi355::CloudView{model.data(), n_model, 4 * model_cols}});
       // the request is run three times: the last pass shows the steady state of a service (buffers sized, code loaded)
       for (int rep = 0; rep < 3; ++rep) {
       for (int k = 0; k < n_cand; ++k) results[k]->updatePose(rotation_about(0.2, 1, -0.4, 1.0 + k, 0.01, -0.02, 0.015));
@@ -129,7 +134,7 @@ int main(int argc, char** argv) {
       pose.assign(7, 0.f);
       mi355_icp_pose_to_pose7(results[best]->pose.data(), pose.data(), 1);
     } else {
-      pose = mi355::ppf_match_3d::refine_candidates(icp, mi355::CloudView{model.data(), n_model, 12},
+      pose = mi355::ppf_match_3d::refine_candidates(icp, mi355::CloudView{model.data(), n_model, 4 * model_cols},
                                                     mi355::CloudView{scene.data(), n_scene, 4 * scene_cols}, results, true, &best);
     }
     for (size_t k = 0; k < results.size(); ++k)

@@ -189,8 +189,12 @@ using Pose3DPtr = std::shared_ptr<Pose3D>;
 // Mirror of cv::ppf_match_3d::ICP: same constructor arguments as the reference call site.
 // Mode::Reference (default: it is what the reference's call runs) keeps all four arguments live (pyramid, MAD
 // rejection, picky, point-to-plane on the scene normals: mi355_icp_align_reference) and needs the scene as N x 6 rows,
-// which is what the reference hands over (opencv_surface_match.cpp:57-59).  Mode::PointToPoint must be asked for by
-// name: the engine of BASELINE.json (exact NN + Kabsch; numLevels and rejectionScale are recorded only).
+// which is what the reference hands over (opencv_surface_match.cpp:57-59).  It runs with MI355_ICP_FLAG_UPSTREAM -
+// upstream's control flow as recalled: model normals in the stop rule, pre-normalisation, cvRound sampling step - so the
+// model must be N x 6 rows too, as the reference's models are (opencv_surface_match.cpp:22); setUpstreamFaithful(false)
+// selects the round 1-3 form (xyz-only stop rule, step 2^l, residual in cloud units; works with an N x 3 model).
+// Mode::PointToPoint must be asked for by name: the engine of BASELINE.json (exact NN + Kabsch; numLevels and
+// rejectionScale are recorded only).
 class ICP {
  public:
   enum class Mode { PointToPoint, Reference };
@@ -204,7 +208,7 @@ class ICP {
     ref_params_.tolerance = tolerence;
     ref_params_.rejection_scale = rejectionScale;
     ref_params_.num_levels = numLevels;
-    ref_params_.flags = 0;
+    ref_params_.flags = MI355_ICP_FLAG_UPSTREAM;
   }
 
   // Refines every pose in place (pose, t, q, residual), returns 0 like upstream.  A candidate whose solve fails keeps
@@ -249,6 +253,11 @@ class ICP {
   void setPrunedScan(bool on) {
     params_.flags = on ? (params_.flags | MI355_ICP_FLAG_PRUNED_SCAN) : (params_.flags & ~MI355_ICP_FLAG_PRUNED_SCAN);
     ref_params_.flags = on ? (ref_params_.flags | MI355_ICP_FLAG_PRUNED_SCAN) : (ref_params_.flags & ~MI355_ICP_FLAG_PRUNED_SCAN);
+  }
+
+  // Reference mode: upstream's control flow (default) or the round 1-3 form.  Not upstream API.
+  void setUpstreamFaithful(bool on) {
+    ref_params_.flags = on ? (ref_params_.flags | MI355_ICP_FLAG_UPSTREAM) : (ref_params_.flags & ~MI355_ICP_FLAG_UPSTREAM);
   }
 
   Engine& engine() { return *engine_; }

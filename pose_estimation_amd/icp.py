@@ -15,7 +15,11 @@ Two modes.  ``mode="reference"`` (the default: it is what the reference's call r
 constructor arguments live — resolution pyramid (``numLevels``), median+MAD rejection
 (``rejectionScale``), picky dedupe and point-to-plane least squares on the scene normals (SURVEY.md
 8f rank 1; numeric definition in oracle/icp_oracle.c) — and needs the scene as N x 6, which is what
-the reference hands over (opencv_surface_match.cpp:57-59).  ``mode="point_to_point"`` must be asked
+the reference hands over (opencv_surface_match.cpp:57-59).  Within it ``upstream=True`` (the default,
+MI355_ICP_FLAG_UPSTREAM) follows upstream's control flow as recalled — model normals in the stop
+rule, pre-normalisation, cvRound sampling step — and needs the MODEL as N x 6 too, as the reference's
+models are (opencv_surface_match.cpp:22); ``upstream=False`` is the form of rounds 1-3 (xyz-only
+stop rule, step 2^l, residual in cloud units).  ``mode="point_to_point"`` must be asked
 for by name: the engine BASELINE.json specifies (exact NN, Kabsch), which uses ``iterations`` and
 ``tolerence`` only.
 """
@@ -115,7 +119,8 @@ class ICP:
 
     def __init__(self, iterations: int = 250, tolerence: float = 0.05, rejectionScale: float = 2.5,
                  numLevels: int = 6, sampleType: int = 0, numMaxCorr: int = 1, device_id: int = 0,
-                 engine: Optional[IcpEngine] = None, mode: str = "reference", pruned_scan: bool = False):
+                 engine: Optional[IcpEngine] = None, mode: str = "reference", pruned_scan: bool = False,
+                 upstream: bool = True):
         if mode not in ("point_to_point", "reference"):
             raise ValueError("mode must be 'point_to_point' or 'reference'")
         self.mode = mode
@@ -130,6 +135,8 @@ class ICP:
         self.pruned_scan = bool(pruned_scan)
         if self.pruned_scan:
             self.params.flags |= _lib.FLAG_PRUNED_SCAN
+        # reference mode: follow upstream where the round 1-3 form left its control flow (needs the model as N x 6)
+        self.upstream = bool(upstream)
         self._engine = engine
         self._device_id = device_id
 
@@ -155,7 +162,8 @@ class ICP:
         if self.mode == "reference":
             res = self.engine.align_reference(init, self.iterations, self.tolerence, self.rejectionScale, self.numLevels,
                                               source_ids=[source_id] * len(plist), target_ids=[target_id] * len(plist),
-                                              flags=_lib.FLAG_PRUNED_SCAN if self.pruned_scan else 0)
+                                              flags=(_lib.FLAG_PRUNED_SCAN if self.pruned_scan else 0) |
+                                                    (_lib.FLAG_UPSTREAM if self.upstream else 0))
         else:
             res = self.engine.align(init, self.params, source_ids=[source_id] * len(plist),
                                     target_ids=[target_id] * len(plist))

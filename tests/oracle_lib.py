@@ -262,6 +262,94 @@ def icp_reference(src_xyz, tgt6, init_pose, iterations=250, tolerance=0.005, rej
     return {"status": st, "pose": out.reshape(4, 4), "residual": res.value, "passes": passes.value}
 
 
+# ---- reference mode, upstream-faithful variant (oracle/icp_oracle.c: "UPSTREAM-FAITHFUL variant") ----
+NREFX = 30
+lib.oracle_upstream_step.restype = C.c_uint32
+lib.oracle_upstream_step.argtypes = [C.c_size_t, C.c_int]
+lib.oracle_upstream_max_iterations.restype = C.c_int
+lib.oracle_upstream_max_iterations.argtypes = [C.c_int, C.c_int]
+lib.oracle_from_centred.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+lib.oracle_upstream_normalisation.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                              C.c_void_p, C.POINTER(C.c_double)]
+lib.oracle_ref_pass_ex.restype = C.c_size_t
+lib.oracle_ref_pass_ex.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_float,
+                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+lib.oracle_icp_reference_upstream.restype = C.c_int
+lib.oracle_icp_reference_upstream.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(OracleRefParams),
+                                              C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p,
+                                              C.POINTER(C.c_double), C.c_void_p]
+
+
+def _f32x6(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] == 6
+    return a
+
+
+def upstream_step(n_model: int, level: int) -> int:
+    """Sampling step of pyramid level `level` for a model of n_model rows (0: the level has no samples)."""
+    return int(lib.oracle_upstream_step(n_model, level))
+
+
+def upstream_max_iterations(iterations: int, level: int) -> int:
+    return int(lib.oracle_upstream_max_iterations(iterations, level))
+
+
+def from_centred(Xc, centre, T0) -> np.ndarray:
+    Xc = np.ascontiguousarray(Xc, dtype=np.float64).reshape(16)
+    T0 = np.ascontiguousarray(T0, dtype=np.float64).reshape(16)
+    c = np.ascontiguousarray(centre, dtype=np.float32)
+    out = np.empty(16)
+    lib.oracle_from_centred(Xc.ctypes.data, c.ctypes.data, T0.ctypes.data, out.ctypes.data)
+    return out.reshape(4, 4)
+
+
+def upstream_normalisation(src6, tgt6, init_pose):
+    """(centre float32[3], scale) of upstream's pre-normalisation for the model under init_pose."""
+    src6, tgt6 = _f32x6(src6), _f32x6(tgt6)
+    init = np.ascontiguousarray(init_pose, dtype=np.float64).reshape(16)
+    c = np.empty(3, dtype=np.float32)
+    s = C.c_double()
+    lib.oracle_upstream_normalisation(src6.ctypes.data, src6.shape[0], 6, tgt6.ctypes.data, tgt6.shape[0], 6, init.ctypes.data,
+                                      c.ctypes.data, C.byref(s))
+    return c, s.value
+
+
+def ref_pass_ex(src, tgt6, pose_start, pose_cur, rejection_scale, centre=None, nthreads=1):
+    """One pass on level clouds, either variant: (n_selected, sums[30], idx, d2, selected mask, threshold).
+    centre=None: the round 1-3 form (src may be N x 3 or N x 6; sums[29] = 0); centre given: upstream-faithful (src N x 6)."""
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    assert src.ndim == 2 and src.shape[1] in (3, 6) and (centre is None or src.shape[1] == 6)
+    tgt6 = _f32x6(tgt6)
+    ps = np.ascontiguousarray(pose_start, dtype=np.float64).reshape(16)
+    pc = np.ascontiguousarray(pose_cur, dtype=np.float64).reshape(16)
+    c = None if centre is None else np.ascontiguousarray(centre, dtype=np.float32)
+    sums = np.empty(NREFX)
+    idx = np.empty(src.shape[0], dtype=np.int32)
+    d2 = np.empty(src.shape[0], dtype=np.float32)
+    sel = np.empty(src.shape[0], dtype=np.uint8)
+    thr = C.c_float()
+    n = lib.oracle_ref_pass_ex(src.ctypes.data, src.shape[0], src.shape[1], tgt6.ctypes.data, tgt6.shape[0], ps.ctypes.data,
+                               pc.ctypes.data, float(rejection_scale), None if c is None else c.ctypes.data, nthreads,
+                               sums.ctypes.data, idx.ctypes.data, d2.ctypes.data, sel.ctypes.data, C.byref(thr))
+    return int(n), sums, idx, d2, sel.astype(bool), thr.value
+
+
+def icp_reference_upstream(src6, tgt6, init_pose, iterations=250, tolerance=0.005, rejection_scale=2.5, num_levels=8, nthreads=1):
+    src6, tgt6 = _f32x6(src6), _f32x6(tgt6)
+    init = np.ascontiguousarray(init_pose, dtype=np.float64).reshape(16)
+    rp = OracleRefParams(iterations, tolerance, rejection_scale, num_levels)
+    out = np.empty(16)
+    res, passes, scale = C.c_double(), C.c_int(), C.c_double()
+    centre = np.empty(3, dtype=np.float32)
+    per_level = np.zeros(num_levels, dtype=np.int32)
+    st = lib.oracle_icp_reference_upstream(src6.ctypes.data, src6.shape[0], tgt6.ctypes.data, tgt6.shape[0], init.ctypes.data,
+                                           C.byref(rp), nthreads, out.ctypes.data, C.byref(res), C.byref(passes),
+                                           centre.ctypes.data, C.byref(scale), per_level.ctypes.data)
+    return {"status": st, "pose": out.reshape(4, 4), "residual": res.value, "passes": passes.value, "centre": centre,
+            "scale": scale.value, "level_passes": per_level}
+
+
 # ---- scene preparation filters (reference pose_estimation.cpp:248, :310-333, :347-372) ----
 class OracleSceneFilter(C.Structure):
     _fields_ = [("kind", C.c_int32), ("p", C.c_float * 5)]

@@ -38,8 +38,10 @@ def test_adapter_refines_candidates_like_the_engine_and_the_oracle(engine):
         inits.append(P)
     engine.set_targets([scene])
     engine.set_sources([model])
-    res = engine.align_reference(np.stack(inits), 250, 0.005, 2.5, 8, source_ids=[0] * 3, target_ids=[0] * 3)
+    # the adapter's default is the upstream-faithful form of reference mode (MI355_ICP_FLAG_UPSTREAM)
+    res = engine.align_reference(np.stack(inits), 250, 0.005, 2.5, 8, source_ids=[0] * 3, target_ids=[0] * 3, flags=pa._lib.FLAG_UPSTREAM)
     for k in range(3):
         assert np.array_equal(poses[k], res.poses[k]) and residual[k] == res.residual[k], k       # the same library underneath: same bits
-        o = ora.icp_reference(model, scene, inits[k], 250, 0.005, 2.5, 8, nthreads=ora.max_threads())
+        o = ora.icp_reference_upstream(model, scene, inits[k], 250, 0.005, 2.5, 8, nthreads=ora.max_threads())
         assert np.linalg.norm(poses[k] - o["pose"]) <= 1e-5 and o["passes"] == res.passes[k]
+        assert abs(residual[k] - o["residual"]) <= 1e-9 * max(1.0, o["residual"])

@@ -73,7 +73,7 @@ def test_align_reference_matches_oracle_with_the_reference_parameters(engine):
     assert abs(res.residual[0] - o["residual"]) <= 1e-9
     assert np.linalg.norm(res.poses[0] - gt) < 2e-3
     # the Python mirror of cv::ppf_match_3d::ICP in reference mode drives the same path
-    icp = pa.ICP(250, 0.005, 2.5, 8, engine=engine, mode="reference")
+    icp = pa.ICP(250, 0.005, 2.5, 8, engine=engine, mode="reference", upstream=False)  # the round 1-3 form (N x 3 model)
     p = pa.Pose3D()
     icp.registerModelToScene(src, tgt, [p])
     assert np.array_equal(p.pose, res.poses[0]) and p.residual == res.residual[0]
@@ -165,7 +165,7 @@ def test_cpp_harness_reference_mode_matches_python_engine(engine):
     import pose_estimation_amd as pa
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "build", "estimate_pose_harness")
-    out = subprocess.run([exe, "2500", "3000", "4", "reference"], capture_output=True, text=True, timeout=120)
+    out = subprocess.run([exe, "2500", "3000", "4", "reference", "legacy"], capture_output=True, text=True, timeout=120)  # the round 1-3 form
     assert out.returncode == 0, out.stderr
     poses = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]).reshape(4, 4)
              for l in out.stdout.splitlines() if l.startswith("pose ")}
@@ -204,7 +204,7 @@ def test_sharded_code_path_with_one_rank_is_bit_identical(engine):
         engine.comm_detach()
     assert np.array_equal(got.passes, ref.passes) and np.array_equal(got.poses, ref.poses) and np.array_equal(got.residual, ref.residual)
     assert sizes[0] == 8                               # the slab sizes: (cloud count, n) as uint32
-    assert 2 * 2048 * 4 in sizes and 2 * 30 * 8 in sizes    # two jobs: histograms, and 29 sums + the flag each
+    assert 2 * 2048 * 4 in sizes and 2 * 31 * 8 in sizes    # two jobs: histograms, and a row of 30 sums + the flag each
     again = engine.align_reference(init, 120, 0.005, 2.5, 7, source_ids=[0, 0], target_ids=[0, 0])   # and back to unsharded
     assert np.array_equal(again.poses, ref.poses)
 
