@@ -25,7 +25,10 @@ def random_cloud6(rng, n, kind):
     return np.ascontiguousarray(np.hstack([p, nrm.astype(np.float32)]))
 
 
-def test_randomised_reference_mode_against_the_oracle(engine):
+@pytest.mark.parametrize("upstream", [False, True], ids=["round1to3_form", "upstream_form"])
+def test_randomised_reference_mode_against_the_oracle(engine, upstream):
+    """upstream: MI355_ICP_FLAG_UPSTREAM against oracle_icp_reference_upstream - the models carry normals, the sizes below
+    16,385 points sample with steps that are not powers of two, mixed batches run their levels in groups by step."""
     rng = np.random.default_rng(20261004)
     worst = 0.0
     for case in range(CASES):
@@ -40,6 +43,8 @@ def test_randomised_reference_mode_against_the_oracle(engine):
             pick = rng.integers(0, nt, ns)
             base = tgt[pick, :3].astype(np.float64) + rng.standard_normal((ns, 3)) * 1e-3
             src = ((base - T[:3, 3]) @ T[:3, :3]).astype(np.float32)  # T maps src onto the scene, up to the noise
+            if upstream:  # N x 6 model: the scene normals of the picked points, taken back to the model frame
+                src = np.hstack([src, (tgt[pick, 3:].astype(np.float64) @ T[:3, :3]).astype(np.float32)])
             tgts.append(tgt)
             srcs.append(np.ascontiguousarray(src))
             gts.append(T)
@@ -52,9 +57,9 @@ def test_randomised_reference_mode_against_the_oracle(engine):
         tol = float(rng.choice([0.005, 0.05, 1e-6]))
         scale = float(rng.choice([2.5, 0.0, 1.0]))
         levels = int(rng.integers(1, 11))
-        res = engine.align_reference(inits, iters, tol, scale, levels, source_ids=ids, target_ids=ids)
+        res = engine.align_reference(inits, iters, tol, scale, levels, source_ids=ids, target_ids=ids, flags=4 if upstream else 0)
         for k, i in enumerate(ids):
-            o = ora.icp_reference(srcs[i], tgts[i], inits[k], iters, tol, scale, levels, nthreads=4)
+            o = (ora.icp_reference_upstream if upstream else ora.icp_reference)(srcs[i], tgts[i], inits[k], iters, tol, scale, levels, nthreads=4)
             tag = f"case {case} job {k}: clouds {srcs[i].shape[0]} x {tgts[i].shape[0]}, kind {kind}, ({iters}, {tol}, {scale}, {levels})"
             assert res.status[k] == 0, tag
             assert res.passes[k] == o["passes"], f"{tag}: passes {res.passes[k]} vs oracle {o['passes']}"
@@ -62,7 +67,7 @@ def test_randomised_reference_mode_against_the_oracle(engine):
             worst = max(worst, err)
             assert err <= 1e-6 * max(1.0, float(np.abs(o["pose"]).max())), f"{tag}: pose differs by {err}"
             assert abs(res.residual[k] - o["residual"]) <= 1e-9 * max(1.0, abs(o["residual"])), tag
-    print(f"{CASES} random reference-mode cases, worst pose difference to the oracle {worst:.2e}")
+    print(f"{CASES} random reference-mode cases ({'upstream' if upstream else 'round 1-3'} form), worst pose difference to the oracle {worst:.2e}")
 
 
 def test_randomised_point_to_point_loop_against_the_oracle(engine):

@@ -24,29 +24,36 @@ def main():
     ap.add_argument("--scene", type=int, default=100_000)
     ap.add_argument("--candidates", type=int, default=6)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--legacy", action="store_true", help="the round 1-3 form of reference mode (flags = 0) instead of MI355_ICP_FLAG_UPSTREAM")
+    ap.add_argument("--shift", type=float, nargs=3, default=(0.0, 0.0, 0.0), help="move the scene (and the candidates) away from the camera origin")
     a = ap.parse_args()
+    flags = 0 if a.legacy else pa._lib.FLAG_UPSTREAM
     T = st.perturbation(-1)
     tgt = pa.synth_cloud(st.TARGET_SEED, a.scene, normals=True)
-    src = pa.synth_cloud(st.SOURCE_SEED, a.model, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T)
-    gt = np.linalg.inv(T)
-    cands = [np.eye(4)] + [st.rigid_transform(k, (0.2, 1, -0.4), (0.01, -0.02, 0.015)) @ gt for k in (1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0)]
+    src = pa.synth_cloud(st.SOURCE_SEED, a.model, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T, normals=True)  # N x 6, as the reference's models
+    S = np.eye(4)
+    S[:3, 3] = a.shift
+    tgt[:, :3] += np.asarray(a.shift, dtype=np.float32)
+    gt = S @ np.linalg.inv(T)
+    cands = [S] + [st.rigid_transform(k, (0.2, 1, -0.4), (0.01, -0.02, 0.015)) @ gt for k in (1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0)]
     inits = np.stack(cands[:a.candidates])
     with pa.IcpEngine(0) as eng:
         eng.set_targets([tgt])
         eng.set_sources([src])
         for _ in range(3):
-            res = eng.align_reference(inits, 250, 0.005, 2.5, 8)
+            res = eng.align_reference(inits, 250, 0.005, 2.5, 8, flags=flags)
         times = []
         for _ in range(a.reps):
             t0 = time.perf_counter()
-            res = eng.align_reference(inits, 250, 0.005, 2.5, 8)
+            res = eng.align_reference(inits, 250, 0.005, 2.5, 8, flags=flags)
             times.append(time.perf_counter() - t0)
         eng.set_profiling(True)
         eng.reset_profile()
-        eng.align_reference(inits, 250, 0.005, 2.5, 8)
+        eng.align_reference(inits, 250, 0.005, 2.5, 8, flags=flags)
         prof = eng.profile()
     gpu = prof.nn_scan_ms + prof.resolve_ms
     print(json.dumps({"workload": f"{a.candidates} candidates, {a.model} model vs {a.scene} scene, ICP(250, 0.005, 2.5, 8)",
+                      "form": "round 1-3 (flags 0)" if a.legacy else "upstream-faithful (MI355_ICP_FLAG_UPSTREAM)",
                       "wall_ms_median": 1e3 * statistics.median(times), "wall_ms_min": 1e3 * min(times), "reps": a.reps,
                       "passes": res.passes.tolist(), "passes_max": int(res.passes.max()),
                       "profiled_scan_ms_total": prof.nn_scan_ms, "profiled_other_kernels_ms_total": prof.resolve_ms,
