@@ -119,6 +119,26 @@ unsigned mi355_icp_abi_version(void); /* [host] */
 int mi355_icp_create(int device_id, mi355_icp_ctx** out);
 void mi355_icp_destroy(mi355_icp_ctx* ctx);
 
+/* ONE handle over `n_devices` devices of THIS process (SURVEY.md 8b "Lifetime" / "Threading": the reference holds its backend
+ * by value in one node process - pose_estimation.hpp:160-162, one component container: launch/pose_estimation.launch.py:17-35 -
+ * so multi-GPU must not need a launcher or a rank per process).  The library keeps one engine, one stream and one host thread
+ * per entry of device_ids (an id may repeat: two engines on one device, which is how the one-GPU test boxes run it); every
+ * call below works on the handle unchanged and is fanned out internally:
+ *   - clouds: the scene (targets) is replicated on every device; the models (sources) are kept on the host as uploaded and
+ *     laid out per call;
+ *   - mi355_icp_align / _align_reference / _correspond with AT LEAST as many jobs as devices (batched bin-picking: BASELINE
+ *     config[3]; a request's candidates on two GPUs): whole jobs per device, no exchange, every job's result is the
+ *     single-device engine's bit for bit;
+ *   - with FEWER jobs than devices (BASELINE config[4], one 8M-point model): every device takes a slab of each source cloud
+ *     (mi355_icp_slab_range) and the per-pass rows of MI355_ICP_NSUMS (MI355_ICP_NREFSUMS_EX) doubles are exchanged through
+ *     pinned host memory and added in device order - no RCCL, no torch; the arithmetic of a slab-sharded run of the same
+ *     rank count (mi355_icp_comm_attach*), bit for bit;
+ *   - scene preparation (mi355_icp_scene_*) runs on every device (each needs the whole scene; the kernels are deterministic);
+ *     host outputs come from device slot 0, as do mi355_icp_get_profile and mi355_icp_device_info;
+ *   - mi355_icp_comm_attach* are refused (the handle shards by itself); mi355_icp_comm_info reports kind 3, n_devices ranks.
+ * Calls on one handle must still come from one thread at a time (the reference's executor is single-threaded). */
+int mi355_icp_create_multi(const int* device_ids, int n_devices, mi355_icp_ctx** out);
+
 /* Last error text of this context (never NULL; "" if none).  With ctx == NULL
  * returns the text of the last failed mi355_icp_create on this thread. */
 const char* mi355_icp_last_error(const mi355_icp_ctx* ctx); /* [host] */
@@ -434,7 +454,8 @@ int mi355_icp_comm_attach_external(mi355_icp_ctx* ctx, int rank, int n_ranks, mi
 int mi355_icp_comm_detach(mi355_icp_ctx* ctx);
 
 /* What is attached: *kind = 0 none, 1 RCCL (rank and size as the communicator itself reports them:
- * ncclCommUserRank / ncclCommCount), 2 external.  Any output may be NULL. */
+ * ncclCommUserRank / ncclCommCount), 2 external, 3 a multi-device handle (mi355_icp_create_multi: n_ranks = its devices).
+ * Any output may be NULL. */
 int mi355_icp_comm_info(const mi355_icp_ctx* ctx, int* rank, int* n_ranks, int* kind);
 
 /* ---- measurement ---------------------------------------------------------- */

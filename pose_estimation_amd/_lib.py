@@ -111,6 +111,7 @@ _ctx = C.c_void_p
 SIGNATURES = {
     "mi355_icp_abi_version": (C.c_uint, []),
     "mi355_icp_create": (C.c_int, [C.c_int, _P(_ctx)]),
+    "mi355_icp_create_multi": (C.c_int, [_P(C.c_int), C.c_int, _P(_ctx)]),
     "mi355_icp_destroy": (None, [_ctx]),
     "mi355_icp_last_error": (C.c_char_p, [_ctx]),
     "mi355_icp_default_params": (None, [_P(Params)]),

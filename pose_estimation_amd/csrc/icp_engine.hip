@@ -177,6 +177,7 @@ using namespace mi355;
 constexpr size_t kReadyWords = 1024;  // jobs of one pass that can publish for themselves (PassTail::ready); more take the copy path
 
 struct mi355_icp_ctx {
+  mi355::MultiState* multi = nullptr;  // mi355_icp_create_multi: this handle only fans calls out to its per-device contexts (multi.cpp)
   BufferPool pool;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -1656,7 +1657,31 @@ int normalisation_finish(mi355_icp_ctx* c, int n_jobs, Normalisation& N) {
 
 extern "C" {
 
-const char* mi355_icp_last_error(const mi355_icp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char* mi355_icp_last_error(const mi355_icp_ctx* ctx) {
+  if (ctx && ctx->multi && ctx->err.empty()) return multi_last_error(ctx->multi);
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int mi355_icp_create_multi(const int* device_ids, int n_devices, mi355_icp_ctx** out) {
+  if (!out) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!device_ids || n_devices < 1 || n_devices > 64) {
+    g_create_error = "create_multi: 1 <= n_devices <= 64 device ids required";
+    return MI355_ICP_ERR_INVALID_ARGUMENT;
+  }
+  mi355_icp_ctx* c = new (std::nothrow) mi355_icp_ctx();
+  if (!c) return MI355_ICP_ERR_INTERNAL;
+  c->device = device_ids[0];
+  std::string why;
+  const int st = multi_create(device_ids, n_devices, &c->multi, &why);
+  if (st != MI355_ICP_OK) {
+    g_create_error = "create_multi: " + why;
+    delete c;
+    return st;
+  }
+  *out = c;
+  return MI355_ICP_OK;
+}
 
 int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   if (!out) return MI355_ICP_ERR_INVALID_ARGUMENT;
@@ -1749,6 +1774,11 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
 
 void mi355_icp_destroy(mi355_icp_ctx* c) {
   if (!c) return;
+  if (c->multi) {  // a multi-device handle owns nothing but its per-device contexts
+    multi_destroy(c->multi);
+    delete c;
+    return;
+  }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   comm_release(c->comm);
@@ -1825,12 +1855,14 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
 int mi355_icp_set_targets(mi355_icp_ctx* ctx, int n_clouds, const float* const* xyz, const size_t* n_points, size_t stride_bytes) {
   if (!ctx) return MI355_ICP_ERR_INVALID_ARGUMENT;
   ctx->err.clear();
+  if (ctx->multi) return multi_set_targets(ctx->multi, n_clouds, xyz, n_points, stride_bytes);
   return upload_clouds(ctx, ctx->targets, n_clouds, xyz, n_points, stride_bytes, kTile, kTargetPad, false, "set_targets");
 }
 
 int mi355_icp_set_sources(mi355_icp_ctx* ctx, int n_clouds, const float* const* xyz, const size_t* n_points, size_t stride_bytes) {
   if (!ctx) return MI355_ICP_ERR_INVALID_ARGUMENT;
   ctx->err.clear();
+  if (ctx->multi) return multi_set_sources(ctx->multi, n_clouds, xyz, n_points, stride_bytes);
   return upload_clouds(ctx, ctx->sources, n_clouds, xyz, n_points, stride_bytes, kSrcPad, 0.0f, true, "set_sources");
 }
 
@@ -1839,6 +1871,7 @@ int mi355_icp_align(mi355_icp_ctx* c, int n_jobs, const int* source_ids, const i
                     int* out_status, int* out_converged) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   c->err.clear();
+  if (c->multi) return multi_align(c->multi, n_jobs, source_ids, target_ids, init_poses, params, out_poses, out_residual, out_iterations, out_status, out_converged);
   if (n_jobs < 1 || !init_poses || !params) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align: bad arguments");
   if (params->max_iterations < 1) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align: max_iterations must be >= 1");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1901,6 +1934,7 @@ int mi355_icp_correspond(mi355_icp_ctx* c, int n_jobs, const int* source_ids, co
                          float max_correspondence_distance, int32_t* out_index, float* out_dist2, double* out_sums) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   c->err.clear();
+  if (c->multi) return multi_correspond(c->multi, n_jobs, source_ids, target_ids, poses, max_correspondence_distance, out_index, out_dist2, out_sums);
   c->call_pruned = false;
   if (n_jobs < 1 || !poses) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "correspond: bad arguments");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1935,6 +1969,11 @@ int mi355_icp_debug_filter_bounds(mi355_icp_ctx* c, int source_id, int target_id
                                   int32_t* out_run_targets, size_t* inout_n_runs) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   c->err.clear();
+  if (c->multi) {
+    mi355_icp_ctx* one = nullptr;
+    const int mst = multi_single_context(c->multi, &one);
+    return mst != MI355_ICP_OK ? mst : mi355_icp_debug_filter_bounds(one, source_id, target_id, pose, out_lower, out_run_targets, inout_n_runs);
+  }
   c->call_pruned = false;
   if (!pose || !inout_n_runs) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "debug_filter_bounds: bad arguments");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1993,6 +2032,11 @@ int mi355_icp_debug_filter_bounds(mi355_icp_ctx* c, int source_id, int target_id
 int mi355_icp_upstream_normalisation(mi355_icp_ctx* c, int source_id, int target_id, const double* pose, float* out_centre, double* out_scale) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   c->err.clear();
+  if (c->multi) {
+    mi355_icp_ctx* one = nullptr;
+    const int mst = multi_single_context(c->multi, &one);
+    return mst != MI355_ICP_OK ? mst : mi355_icp_upstream_normalisation(one, source_id, target_id, pose, out_centre, out_scale);
+  }
   if (!pose) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "upstream_normalisation: bad arguments");
   HIP_TRY(c, hipSetDevice(c->device));
   if (c->targets.clouds.empty() || c->sources.clouds.empty()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "upstream_normalisation: upload clouds first");
@@ -2012,6 +2056,7 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
                               double* out_residual, int* out_passes, int* out_status) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   c->err.clear();
+  if (c->multi) return multi_align_reference(c->multi, n_jobs, source_ids, target_ids, init_poses, rp, out_poses, out_residual, out_passes, out_status);
   if (n_jobs < 1 || !init_poses || !rp) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: bad arguments");
   if (rp->iterations < 1 || rp->num_levels < 1 || rp->num_levels > 24) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "align_reference: iterations >= 1 and 1 <= num_levels <= 24 required");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -2247,6 +2292,12 @@ int mi355_icp_reference_pass_ex(mi355_icp_ctx* c, int source_id, int target_id, 
                                 float* out_dist2, uint8_t* out_selected, float* out_threshold, double* out_sums) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   c->err.clear();
+  if (c->multi) {
+    mi355_icp_ctx* one = nullptr;
+    const int mst = multi_single_context(c->multi, &one);
+    return mst != MI355_ICP_OK ? mst : mi355_icp_reference_pass_ex(one, source_id, target_id, step, pose_start, pose_cur, rejection_scale, centre, out_index,
+                                                                   out_dist2, out_selected, out_threshold, out_sums);
+  }
   c->call_pruned = false;
   if (!pose_start || !pose_cur || step < 1) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: bad arguments");
   if (c->comm.attached()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: a single-context diagnostic; detach the communicator (mi355_icp_align_reference is the slab-sharded entry point)");
@@ -2326,6 +2377,9 @@ int mi355_icp_solve_point_to_plane(const double* sums29, double out_x[6]) {
 int mi355_icp_scene_load(mi355_icp_ctx* c, const float* xyz, size_t n_points, size_t stride_bytes) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   c->err.clear();
+  // a multi-device handle prepares the scene on every device (each needs the whole target; the kernels are deterministic, so
+  // every device ends up with the same scene) and reports device slot 0's outputs
+  if (c->multi) return multi_broadcast(c->multi, [&](mi355_icp_ctx* s, int) { return mi355_icp_scene_load(s, xyz, n_points, stride_bytes); });
   if ((n_points && !xyz) || stride_bytes < 12 || stride_bytes % 4 != 0) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_load: bad arguments");
   if (n_points > 0xFFFF0000ull) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_load: too many points");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -2368,6 +2422,7 @@ int mi355_icp_scene_load(mi355_icp_ctx* c, const float* xyz, size_t n_points, si
 int mi355_icp_scene_filter(mi355_icp_ctx* c, int n_filters, const mi355_scene_filter* filters, size_t* out_n_points) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   c->err.clear();
+  if (c->multi) return multi_broadcast(c->multi, [&](mi355_icp_ctx* s, int slot) { return mi355_icp_scene_filter(s, n_filters, filters, slot == 0 ? out_n_points : nullptr); });
   if (!c->scene_loaded) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_filter: no scene loaded (mi355_icp_scene_load)");
   if (n_filters < 0 || n_filters > MI355_SCENE_MAX_FILTERS || (n_filters && !filters)) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_filter: bad filter list");
   SceneFilterSet F{};
@@ -2412,6 +2467,7 @@ int mi355_icp_scene_filter(mi355_icp_ctx* c, int n_filters, const mi355_scene_fi
 int mi355_icp_scene_download(mi355_icp_ctx* c, float* out_xyz, size_t capacity_points, size_t* out_n_points) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   c->err.clear();
+  if (c->multi) return mi355_icp_scene_download(multi_sub(c->multi, 0), out_xyz, capacity_points, out_n_points);
   if (!c->scene_loaded) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_download: no scene loaded");
   if (out_n_points) *out_n_points = c->scene_n;
   if (!out_xyz) return MI355_ICP_OK;
@@ -2425,6 +2481,10 @@ int mi355_icp_scene_normals(mi355_icp_ctx* c, int k, int flip_viewpoint, const f
                             int32_t* out_neighbors) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   c->err.clear();
+  if (c->multi)
+    return multi_broadcast(c->multi, [&](mi355_icp_ctx* s, int slot) {
+      return mi355_icp_scene_normals(s, k, flip_viewpoint, viewpoint, slot == 0 ? out_normals : nullptr, slot == 0 ? out_neighbors : nullptr);
+    });
   if (!c->scene_loaded || c->scene_n == 0) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_normals: the scene is empty");
   if (k < 1 || k > kMaxNormalNeighbors) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_normals: 1 <= k <= 32 required");
   if (flip_viewpoint && !viewpoint) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_normals: viewpoint missing");
@@ -2512,6 +2572,13 @@ int mi355_icp_scene_fit_plane(mi355_icp_ctx* c, const mi355_plane_fit_params* fp
                               int* out_iterations) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   c->err.clear();
+  if (c->multi) {  // the fit is deterministic: every device finds the same plane; slot 0's is reported
+    if (!fp || !out_coefficients) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_fit_plane: bad arguments");
+    return multi_broadcast(c->multi, [&](mi355_icp_ctx* s, int slot) {
+      float scratch[4];
+      return mi355_icp_scene_fit_plane(s, fp, slot == 0 ? out_coefficients : scratch, slot == 0 ? out_inliers : nullptr, slot == 0 ? out_iterations : nullptr);
+    });
+  }
   if (!fp || !out_coefficients) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_fit_plane: bad arguments");
   if (!c->scene_loaded || c->scene_n < 3) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_fit_plane: the scene has fewer than 3 points");
   if (fp->max_iterations < 1 || fp->max_iterations > kPlaneMaxHypotheses || !(fp->distance_threshold >= 0.0f) ||
@@ -2576,6 +2643,7 @@ int mi355_icp_scene_fit_plane(mi355_icp_ctx* c, const mi355_plane_fit_params* fp
 int mi355_icp_scene_commit_target(mi355_icp_ctx* c) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
   c->err.clear();
+  if (c->multi) return multi_broadcast(c->multi, [&](mi355_icp_ctx* s, int) { return mi355_icp_scene_commit_target(s); });
   if (!c->scene_loaded || c->scene_n == 0) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_commit_target: the scene is empty");
   HIP_TRY(c, hipSetDevice(c->device));
   CloudSet& set = c->targets;
@@ -2639,6 +2707,7 @@ int mi355_icp_comm_unique_id(unsigned char out_id[MI355_ICP_UNIQUE_ID_BYTES]) {
 
 int mi355_icp_comm_attach(mi355_icp_ctx* c, const unsigned char id[MI355_ICP_UNIQUE_ID_BYTES], int rank, int n_ranks) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  if (c->multi) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "comm_attach: a multi-device handle shards inside the process (mi355_icp_create_multi); attach a communicator to a single-device context");
   if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "comm_attach: bad rank / size");
   if (c->comm.attached()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "comm_attach: a communicator is already attached");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -2653,6 +2722,7 @@ int mi355_icp_comm_attach(mi355_icp_ctx* c, const unsigned char id[MI355_ICP_UNI
 
 int mi355_icp_comm_attach_external(mi355_icp_ctx* c, int rank, int n_ranks, mi355_icp_allgather_fn allgather, void* user) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  if (c->multi) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "comm_attach_external: a multi-device handle shards inside the process (mi355_icp_create_multi)");
   if (!allgather || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "comm_attach_external: bad rank / size / callback");
   if (c->comm.attached()) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "comm_attach_external: a communicator is already attached");
   c->comm.ext = allgather;
@@ -2664,6 +2734,7 @@ int mi355_icp_comm_attach_external(mi355_icp_ctx* c, int rank, int n_ranks, mi35
 
 int mi355_icp_comm_detach(mi355_icp_ctx* c) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  if (c->multi) return MI355_ICP_OK;  // nothing of the caller's is attached
   if (c->comm.attached()) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -2674,6 +2745,12 @@ int mi355_icp_comm_detach(mi355_icp_ctx* c) {
 
 int mi355_icp_comm_info(const mi355_icp_ctx* c, int* rank, int* n_ranks, int* kind) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  if (c->multi) {  // kind 3: the devices of one handle, sharded inside the process
+    if (rank) *rank = 0;
+    if (n_ranks) *n_ranks = multi_devices(c->multi);
+    if (kind) *kind = 3;
+    return MI355_ICP_OK;
+  }
   int r = c->comm.rank, n = c->comm.size;
   if (c->comm.rccl) {  // what the communicator itself reports, not what the caller claimed at attach
     const char* why = nullptr;
@@ -2687,24 +2764,28 @@ int mi355_icp_comm_info(const mi355_icp_ctx* c, int* rank, int* n_ranks, int* ki
 
 int mi355_icp_set_profiling(mi355_icp_ctx* c, int enabled) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  if (c->multi) return multi_broadcast(c->multi, [&](mi355_icp_ctx* s, int) { return mi355_icp_set_profiling(s, enabled); });
   c->profile_always = enabled != 0;
   return MI355_ICP_OK;
 }
 
 int mi355_icp_get_profile(const mi355_icp_ctx* c, mi355_icp_profile* out) {
   if (!c || !out) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  if (c->multi) return mi355_icp_get_profile(multi_sub(c->multi, 0), out);  // device slot 0's kernels
   *out = c->prof;
   return MI355_ICP_OK;
 }
 
 int mi355_icp_reset_profile(mi355_icp_ctx* c) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  if (c->multi) return multi_broadcast(c->multi, [&](mi355_icp_ctx* s, int) { return mi355_icp_reset_profile(s); });
   c->prof = mi355_icp_profile{};
   return MI355_ICP_OK;
 }
 
 int mi355_icp_device_info(const mi355_icp_ctx* c, char* name, size_t name_len, int* compute_units, size_t* total_mem) {
   if (!c) return MI355_ICP_ERR_INVALID_ARGUMENT;
+  if (c->multi) return mi355_icp_device_info(multi_sub(c->multi, 0), name, name_len, compute_units, total_mem);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return MI355_ICP_ERR_HIP;
   if (name && name_len) {

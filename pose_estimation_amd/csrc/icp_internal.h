@@ -3,6 +3,8 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
+#include <string>
 
 #include "../../include/mi355_icp.h"
 
@@ -536,5 +538,23 @@ void comm_release(CommState& cs);  // frees the staging buffers and destroys a n
 int stage_jobs(void* stream, const JobDesc* jobs_host, const RefJobDesc* rjobs_host, int n, JobDesc* jobs_dev, RefJobDesc* rjobs_dev);
 // the same descriptors as one StageArgs value, for a launch that stages them itself (launch_nn_scan); false: more than 8 jobs
 bool fill_stage_args(const JobDesc* jobs_host, const RefJobDesc* rjobs_host, int n, StageArgs* out);
+
+// ---- one handle over several devices of one process (multi.cpp; mi355_icp_create_multi) ----
+struct MultiState;
+int multi_create(const int* device_ids, int n_devices, MultiState** out, std::string* err);
+void multi_destroy(MultiState* ms);
+const char* multi_last_error(const MultiState* ms);
+int multi_devices(const MultiState* ms);
+mi355_icp_ctx* multi_sub(MultiState* ms, int slot);
+int multi_broadcast(MultiState* ms, const std::function<int(mi355_icp_ctx*, int)>& f);  // f(sub-context, slot) on every device at once
+int multi_set_targets(MultiState* ms, int n_clouds, const float* const* xyz, const size_t* n_points, size_t stride_bytes);
+int multi_set_sources(MultiState* ms, int n_clouds, const float* const* xyz, const size_t* n_points, size_t stride_bytes);
+int multi_align(MultiState* ms, int n_jobs, const int* source_ids, const int* target_ids, const double* init_poses, const mi355_icp_params* params,
+                double* out_poses, double* out_residual, int* out_iterations, int* out_status, int* out_converged);
+int multi_align_reference(MultiState* ms, int n_jobs, const int* source_ids, const int* target_ids, const double* init_poses,
+                          const mi355_icp_reference_params* rp, double* out_poses, double* out_residual, int* out_passes, int* out_status);
+int multi_correspond(MultiState* ms, int n_jobs, const int* source_ids, const int* target_ids, const double* poses, float max_corr,
+                     int32_t* out_index, float* out_dist2, double* out_sums);
+int multi_single_context(MultiState* ms, mi355_icp_ctx** out);  // device slot 0 holding the whole clouds (diagnostic entry points)
 
 }  // namespace mi355

@@ -183,15 +183,23 @@ def _cloud_ptrs(clouds: Sequence[np.ndarray]):
 
 
 class IcpEngine:
-    """One engine per GPU. Not thread-safe (the reference calls this path from one executor thread)."""
+    """One engine per GPU - or, with ``device_ids=[...]``, ONE handle over several devices of this process
+    (mi355_icp_create_multi: jobs or source slabs are spread over them inside the library).  Not thread-safe (the reference
+    calls this path from one executor thread)."""
 
-    def __init__(self, device_id: int = 0):
+    def __init__(self, device_id: int = 0, device_ids: Optional[Sequence[int]] = None):
         h = C.c_void_p()
-        st = lib.mi355_icp_create(device_id, C.byref(h))
+        if device_ids is not None:
+            ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+            st = lib.mi355_icp_create_multi(ids, len(device_ids), C.byref(h))
+            device_id = int(device_ids[0]) if len(device_ids) else 0
+        else:
+            st = lib.mi355_icp_create(device_id, C.byref(h))
         if st != _lib.OK:
             raise IcpError(st, lib.mi355_icp_last_error(None).decode())
         self._h = h
         self.device_id = device_id
+        self.device_ids = None if device_ids is None else [int(d) for d in device_ids]
         self.n_targets = 0
         self.n_sources = 0
         self._source_sizes: list[int] = []

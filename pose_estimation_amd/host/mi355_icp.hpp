@@ -46,6 +46,12 @@ class Engine {
     const int st = mi355_icp_create(device_id, &ctx_);
     if (st != MI355_ICP_OK) throw Error(st, std::string("mi355_icp_create: ") + mi355_icp_last_error(nullptr));
   }
+  // ONE handle over several devices of this process (mi355_icp_create_multi): the node keeps holding one backend by value
+  // (pose_estimation.hpp:160-162) and the library spreads jobs or source slabs over the devices itself
+  explicit Engine(const std::vector<int>& device_ids) {
+    const int st = mi355_icp_create_multi(device_ids.data(), static_cast<int>(device_ids.size()), &ctx_);
+    if (st != MI355_ICP_OK) throw Error(st, std::string("mi355_icp_create_multi: ") + mi355_icp_last_error(nullptr));
+  }
   ~Engine() { mi355_icp_destroy(ctx_); }
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
@@ -201,7 +207,12 @@ class ICP {
 
   ICP(int iterations, float tolerence = 0.05f, float rejectionScale = 2.5f, int numLevels = 6, int device_id = 0,
       Mode mode = Mode::Reference)
-      : engine_(std::make_shared<Engine>(device_id)), mode_(mode) {
+      : ICP(iterations, tolerence, rejectionScale, numLevels, std::make_shared<Engine>(device_id), mode) {}
+  // the same on several devices of this process: ICP icp(250, 0.005f, 2.5f, 8, std::vector<int>{0, 1, 2, 3});
+  ICP(int iterations, float tolerence, float rejectionScale, int numLevels, const std::vector<int>& device_ids, Mode mode = Mode::Reference)
+      : ICP(iterations, tolerence, rejectionScale, numLevels, std::make_shared<Engine>(device_ids), mode) {}
+  ICP(int iterations, float tolerence, float rejectionScale, int numLevels, std::shared_ptr<Engine> engine, Mode mode)
+      : engine_(std::move(engine)), mode_(mode) {
     const int st = mi355_icp_params_from_reference(iterations, tolerence, rejectionScale, numLevels, &params_);
     if (st != MI355_ICP_OK) throw Error(st, "mi355_icp_params_from_reference");
     ref_params_.iterations = iterations;
