@@ -2,9 +2,12 @@
 """bench.py — correspondence-pairs/s and ICP iterations/s of the MI355X alignment engine.
 
 Contract: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the driver launches it under
-torch.distributed.run, one rank per GPU; run plainly (no WORLD_SIZE in the environment) with --gpus N > 1 it spawns the
-N ranks ITSELF - fresh child processes, started before this process has touched torch or HIP - and relays rank 0's JSON
-line.  `n_gpus` in that line is what the communicator reports (ncclCommCount), and a run whose rank count differs from
+torch.distributed.run, one rank per GPU (RCCL exchange).  Run plainly (no WORLD_SIZE in the environment) with --gpus N > 1 it
+stays ONE process and drives the N devices through ONE multi-device handle (mi355_icp_create_multi: the shape the reference's
+single node process can use - pose_estimation.hpp:160-162 - with the per-pass rows exchanged through pinned host memory in
+device order, no RCCL, no torch); `--spawn-ranks` keeps the older behaviour of starting N rank processes itself - fresh
+children, started before this process has touched torch or HIP - and relaying rank 0's JSON line.  `n_gpus` in that line is
+what the communicator (ncclCommCount) or the handle (its device count) reports, and a run whose count differs from
 --gpus exits non-zero instead of printing a mislabelled line.  A *step* is one ICP iteration: source transform + exact brute-force NN scan +
 covariance accumulation + (N > 1: one RCCL exchange of 17 doubles per rank: all-gather + rank-ordered sum) + host Kabsch/convergence, all
 through `mi355_icp_align`.  Clouds are uploaded before the timed region (inputs resident in HBM).
@@ -65,11 +68,15 @@ def parse():
     ap.add_argument("--n-target", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-iters", type=int, default=20, help="ICP iterations of the CPU baseline sample (about 3 s on 16 threads)")
-    ap.add_argument("--cpu-baseline-iters-1thread", type=int, default=3, help="... of its 1-thread leg (about 5 s)")
+    ap.add_argument("--cpu-baseline-iters-1thread", type=int, default=1, help="... of its 1-thread leg (about 2 s)")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the short all-exact-scan leg (roofline_exact)")
     ap.add_argument("--exact-leg-steps", type=int, default=3)
     ap.add_argument("--no-config-legs", action="store_true", help="skip the short legs for the other BASELINE configurations (other_configs)")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--spawn-ranks", action="store_true",
+                    help="plain invocation with --gpus N > 1: start N rank processes (RCCL) instead of one multi-device handle in this process")
+    ap.add_argument("--device-ids", type=int, nargs="+", default=None,
+                    help="multi-device handle: the device of every slot (default 0 .. N-1; ids may repeat, e.g. 0 0 on a one-GPU box)")
     ap.add_argument("--collective", choices=["native", "torch"], default="native",
                     help="N > 1: the per-iteration exchange issued inside the engine over RCCL (native) or by torch.distributed")
     ap.add_argument("--force-dist", action="store_true", help="exercise the distributed code path even at N = 1")
@@ -149,27 +156,79 @@ def other_config_legs(pa, st, np, main_engine):
     p2p("config0_stand_in_1k_x_1k", 1, 1000, 1000, 50)
     p2p("config1_100k_x_100k_50_iterations", 1, 100_000, 100_000, 50)
     p2p("config3_64_objects_50k_x_50k", 64, 50_000, 50_000, 20)
-    # the reference's request: 6 candidate poses, one 20k-point model, one 100k-point scene with normals
+    # the reference's request: 6 candidate poses, one 20k-point model (N x 6, as the reference's models), one 100k-point scene
+    # with normals.  The form the host mirrors run by default - MI355_ICP_FLAG_UPSTREAM, upstream's control flow - and, beside
+    # it, the round 1-3 form on the same clouds (flags 0; what BENCH_r03 and earlier timed under this key)
     T = st.perturbation(-1)
     gt = np.linalg.inv(T)
     scene = pa.synth_cloud(st.TARGET_SEED, 100_000, normals=True)
-    model = pa.synth_cloud(st.SOURCE_SEED, 20_000, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T)
+    model = pa.synth_cloud(st.SOURCE_SEED, 20_000, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T, normals=True)
     inits = np.stack([np.eye(4)] + [st.rigid_transform(k, (0.2, 1, -0.4), (0.01, -0.02, 0.015)) @ gt for k in (1.0, 2.0, 3.0, 4.0, 5.0)])
     with pa.IcpEngine(main_engine.device_id) as e:
         e.set_targets([scene])
         e.set_sources([model])
-        for _ in range(3):
-            r = e.align_reference(inits, 250, 0.005, 2.5, 8)
-        times = []
-        for _ in range(20):
-            t0 = time.perf_counter()
-            r = e.align_reference(inits, 250, 0.005, 2.5, 8)
-            times.append(time.perf_counter() - t0)
-    times.sort()
-    legs["reference_request_6_candidates_20k_model_100k_scene"] = {
-        "call": "mi355_icp_align_reference(250, 0.005, 2.5, 8)", "ms_per_request_median": 1e3 * times[len(times) // 2],
-        "ms_per_request_min": 1e3 * times[0], "calls": len(times), "passes": [int(x) for x in r.passes],
-        "pose_error_vs_truth_max": float(max(np.linalg.norm(q - gt) for q in r.poses))}
+        for form, flags, calls in (("upstream", pa._lib.FLAG_UPSTREAM, 20), ("round1to3", 0, 10)):
+            for _ in range(3):
+                r = e.align_reference(inits, 250, 0.005, 2.5, 8, flags=flags)
+            times = []
+            for _ in range(calls):
+                t0 = time.perf_counter()
+                r = e.align_reference(inits, 250, 0.005, 2.5, 8, flags=flags)
+                times.append(time.perf_counter() - t0)
+            times.sort()
+            leg = {"call": f"mi355_icp_align_reference(250, 0.005, 2.5, 8, flags = {'MI355_ICP_FLAG_UPSTREAM' if flags else '0'})",
+                   "ms_per_request_median": 1e3 * times[len(times) // 2], "ms_per_request_min": 1e3 * times[0], "calls": len(times),
+                   "passes": [int(x) for x in r.passes], "pose_error_vs_truth_max": float(max(np.linalg.norm(q - gt) for q in r.poses))}
+            if form == "upstream":
+                legs["reference_request_6_candidates_20k_model_100k_scene"] = leg
+            else:
+                legs["reference_request_6_candidates_20k_model_100k_scene"]["round1to3_form"] = leg
+    # the one HBM-bound kernel of the path: scene compaction (reference pose_estimation.cpp:248, NaN removal) over a frame far
+    # beyond the 256 MB Infinity Cache; kernel time from the engine's own HIP events, algorithmic bytes = 12 B read per point +
+    # 12 B written per kept point
+    n = 64_000_000
+    pts = np.empty((n, 3), dtype=np.float32)
+    ramp = (np.arange(n, dtype=np.uint32) % np.uint32(4099)).astype(np.float32)
+    pts[:, 0] = ramp * np.float32(1e-3)
+    pts[:, 1] = ramp * np.float32(-7e-4)
+    pts[:, 2] = np.float32(1.0)
+    pts[::5, 0] = np.nan   # 80 % kept
+    with pa.IcpEngine(main_engine.device_id) as e:
+        e.set_profiling(True)
+        best, kept = None, 0
+        for rep in range(3):
+            e.scene_load(pts)
+            e.reset_profile()
+            kept = e.scene_filter([(pa._lib.SCENE_FILTER_FINITE, [])])
+            ms = e.profile().scene_filter_ms
+            best = ms if best is None or (rep and ms < best) else best
+    del pts
+    alg = 12.0 * n + 12.0 * kept
+    legs["scene_compaction_64M_points_nan_removal"] = {
+        "kernel": "scene_compact_kernel", "points": n, "kept": int(kept), "kernel_ms_best_of_3": best, "algorithmic_bytes": alg,
+        "roofline": {"bound": "hbm", "achieved": alg / (best * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    # a whole EstimatePose request through the C++ host mirror (build/estimate_pose_harness ... pipeline): camera-like frame
+    # -> NaN removal -> RANSAC plane fit -> band filter -> k = 20 normals -> commit -> reference-mode ICP of 6 candidates ->
+    # best pose; its third pass is the steady state of a service.  A child process (never an exec of this one).
+    exe = os.path.join(ROOT, "build", "estimate_pose_harness")
+    if os.path.exists(exe):
+        import re
+        import subprocess
+        try:
+            out = subprocess.run([exe, "20000", "100000", "6", "pipeline"], capture_output=True, text=True, timeout=120)
+            passes = [ln for ln in out.stdout.splitlines() if ln.startswith("pipeline pass")]
+            m = re.search(r"upload\+filters\+plane fit ([0-9.]+) ms, normals ([0-9.]+) ms, commit ([0-9.]+) ms, ICP of (\d+) candidates ([0-9.]+) ms, total ([0-9.]+) ms", passes[-1]) if passes else None
+            if out.returncode == 0 and m:
+                legs["whole_request_pipeline_150k_frame_20k_model"] = {
+                    "command": "build/estimate_pose_harness 20000 100000 6 pipeline (third pass: steady state)",
+                    "filters_and_plane_fit_ms": float(m.group(1)), "normals_ms": float(m.group(2)), "commit_ms": float(m.group(3)),
+                    "icp_candidates": int(m.group(4)), "icp_ms": float(m.group(5)), "total_ms": float(m.group(6)),
+                    "icp_form": "upstream-faithful (the mirror's default)"}
+            else:
+                legs["whole_request_pipeline_150k_frame_20k_model"] = {"error": (out.stderr or out.stdout)[-300:]}
+        except Exception as ex:   # the headline line must not depend on this leg
+            legs["whole_request_pipeline_150k_frame_20k_model"] = {"error": repr(ex)}
     return legs
 
 
@@ -268,17 +327,27 @@ def launcher_selftest():
 
 def main():
     a = parse()
+    multi_ids = None   # plain invocation with N > 1: ONE process, one multi-device handle
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # nothing GPU-related has been imported yet: spawn the ranks and relay rank 0's line
-        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:], check_devices=not (a.launcher_selftest or os.environ.get("MI355_BENCH_SKIP_DEVICE_CHECK"))))
+        if a.launcher_selftest or a.spawn_ranks:
+            # nothing GPU-related has been imported yet: spawn the ranks and relay rank 0's line
+            raise SystemExit(launch_ranks(a.gpus, sys.argv[1:], check_devices=not (a.launcher_selftest or os.environ.get("MI355_BENCH_SKIP_DEVICE_CHECK"))))
+        multi_ids = a.device_ids if a.device_ids else list(range(a.gpus))
+        if len(multi_ids) != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but --device-ids names {len(multi_ids)} slots: refusing to print a mislabelled line")
+        have = visible_gpu_count()
+        if have is not None and max(multi_ids) >= have:
+            print(f"bench.py: --gpus {a.gpus} (devices {multi_ids}) but only {have} GPU(s) are visible to this process", file=sys.stderr)
+            raise SystemExit(2)
     if a.launcher_selftest:
         return launcher_selftest()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist_mode = world > 1 or a.force_dist
-    if world != a.gpus:
+    if multi_ids is None and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: refusing to print a mislabelled line")
+    n_slots = len(multi_ids) if multi_ids else world   # devices the workload is spread over
     torch = dist = None
     json_fd = 1
     if dist_mode:
@@ -304,20 +373,23 @@ def main():
     import synth_twin as st  # seeds / named configurations only
 
     nt = a.n_target
-    ns_total = a.n_source * world if a.scaling == "weak" else a.n_source
-    ns_local = a.n_source if a.scaling == "weak" else (ns_total + world - 1) // world
+    ns_total = a.n_source * n_slots if a.scaling == "weak" else a.n_source
+    ns_local = a.n_source if a.scaling == "weak" else (ns_total + n_slots - 1) // n_slots
     T = st.perturbation(-1)
     tgt = pa.synth_cloud(st.TARGET_SEED, nt)
-    begin, count = pa.slab_range(ns_total, rank, world)
+    if multi_ids:   # the handle takes the WHOLE model and cuts the slabs itself
+        begin, count = 0, ns_total
+    else:
+        begin, count = pa.slab_range(ns_total, rank, world)
     src = pa.synth_cloud(st.SOURCE_SEED, count, first_index=begin, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T)
 
-    eng = pa.IcpEngine(local_rank)
+    eng = pa.IcpEngine(device_ids=multi_ids) if multi_ids else pa.IcpEngine(local_rank)
     t_up = time.perf_counter()
     eng.set_targets([tgt])
     eng.set_sources([src])
     upload_s = time.perf_counter() - t_up
 
-    collective = "none"
+    collective = "in-process: per-device rows through pinned host memory, added in device order (mi355_icp_create_multi)" if multi_ids else "none"
     if dist_mode:
         if a.collective == "native":
             try:
@@ -363,7 +435,7 @@ def main():
 
     prof = eng.profile()
     # the rank count the line reports is the communicator's own (ncclCommCount), not an environment variable
-    if collective == "rccl-native":
+    if collective == "rccl-native" or multi_ids:
         n_ranks = eng.comm_info()[1]
     elif dist_mode:
         n_ranks = dist.get_world_size()
@@ -381,6 +453,7 @@ def main():
     if rank == 0:
         pairs_step = float(ns_total) * float(nt)
         scan_ms = prof.nn_scan_ms / max(prof.nn_scan_launches, 1)
+        count = ns_local if multi_ids else count   # points of ONE device's launch (the profile is device slot 0's)
         pairs_launch = float(count) * float(nt)
         alg_bytes = 12.0 * count + 12.0 * nt + 8.0 * count   # read both clouds once, write index + d2
         mode = os.environ.get("MI355_ICP_SCAN_MODE", "") or ("xbf16" if pairs_launch >= 2.5e8 else "exact")
@@ -392,7 +465,9 @@ def main():
             "icp_iters_per_sec": a.steps / elapsed,
             "correspondences_per_sec": float(ns_total) * a.steps / elapsed,
             "config": {"workload": f"{ns_total}x{nt} point-to-point ICP, exact brute-force NN "
-                                   f"({'BASELINE config[2] 1M<->1M' if world == 1 else 'source slab-sharded, ' + str(ns_local) + ' pts/GPU, target replicated'})",
+                                   f"({'BASELINE config[2] 1M<->1M' if n_slots == 1 else 'source slab-sharded, ' + str(ns_local) + ' pts/GPU, target replicated'})",
+                       "process_model": "one process, one multi-device handle" if multi_ids else ("one process per GPU" if world > 1 else "one process, one GPU"),
+                       "device_ids": multi_ids,
                        "n_source_total": ns_total, "n_target": nt, "source_points_per_gpu": ns_local,
                        "collective": collective, "pair_definition": "one (source,target) distance evaluation: Ns*Nt*iterations"},
             "roofline": {
@@ -400,6 +475,7 @@ def main():
                 "achieved": exec_flop * pairs_launch / (scan_ms * 1e-3) / 1e12, "peak": peak,
                 "unit": "TFLOP/s", "frac": exec_flop * pairs_launch / (scan_ms * 1e-3) / 1e12 / peak,
                 "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_note,
+                "traffic_from_this_run": False,   # PMC counters cannot be read in-process: the committed rocprofv3 pass of this command, or null
                 "algorithmic_flop_per_launch": exec_flop * pairs_launch, "flop_per_pair": exec_flop,
                 "model_flop_per_pair": FLOP_PER_PAIR, "model_tflops": FLOP_PER_PAIR * pairs_launch / (scan_ms * 1e-3) / 1e12,
                 "avg_launch_ms": scan_ms, "launches": int(prof.nn_scan_launches), "note": note,
@@ -425,7 +501,7 @@ def main():
             "upload_s": upload_s, "device": eng.device_info()["name"],
             "final_pose_error_vs_truth": float(np.linalg.norm(res.poses[0] - np.linalg.inv(T))),
         }
-        if world == 1 and not a.no_exact_leg and mode != "exact":
+        if n_slots == 1 and not a.no_exact_leg and mode != "exact":
             # north_star's literal kernel (LDS-tiled all-exact scan, no matrix cores) in the same driver-timed run: a
             # second engine with the planner forced to it, a few steps, priced against the FP32 vector peak
             os.environ["MI355_ICP_SCAN_MODE"] = "exact"
@@ -453,9 +529,9 @@ def main():
                 "note": note2 + " This is north_star's literal form (target tiles through LDS, no MFMA); the default path above "
                                 "returns the same bits faster.",
             }
-        if world == 1 and not a.no_config_legs:
+        if n_slots == 1 and not a.no_config_legs:
             out["other_configs"] = other_config_legs(pa, st, np, eng)
-        if world == 1 and not a.no_cpu_baseline:
+        if n_slots == 1 and not a.no_cpu_baseline:
             cb = cpu_baseline(src, tgt, a.cpu_baseline_iters, a.cpu_baseline_iters_1thread)
             cpu_pose = cb.pop("pose")
             if a.cpu_baseline_iters == a.steps:
