@@ -81,6 +81,12 @@ typedef struct mi355_icp_params {
                                         tile and run).  Off by default: the reference path this engine replaces is
                                         specified - and benchmarked - as brute force.  Worth it from ~100k points. */
 
+#define MI355_ICP_FLAG_BRUTE_SCAN 8  /* mi355_icp_align_reference only: every pass by the brute-force scan.  Without this flag and
+                                        without MI355_ICP_FLAG_PRUNED_SCAN that call picks, per pass, whichever of the two
+                                        exact scans is estimated faster (the pruned one from a few hundred thousand scene
+                                        points on; same indices, distances and poses either way; MI355_ICP_SERVICE_PRUNE=0|1
+                                        overrides the estimate).  mi355_icp_align - the benchmarked path - is brute force
+                                        unless MI355_ICP_FLAG_PRUNED_SCAN asks otherwise. */
 #define MI355_ICP_FLAG_UPSTREAM 4    /* mi355_icp_align_reference only: follow upstream cv::ppf_match_3d::ICP where the round 1-3
                                         form of reference mode left its control flow (see mi355_icp_reference_params).
                                         The host mirrors (mi355::cv_adapter::ICP, mi355::ppf_match_3d::ICP, Python ICP) set

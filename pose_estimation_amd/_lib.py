@@ -17,6 +17,7 @@ UNIQUE_ID_BYTES = 128
 FLAG_PROFILE = 1
 FLAG_PRUNED_SCAN = 2
 FLAG_UPSTREAM = 4
+FLAG_BRUTE_SCAN = 8
 
 OK = 0
 ERR_INVALID_ARGUMENT = 1

@@ -286,6 +286,9 @@ struct mi355_icp_ctx {
                                      // rows per split, so fewer, longer ones cost less key traffic (100k<->100k: resolve
                                      // 82 -> 35 us at equal scan time; profiles/r01o_target_blocks.txt)
   bool call_pruned = false;          // this call asked for the pruned scan (MI355_ICP_FLAG_PRUNED_SCAN)
+  bool call_auto_prune = false;      // this call (mi355_icp_align_reference without a scan flag) lets the planner take the exact pruned
+                                     // scan for the passes where it is the faster way to the same bits (service_prune_pays)
+  int service_prune = -1;            // MI355_ICP_SERVICE_PRUNE: -1 auto (default), 0 never, 1 every pass of such a call
   int xbf16_shape = 0;               // 0: <4 sets, 256 threads> workgroups, 1: <2 sets, 512 threads> (MI355_ICP_XBF16_SHAPE)
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
   int resolve_wave_points = 0;       // MI355_ICP_RESOLVE_WAVE_POINTS=16|32|64: points per wave of the filter's resolve (0: by launch size)
@@ -565,6 +568,22 @@ uint32_t xcd_round(uint32_t split) {
   return 1;
 }
 
+// The service path's choice between the brute-force scan and the exact PRUNED scan for one pass of a request (reference mode
+// only: the path the node calls; mi355_icp_align - what bench.py measures - is brute force unless asked otherwise).  Both give
+// the same indices and distances bit for bit; this only estimates which is faster.  Fitted to profiles/r04e_pruned_vs_brute_sweep.jsonl
+// (6 candidates of an n-point model against an m-point scene, one pass; scan + resolve + reduce, milliseconds):
+//   brute force  ~ pairs / 3.4e10 + 0.03 + 2e-7 x source points       (3.4e13 pairs/s at these launch sizes)
+//   pruned       ~ 0.30 + 2e-6 n + m (2e-6 + 0.02 / n)                 (a dense scene under a sparse model prunes badly)
+// the pruned scan is taken when it wins by more than 10 % - below that the brute-force pass, whose time does not depend on
+// how far the candidate still is from the scene, is the safer one.
+bool service_prune_pays(double jobs, double n_model, double n_scene) {
+  if (n_model < 1.0 || n_scene < 1.0) return false;
+  const double width = jobs > 6.0 ? jobs / 6.0 : 1.0;  // measured with 6 candidates; more of them are more workgroups
+  const double brute = jobs * n_model * n_scene / 3.4e10 + 0.03 + 2e-7 * jobs * n_model;
+  const double pruned = 0.30 + (2e-6 * n_model + n_scene * (2e-6 + 0.02 / n_model)) * width;
+  return pruned * 1.1 < brute;
+}
+
 // Lays the jobs out and decides how finely to cut each target: enough scan workgroups to keep
 // 256 CUs x 4 resident workgroups busy for several rounds, never finer than min_tiles_per_split.
 int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, const std::vector<CloudEntry>& tgt_clouds,
@@ -596,7 +615,19 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   // ... and the split-bf16 matrix-core form of it (xkind 3: one issue slot per pair, 2.3x the VALU filter end to end at
   // 100k<->100k, 1M<->1M and 64 x 50k<->50k: profiles/r01n_baseline_configs.jsonl) is the default wherever it applies
   plan.xkind = c->scan_fused < 0 ? 3 : (c->scan_fused >= 2 ? c->scan_fused - 2 : 0);
-  if (c->scan_fused == 6 || c->call_pruned) {  // the optional pruned scan: no keys, no filters, no splits
+  bool auto_pruned = false;
+  if (c->call_auto_prune && c->scan_fused < 0 && !c->call_pruned) {  // a request's pass: whichever exact scan is faster
+    double n_model = 0.0, n_scene = 0.0;
+    uint32_t max_tiles = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+      n_model += src_clouds[source_ids ? source_ids[k] : 0].n;
+      n_scene += tgt_clouds[target_ids ? target_ids[k] : 0].n;
+      max_tiles = std::max(max_tiles, tgt_clouds[target_ids ? target_ids[k] : 0].padded / kTile);
+    }
+    auto_pruned = max_tiles <= kPrunedMaxTiles &&
+                  (c->service_prune == 1 || (c->service_prune < 0 && service_prune_pays(n_jobs, n_model / n_jobs, n_scene / n_jobs)));
+  }
+  if (c->scan_fused == 6 || c->call_pruned || auto_pruned) {  // the optional pruned scan: no keys, no filters, no splits
     plan.pruned = true;
     plan.fused = plan.xfilter = false;
     plan.xkind = 0;
@@ -727,8 +758,8 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
 
   if (static_cast<uint64_t>(plan.key_rows()) * plan.out_total > 0xFFFF0000ull) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "batch too large");
   if (c->plan_debug)
-    std::fprintf(stderr, "mi355_icp plan: %d jobs, %.3g pairs, fused %d xkind %d ppl %d, source blocks %llu, want_split %u%s -> split %u, %u workgroups x %d, sub_split %u\n",
-                 n_jobs, total_pairs, int(plan.fused), plan.xkind, plan.scan_ppl, static_cast<unsigned long long>(total_src_blocks), want_split,
+    std::fprintf(stderr, "mi355_icp plan: %d jobs, %.3g pairs, pruned %d fused %d xkind %d ppl %d, source blocks %llu, want_split %u%s -> split %u, %u workgroups x %d, sub_split %u\n",
+                 n_jobs, total_pairs, int(plan.pruned), int(plan.fused), plan.xkind, plan.scan_ppl, static_cast<unsigned long long>(total_src_blocks), want_split,
                  model_split ? " (model)" : "", plan.jobs[0].n_split, plan.max_blocks_x, n_jobs, plan.jobs[0].sub_split);
   return MI355_ICP_OK;
 }
@@ -1196,7 +1227,9 @@ int level_slot(const CloudSet& set, uint32_t step) {
 
 // Builds (once per upload, and again when the sharding changes) the subsampled planes of every cloud of `set` for each step of
 // `steps` that is missing.  shard_begin / shard_total: this rank's slab of every cloud (nullptr = the clouds are whole).
-int ensure_levels(mi355_icp_ctx* c, CloudSet& set, const std::vector<uint32_t>& steps, uint32_t pad_multiple, float pad_value,
+// want_rows: a set with normals also gets its 32-byte rows from the same launch (the targets always; the sources only for the
+// upstream-faithful variant - ensure_rows builds a missing level's rows on demand either way).
+int ensure_levels(mi355_icp_ctx* c, CloudSet& set, const std::vector<uint32_t>& steps, uint32_t pad_multiple, float pad_value, bool want_rows,
                   const std::vector<uint64_t>* shard_begin = nullptr, const std::vector<uint64_t>* shard_total = nullptr) {
   const std::vector<uint64_t> none;
   const std::vector<uint64_t>& want_begin = shard_begin ? *shard_begin : none;
@@ -1243,7 +1276,7 @@ int ensure_levels(mi355_icp_ctx* c, CloudSet& set, const std::vector<uint32_t>& 
     lv.stride = static_cast<size_t>(std::max<uint64_t>(total, pad_multiple));
     hipError_t e = c->pool.take(reinterpret_cast<void**>(&lv.planes), 3 * lv.stride * sizeof(float));
     // a set with normals: the level's rows (coordinates + normal, what the point-to-plane accumulate reads) come out of the same launch
-    if (e == hipSuccess && set.normals) e = c->pool.take(&lv.rows, lv.stride * 32);
+    if (e == hipSuccess && set.normals && want_rows) e = c->pool.take(&lv.rows, lv.stride * 32);
     if (e == hipSuccess && total == 0) e = hipMemsetAsync(lv.planes, 0, 3 * lv.stride * sizeof(float), c->stream);
     fresh.push_back(lv);
     if (e != hipSuccess) {
@@ -1767,6 +1800,7 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->ready_mapped), c->ready_host, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
   std::memset(c->ready_host, 0, kReadyWords * sizeof(uint32_t));
   if (const char* v = std::getenv("MI355_ICP_PASS_TAIL")) c->pass_tail = std::atoi(v) != 0;
+  if (const char* v = std::getenv("MI355_ICP_SERVICE_PRUNE")) c->service_prune = std::string(v) == "auto" ? -1 : (std::atoi(v) != 0 ? 1 : 0);
   if (const char* v = std::getenv("MI355_ICP_LEVEL_SORT")) c->level_sort = std::atoi(v) != 0;
   *out = c;
   return MI355_ICP_OK;
@@ -2112,6 +2146,10 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
   // clears it (ensure_ref_buffers); whoever resets owner_epoch to 0 gets it cleared by the next pass (run_ref_pass_once).
   if (sharded) c->owner_epoch = 0;
   c->call_pruned = (rp->flags & MI355_ICP_FLAG_PRUNED_SCAN) != 0;
+  // no scan flag: the planner takes the exact pruned scan for the passes where it is faster (large frames; never slab-sharded:
+  // the ranks' plans stay independent of each other's slab sizes)
+  c->call_auto_prune = !sharded && (rp->flags & (MI355_ICP_FLAG_PRUNED_SCAN | MI355_ICP_FLAG_BRUTE_SCAN)) == 0;
+  struct AutoPruneOff { mi355_icp_ctx* c; ~AutoPruneOff() { c->call_auto_prune = false; } } auto_prune_off{c};
   const bool profile = c->profile_always || (rp->flags & MI355_ICP_FLAG_PROFILE) != 0;
 
   std::vector<double> solve_x;
@@ -2151,8 +2189,8 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
         uint32_t step = 0;
         if (level_runs(k, level, &step) && std::find(steps.begin(), steps.end(), step) == steps.end()) steps.push_back(step);
       }
-    if ((st = ensure_levels(c, c->sources, steps, kSrcPad, 0.0f, sharded ? &shard_begin : nullptr, sharded ? &shard_total : nullptr)) != MI355_ICP_OK) return st;
-    if ((st = ensure_levels(c, c->targets, steps, kTile, kTargetPad)) != MI355_ICP_OK) return st;
+    if ((st = ensure_levels(c, c->sources, steps, kSrcPad, 0.0f, upstream, sharded ? &shard_begin : nullptr, sharded ? &shard_total : nullptr)) != MI355_ICP_OK) return st;
+    if ((st = ensure_levels(c, c->targets, steps, kTile, kTargetPad, true)) != MI355_ICP_OK) return st;
   }
 
   bool select_cleared = false, overflow_cleared = false;
@@ -2306,8 +2344,8 @@ int mi355_icp_reference_pass_ex(mi355_icp_ctx* c, int source_id, int target_id, 
   if (st != MI355_ICP_OK) return st;
   if (centre && !c->sources.normals) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "reference_pass: the upstream-faithful form needs the source uploaded with normals");
   const std::vector<uint32_t> steps{step};
-  if ((st = ensure_levels(c, c->sources, steps, kSrcPad, 0.0f)) != MI355_ICP_OK) return st;
-  if ((st = ensure_levels(c, c->targets, steps, kTile, kTargetPad)) != MI355_ICP_OK) return st;
+  if ((st = ensure_levels(c, c->sources, steps, kSrcPad, 0.0f, centre != nullptr)) != MI355_ICP_OK) return st;
+  if ((st = ensure_levels(c, c->targets, steps, kTile, kTargetPad, true)) != MI355_ICP_OK) return st;
   RefLevel lvl;
   lvl.sslot = level_slot(c->sources, step);
   lvl.tslot = level_slot(c->targets, step);
@@ -2587,7 +2625,11 @@ int mi355_icp_scene_fit_plane(mi355_icp_ctx* c, const mi355_plane_fit_params* fp
   HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t n = c->scene_n, n_hyp = static_cast<uint32_t>(fp->max_iterations);
   const uint32_t blocks = (n + 4 * kBlockThreads - 1) / (4 * kBlockThreads);
-  constexpr size_t kHypBytes = (kPlaneMaxHypotheses + 1) * 4 * sizeof(float), kCountBytes = (kPlaneMaxHypotheses + 1) * sizeof(uint32_t);
+  // the moment rows (doubles) sit behind the counters in the pinned read-back block: the counters' size is rounded up so that
+  // they start on an 8-byte boundary (4100 bytes of counters would put them on a 4-mod-8 address)
+  constexpr size_t kHypBytes = (kPlaneMaxHypotheses + 1) * 4 * sizeof(float);
+  constexpr size_t kCountBytes = ((kPlaneMaxHypotheses + 1) * sizeof(uint32_t) + 7) & ~static_cast<size_t>(7);
+  static_assert((kHypBytes + kCountBytes) % alignof(double) == 0, "the moment rows must be aligned for double");
   if (!c->plane_hyp) {  // hypotheses | counters: one block, one read-back
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->plane_hyp), kHypBytes + kCountBytes));
     c->plane_counts = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(c->plane_hyp) + kHypBytes);

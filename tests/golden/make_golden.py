@@ -11,18 +11,23 @@ an independent implementation before it is written:
   * quaternions against scipy.spatial.transform.Rotation.
 Inputs come from the deterministic generator (csrc/synth.c == tests/synth_twin.py).
 
-    python tests/golden/make_golden.py        # rewrites tests/golden/*.npz|json
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz|json
+    python tests/golden/make_golden.py --check  # regenerates into a scratch directory and FAILS (exit 1) if anything differs
+                                                # from the committed fixtures (tests/test_oracle.py runs this)
 """
+import argparse
 import hashlib
 import json
 import os
 import sys
+import tempfile
 
 import numpy as np
 from scipy.spatial import cKDTree
 from scipy.spatial.transform import Rotation
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE  # where the fixtures are written (--check: a scratch directory)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -84,7 +89,7 @@ def icp_fixture(name, src, tgt, gt, p, sample_stride=None, hash_iters=()):
             else:
                 arrays["idx0"] = idx
                 arrays["d2_0"] = d2
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
     return out
 
 
@@ -96,7 +101,7 @@ def main():
     src, tgt, gt = st.make_pair(synth, 1000, 1000)
     p = ora.params(max_iterations=50)
     meta["c1_1k"] = icp_fixture("c1_1k", src, tgt, gt, p, hash_iters=(0, 1, 49))
-    np.savez_compressed(os.path.join(HERE, "c1_1k_clouds.npz"), src=src, tgt=tgt)
+    np.savez_compressed(os.path.join(OUT, "c1_1k_clouds.npz"), src=src, tgt=tgt)
 
     # (2) C2 100k<->100k, 50 iterations: hashes + strided sample
     src, tgt, gt = st.make_pair(synth, 100_000, 100_000)
@@ -106,7 +111,7 @@ def main():
     src, tgt, gt = st.make_pair(synth, 1337, 777)
     pc = ora.params(max_iterations=60, transformation_epsilon=1e-10, rotation_epsilon=1e-9, relative_mse_epsilon=1e-7)
     meta["ragged"] = icp_fixture("ragged", src, tgt, gt, pc, hash_iters=(0,))
-    np.savez_compressed(os.path.join(HERE, "ragged_clouds.npz"), src=src, tgt=tgt)
+    np.savez_compressed(os.path.join(OUT, "ragged_clouds.npz"), src=src, tgt=tgt)
 
     # (4) tie fixture: integer lattice, queries on cell centres -> many exact float32 ties
     g = np.arange(12, dtype=np.float32)
@@ -122,7 +127,7 @@ def main():
     D = ((q[:, None, :].astype(np.float64) - tgt[None, :, :].astype(np.float64)) ** 2).sum(-1)
     assert np.array_equal(idx, D.argmin(1).astype(np.int32))
     ties = int(((D == D.min(1, keepdims=True)).sum(1) > 1).sum())
-    np.savez_compressed(os.path.join(HERE, "ties.npz"), q=q, tgt=tgt, idx=idx, d2=d2)
+    np.savez_compressed(os.path.join(OUT, "ties.npz"), q=q, tgt=tgt, idx=idx, d2=d2)
     meta["ties"] = {"queries_with_ties": ties, "n": int(q.shape[0])}
 
     # (5) degenerate clouds for the Kabsch reflection / rank branches
@@ -149,7 +154,7 @@ def main():
     stt, P = ora.solve_rigid(sums)
     assert stt == 0 and abs(np.linalg.det(P[:3, :3]) - 1) < 1e-12 and np.abs(P - kabsch_numpy(sums)).max() < 1e-9
     deg["mirror_sums"], deg["mirror_pose"] = sums, P
-    np.savez_compressed(os.path.join(HERE, "degenerate.npz"), **deg)
+    np.savez_compressed(os.path.join(OUT, "degenerate.npz"), **deg)
 
     # (6) pose7 known answers (reference formula chessboard_pose_estimator.cpp:196-207), incl. w ~ 0
     rots = [Rotation.identity(), Rotation.from_euler("z", 90, degrees=True), Rotation.from_euler("x", 180, degrees=True),
@@ -168,7 +173,7 @@ def main():
         assert np.abs(np.abs(a[3:]) - np.abs(q)).max() < 2e-3, (k, a, q)  # float formula loses digits near w=0
         assert b[5] == 0.0 and b[6] == a[6] and np.array_equal(b[:5], a[:5])
         poses.append(P), p7.append(a), p7ref.append(b)
-    np.savez_compressed(os.path.join(HERE, "pose7.npz"), poses=np.array(poses), pose7=np.array(p7), pose7_ref=np.array(p7ref))
+    np.savez_compressed(os.path.join(OUT, "pose7.npz"), poses=np.array(poses), pose7=np.array(p7), pose7_ref=np.array(p7ref))
 
     # (7) reference mode (pyramid + MAD rejection + picky + point-to-plane), small enough to store the clouds
     T = st.perturbation(-1)
@@ -190,15 +195,82 @@ def main():
     A = np.concatenate([np.cross(pp, nn), nn], axis=1)
     x_np = np.linalg.lstsq(A, ((qq - pp) * nn).sum(1), rcond=None)[0]
     assert np.abs(ora.solve_point_to_plane(sums)[1] - x_np).max() < 1e-9
-    np.savez_compressed(os.path.join(HERE, "refmode_2k.npz"), src=srcr, tgt6=tgt6, final_pose=r["pose"], start=start, cur=cur,
+    np.savez_compressed(os.path.join(OUT, "refmode_2k.npz"), src=srcr, tgt6=tgt6, final_pose=r["pose"], start=start, cur=cur,
                         pass_idx=idx, pass_d2=d2, pass_sel=sel, pass_thr=np.float32(thr), pass_sums=sums)
     meta["refmode_2k"] = {"params": [60, 0.005, 2.5, 5], "passes": int(r["passes"]), "residual": r["residual"],
                           "pass_level": 1, "pass_selected": int(n_sel)}
 
-    with open(os.path.join(HERE, "golden.json"), "w") as f:
+    # (8) reference mode, UPSTREAM-FAITHFUL variant (MI355_ICP_FLAG_UPSTREAM): a 1000-point N x 6 model - its pyramid samples
+    # with steps 125, 62, 32, 16, ... (cvRound of the model size, not 2^l) - against a 3000-point scene a metre from the camera.
+    # Independent check before writing: the literal numpy restatement that materialises upstream's clouds (upstream_literal.py)
+    import upstream_literal as ul
+    shift = np.array([0.0, 0.0, 1.0])
+    tgt_u = st.synth_cloud_np(st.TARGET_SEED, 3000, normals=True)
+    tgt_u[:, :3] += shift.astype(np.float32)
+    src_u = st.synth_cloud_np(st.SOURCE_SEED, 1000, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T, normals=True)
+    init_u = np.eye(4)
+    init_u[:3, 3] = shift
+    init_u = st.rigid_transform(1.5, (0.2, 1, -0.4), (0.004, -0.003, 0.002)) @ init_u
+    ru = ora.icp_reference_upstream(src_u, tgt_u, init_u, 250, 0.005, 2.5, 8)
+    lit = ul.register_model_to_scene(src_u, tgt_u, init_u, 250, 0.005, 2.5, 8)
+    assert ru["status"] == 0 and list(ru["level_passes"]) == list(lit["level_passes"])
+    assert np.linalg.norm(ru["pose"] - lit["pose"]) <= 2e-6 and abs(ru["residual"] - lit["residual"]) <= 1e-6 * lit["residual"]
+    steps = [ora.upstream_step(1000, l) for l in range(8)]
+    assert steps == [1, 2, 4, 8, 16, 32, 62, 125]
+    step_u = 62
+    start_u = st.rigid_transform(0.7, (0.1, 1, 0.3), (0.004, 0.001, -0.002)) @ init_u
+    cur_u = st.rigid_transform(0.2, (1, 0, 0), (0.001, 0, 0)) @ start_u
+    n_u, sums_u, idx_u, d2_u, sel_u, thr_u = ora.ref_pass_ex(src_u[::step_u][:1000 // step_u], tgt_u[::step_u][:3000 // step_u], start_u, cur_u, 2.5,
+                                                               centre=ru["centre"])
+    np.savez_compressed(os.path.join(OUT, "refmode_upstream_1k.npz"), src6=src_u, tgt6=tgt_u, init=init_u, final_pose=ru["pose"],
+                        centre=ru["centre"], level_passes=ru["level_passes"], start=start_u, cur=cur_u, pass_idx=idx_u, pass_d2=d2_u,
+                        pass_sel=sel_u, pass_thr=np.float32(thr_u), pass_sums=sums_u)
+    meta["refmode_upstream_1k"] = {"params": [250, 0.005, 2.5, 8], "passes": int(ru["passes"]), "residual": ru["residual"], "scale": ru["scale"],
+                                   "steps": steps, "pass_step": step_u, "pass_selected": int(n_u)}
+
+    with open(os.path.join(OUT, "golden.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print(json.dumps(meta, indent=1, sort_keys=True)[:1500])
 
 
+def compare_with_committed(fresh_dir):
+    """Every array of every regenerated .npz and the whole golden.json against the committed files; returns the differences."""
+    diffs = []
+    for name in sorted(os.listdir(fresh_dir)):
+        a, b = os.path.join(fresh_dir, name), os.path.join(HERE, name)
+        if not os.path.exists(b):
+            diffs.append(f"{name}: not committed")
+            continue
+        if name.endswith(".json"):
+            if json.load(open(a)) != json.load(open(b)):
+                diffs.append(f"{name}: contents differ")
+            continue
+        fa, fb = np.load(a), np.load(b)
+        if sorted(fa.files) != sorted(fb.files):
+            diffs.append(f"{name}: arrays {sorted(fa.files)} vs committed {sorted(fb.files)}")
+            continue
+        for k in fa.files:
+            x, y = fa[k], fb[k]
+            if x.dtype != y.dtype or x.shape != y.shape or x.tobytes() != y.tobytes():
+                diffs.append(f"{name}[{k}]: differs from the committed array")
+    for name in sorted(os.listdir(HERE)):
+        if name.endswith((".npz", ".json")) and not os.path.exists(os.path.join(fresh_dir, name)):
+            diffs.append(f"{name}: committed but no longer generated")
+    return diffs
+
+
 if __name__ == "__main__":
-    main()
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true", help="regenerate into a scratch directory and fail if anything differs from the committed fixtures")
+    args = ap.parse_args()
+    if args.check:
+        with tempfile.TemporaryDirectory() as tmp:
+            OUT = tmp
+            main()
+            diffs = compare_with_committed(tmp)
+        if diffs:
+            print("make_golden.py --check: the regenerated fixtures differ from the committed ones:\n  " + "\n  ".join(diffs), file=sys.stderr)
+            sys.exit(1)
+        print("make_golden.py --check: regenerated fixtures are identical to the committed ones")
+    else:
+        main()

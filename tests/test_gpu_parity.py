@@ -23,12 +23,6 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def sums_close(a, b):
-    scale = np.maximum(np.abs(b), 1.0)
-    return np.all(np.abs(a - b) <= SUMS_RTOL * scale * max(1.0, b.flat[0]) ** 0.5 + 1e-9 * 0) or \
-        np.allclose(a, b, rtol=1e-11, atol=1e-9)
-
-
 def assert_pass_equal(eng, src, tgt, pose, max_corr=0.0, kd=True):
     idx, d2, sums = eng.correspond(pose[None], max_corr)
     oi, od, osums = ora.correspond(pose, src, tgt, max_corr, use_kdtree=kd, nthreads=ora.max_threads())

@@ -270,3 +270,45 @@ def test_pass_ending_launch_gives_the_separate_reduce_kernels_bits_every_time(en
         got = engine.align(np.stack([np.eye(4)] * 5), params, source_ids=list(range(5)), target_ids=list(range(5)))
         assert np.array_equal(got.iterations, want_p2p.iterations), rep
         assert np.array_equal(got.poses.view(np.uint64), want_p2p.poses.view(np.uint64)), rep
+
+
+def test_service_path_picks_the_faster_exact_scan_per_pass(capfd):
+    """mi355_icp_align_reference without a scan flag: the planner takes the exact PRUNED scan for the passes of a large frame
+    and the brute-force scan for the coarse levels (icp_engine.hip: service_prune_pays).  Whatever it picks, poses, residuals
+    and pass counts are those of the all-brute-force call (MI355_ICP_FLAG_BRUTE_SCAN) and of the all-pruned call, bit for bit."""
+    import pose_estimation_amd as pa
+    T = st.perturbation(-1)
+    tgt = st.synth_cloud_np(st.TARGET_SEED, 300_000, normals=True)
+    src = st.synth_cloud_np(st.SOURCE_SEED, 60_000, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T, normals=True)
+    gt = np.linalg.inv(T)
+    inits = np.stack([np.eye(4)] + [st.rigid_transform(k, (0.2, 1, -0.4), (0.01, -0.02, 0.015)) @ gt for k in (1.0, 2.0, 3.0, 4.0, 5.0)])
+    old = os.environ.get("MI355_ICP_PLAN_DEBUG")
+    os.environ["MI355_ICP_PLAN_DEBUG"] = "1"
+    try:
+        eng = pa.IcpEngine(0)
+    finally:
+        if old is None:
+            os.environ.pop("MI355_ICP_PLAN_DEBUG")
+        else:
+            os.environ["MI355_ICP_PLAN_DEBUG"] = old
+    with eng:
+        eng.set_targets([tgt])
+        eng.set_sources([src])
+        for flags in (pa._lib.FLAG_UPSTREAM, 0):
+            capfd.readouterr()
+            auto = eng.align_reference(inits, 250, 0.005, 2.5, 8, flags=flags)
+            plans = [ln for ln in capfd.readouterr().err.splitlines() if ln.startswith("mi355_icp plan:")]
+            assert any(" pruned 1 " in ln for ln in plans) and any(" pruned 0 " in ln for ln in plans), plans
+            brute = eng.align_reference(inits, 250, 0.005, 2.5, 8, flags=flags | pa._lib.FLAG_BRUTE_SCAN)
+            assert not any(" pruned 1 " in ln for ln in capfd.readouterr().err.splitlines())
+            pruned = eng.align_reference(inits, 250, 0.005, 2.5, 8, flags=flags | pa._lib.FLAG_PRUNED_SCAN)
+            for other in (brute, pruned):
+                assert np.array_equal(auto.passes, other.passes)
+                assert np.array_equal(auto.poses.view(np.uint64), other.poses.view(np.uint64))
+                assert np.array_equal(np.asarray(auto.residual).view(np.uint64), np.asarray(other.residual).view(np.uint64))
+        # the request shape of the reference (20k model, 100k scene) stays brute force on every level: it is the faster one there
+        eng.set_targets([tgt[:100_000].copy()])
+        eng.set_sources([src[:20_000].copy()])
+        capfd.readouterr()
+        eng.align_reference(inits, 250, 0.005, 2.5, 8, flags=pa._lib.FLAG_UPSTREAM)
+        assert not any(" pruned 1 " in ln for ln in capfd.readouterr().err.splitlines())

@@ -235,3 +235,52 @@ def test_cpp_harness_runs_the_upstream_variant_by_default(engine):
         assert np.linalg.norm(poses[k] - res.poses[k]) <= 1e-7, k   # candidate builders differ in the last ulp of cos/sin
         o = ora.icp_reference_upstream(model, scene, inits[k], 250, 0.005, 2.5, 8)
         assert np.linalg.norm(poses[k] - o["pose"]) <= POSE_TOL
+
+
+def test_golden_upstream_fixture(engine):
+    import json
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "refmode_upstream_1k.npz"))
+    meta = json.load(open(os.path.join(gold, "golden.json")))["refmode_upstream_1k"]
+    it, tol, scale, levels = meta["params"]
+    engine.set_targets([g["tgt6"]])
+    engine.set_sources([g["src6"]])
+    idx, d2, sel, thr, sums = engine.reference_pass_ex(g["start"], g["cur"], meta["pass_step"], scale, centre=g["centre"])
+    assert np.array_equal(idx, g["pass_idx"]) and np.array_equal(d2.view(np.uint32), g["pass_d2"].view(np.uint32))
+    assert np.array_equal(sel, g["pass_sel"]) and np.float32(thr) == g["pass_thr"]
+    np.testing.assert_allclose(sums, g["pass_sums"], rtol=1e-10, atol=1e-12)
+    res = engine.align_reference(g["init"][None], it, tol, scale, levels, flags=FLAG_UPSTREAM)
+    assert res.passes[0] == meta["passes"] and abs(res.residual[0] - meta["residual"]) <= 1e-9 * max(1.0, meta["residual"])
+    assert np.linalg.norm(res.poses[0] - g["final_pose"]) <= POSE_TOL
+    c, s_ = engine.upstream_normalisation(g["init"])
+    assert np.all(np.abs(c.view(np.int32) - g["centre"].view(np.int32)) <= 1) and abs(s_ - meta["scale"]) <= 1e-10 * meta["scale"]
+
+
+@pytest.mark.parametrize("upstream", [False, True], ids=["round1to3_form", "upstream_form"])
+def test_reference_mode_without_the_pass_ending_launch_against_the_oracle(upstream):
+    """MI355_ICP_PASS_TAIL=0: the separate final-reduce launch + device-to-host copy per pass - the A/B partner of the fence-free
+    pass-ending launch (icp_internal.h: finish_pass), which every other reference-mode test in this suite runs through - against
+    the oracle, both forms, multi-workgroup and single-workgroup jobs."""
+    import pose_estimation_amd as pa
+    shift = (0.2, 0.1, 0.9)
+    src, tgt, gt = pair66(9000, 12000, shift=shift)
+    inits = np.stack([shifted(shift)] + [st.rigid_transform(a, (0.2, 1, -0.4), (0.01, -0.02, 0.015)) @ gt for a in (1.0, 3.0, 5.0)])
+    old = os.environ.get("MI355_ICP_PASS_TAIL")
+    os.environ["MI355_ICP_PASS_TAIL"] = "0"
+    try:
+        plain = pa.IcpEngine(0)
+    finally:
+        if old is None:
+            os.environ.pop("MI355_ICP_PASS_TAIL")
+        else:
+            os.environ["MI355_ICP_PASS_TAIL"] = old
+    with plain:
+        plain.set_targets([tgt])
+        plain.set_sources([src])
+        res = plain.align_reference(inits, 250, 0.005, 2.5, 8, flags=FLAG_UPSTREAM if upstream else 0)
+    for k in range(len(inits)):
+        o = (ora.icp_reference_upstream if upstream else ora.icp_reference)(src if upstream else src[:, :3], tgt, inits[k], 250, 0.005, 2.5, 8,
+                                                                            nthreads=ora.max_threads())
+        assert res.passes[k] == o["passes"], k
+        assert np.linalg.norm(res.poses[k] - o["pose"]) <= POSE_TOL, k
+        assert abs(res.residual[k] - o["residual"]) <= 1e-9 * max(1.0, o["residual"]), k

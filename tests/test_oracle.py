@@ -174,3 +174,15 @@ def test_pose7_fixture():
     for P, a, b in zip(g["poses"], g["pose7"], g["pose7_ref"]):
         assert np.array_equal(ora.pose_to_pose7(P, False), a)
         assert np.array_equal(ora.pose_to_pose7(P, True), b)
+
+
+def test_committed_fixtures_are_what_the_generator_writes():
+    """tests/golden/make_golden.py --check regenerates every fixture into a scratch directory (cross-checking each against
+    scipy / numpy / the literal upstream restatement on the way) and fails if an array or golden.json differs from the
+    committed files: a fixture can neither drift from the oracle nor be edited by hand unnoticed."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "make_golden.py"), "--check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]

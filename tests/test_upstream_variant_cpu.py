@@ -125,3 +125,22 @@ def test_what_the_variant_changes_against_the_round_1_to_3_form():
     leg = ora.icp_reference(src[:, :3], tgt, init)
     assert np.linalg.norm(up["pose"] - gt) < 3e-3
     assert np.linalg.norm(leg["pose"] - gt) > 1.0
+
+
+def test_golden_upstream_fixture_reproduced():
+    """tests/golden/refmode_upstream_1k.npz (make_golden.py (8): written only after the literal restatement agreed)."""
+    import json
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "refmode_upstream_1k.npz"))
+    meta = json.load(open(os.path.join(gold, "golden.json")))["refmode_upstream_1k"]
+    it, tol, scale, levels = meta["params"]
+    r = ora.icp_reference_upstream(g["src6"], g["tgt6"], g["init"], it, tol, scale, levels)
+    assert r["passes"] == meta["passes"] and r["residual"] == meta["residual"] and r["scale"] == meta["scale"]
+    assert np.array_equal(r["pose"], g["final_pose"]) and np.array_equal(r["centre"], g["centre"]) and list(r["level_passes"]) == list(g["level_passes"])
+    assert [ora.upstream_step(1000, l) for l in range(8)] == meta["steps"]
+    step = meta["pass_step"]
+    n, sums, idx, d2, sel, thr = ora.ref_pass_ex(g["src6"][::step][:1000 // step], g["tgt6"][::step][:3000 // step], g["start"], g["cur"], scale,
+                                                 centre=g["centre"])
+    assert n == meta["pass_selected"] and np.array_equal(idx, g["pass_idx"]) and np.array_equal(d2, g["pass_d2"])
+    assert np.array_equal(sel, g["pass_sel"]) and np.float32(thr) == g["pass_thr"] and np.array_equal(sums, g["pass_sums"])

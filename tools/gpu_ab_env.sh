@@ -2,7 +2,8 @@
 # A/B of environment settings on ONE box, alternating, REPS rounds: the reference request, the four single-GPU
 # configurations and the request harness at the 450k-point frame under each setting.
 #   VARIANTS="on= off=MI355_ICP_SPLIT_MODEL=0" TAG=absplit bash tools/gpu_ab_env.sh
-# (name=ENVVAR=value; an empty setting is the default build)
+# (name=ENVVAR=value; an empty setting is the default build; several variables in one setting are separated by COMMAS:
+#  off=MI355_ICP_SPLIT_MODEL=0,MI355_ICP_MAX_SUB_SPLIT=1 - a setting may not contain spaces)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${TAG:-abenv}
@@ -13,7 +14,8 @@ cd "$R"
 for rep in $(seq 1 ${REPS:-2}); do
   for kv in $VARIANTS; do
     name=${kv%%=*}; setting=${kv#*=}
-    run() { local secs=$1 out=$2; shift 2; if [ -n "$setting" ]; then env "$setting" timeout -k 10 "$secs" "$@" > "$out" 2> "$out.err"; else timeout -k 10 "$secs" "$@" > "$out" 2> "$out.err"; fi; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a "$O/summary.txt"; exit 99; fi; return $rc; }
+    IFS=',' read -r -a assignments <<< "$setting"
+    run() { local secs=$1 out=$2; shift 2; if [ -n "$setting" ]; then env "${assignments[@]}" timeout -k 10 "$secs" "$@" > "$out" 2> "$out.err"; else timeout -k 10 "$secs" "$@" > "$out" 2> "$out.err"; fi; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a "$O/summary.txt"; exit 99; fi; return $rc; }
     run 120 "$O/lat_${name}_$rep.json" python tools/refmode_latency.py --reps 40
     run 300 "$O/cfg_${name}_$rep.jsonl" python tools/bench_configs.py
     run 300 "$O/ref_${name}_$rep.jsonl" python tools/bench_reference_mode.py
