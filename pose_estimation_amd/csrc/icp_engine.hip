@@ -143,6 +143,8 @@ struct Plan {
   bool pruned = false;         // OPTIONAL exact pruned scan (MI355_ICP_SCAN_MODE=pruned), never chosen by the planner
   bool merged_keys = false;    // small all-exact launches (JobDesc::sub_split): one atomically merged key row, cleared per pass
   bool classed = false;        // one-round matrix-core launches: class-weighted runs of tiles (JobDesc::first_class)
+  bool queued = false;         // matrix-core launches of a few rounds: teams of workgroups drawing groups of tiles (kXbLayoutQueue)
+  uint32_t grid3_x = 0, grid3_z = 0;  // the 3-D grid of the classed / queued layouts: source blocks, splits
   bool sorted_src = false;     // the matrix-core scan and its resolve walk the SOURCE cloud in Morton order too (below)
   uint32_t key_rows() const { return (xkind == 3 ? 2u : 1u) * max_split; }  // key rows per rank (wave halves publish separately)
   uint32_t key_ranks() const { return xfilter && xkind != 3 ? 4u : 3u; }       // the VALU expansion kernels also publish U
@@ -298,6 +300,14 @@ struct mi355_icp_ctx {
   double split_model_pairs = 5e10;    // ... below this many pairs per launch (MI355_ICP_SPLIT_MODEL_PAIRS: A/B)
   bool split_model = true;           // small matrix-core launches: pick the split that fills whole rounds of resident workgroups (MI355_ICP_SPLIT_MODEL=0: A/B)
   uint32_t scan_slots = 512;         // matrix-core scan workgroups resident at once: 2 per CU (256 VGPRs x 4 waves each)
+  bool scan_queue = false;           // MI355_ICP_SCAN_QUEUE=1: matrix-core launches below queue_pairs draw their tiles from tickets (kXbLayoutQueue).
+                                     // OFF by default: measured SLOWER than the static cuts on every small shape (round 4: 100k<->100k 0.35 -> 0.59 ms per
+                                     // iteration, the request 1.86 -> 2.2 ms; profiles/r04g_queue_ab.txt, r04g_xb_timeline.txt) - a group of 4 tiles in the
+                                     // hands of the younger wave of a SIMD takes ~50 us, which is the launch's tail, and every draw stalls wave 0 on the
+                                     // ticket's round trip.  Kept as a tested layout (bit-identical results) for the next attempt: docs/LAB_NOTES.md 1.6
+  double queue_pairs = 5e10;          // ... launches below this many pairs draw their tiles from per-source-block tickets (MI355_ICP_QUEUE_PAIRS)
+  uint32_t queue_members = 0;        // MI355_ICP_QUEUE_MEMBERS: workgroups per source block in such a launch (0: by the launch's size)
+  uint32_t* xb_queue = nullptr; size_t xb_queue_cap = 0;  // [job][source block] x (ticket, members done): zero between launches
   bool level_sort = false;           // MI355_ICP_LEVEL_SORT=1: every pyramid level's sorted copy from a radix sort of its own (A/B)
   bool sort_sources = true;          // matrix-core scan: walk the sources in Morton order (MI355_ICP_SORT_SOURCES=0 turns it off: A/B)
 };
@@ -677,6 +687,21 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
     }
     model_split = true;
   }
+  // Launches of one to four rounds of resident workgroups: instead of static runs, the workgroups of a source block form a team
+  // that draws groups of tiles from the block's ticket (nn_scan_xbf16_kernel, kXbLayoutQueue) - about two workgroups per slot over
+  // the whole launch, never more members than a target has tile groups.
+  bool queue_split = false;
+  if (plan.xfilter && plan.xkind == 3 && c->scan_queue && c->xbf16_shape != 1 && !c->target_blocks_mfma_forced && total_pairs < c->queue_pairs && total_src_blocks) {
+    uint32_t groups = 0xFFFFFFFFu;
+    for (int k = 0; k < n_jobs; ++k) groups = std::min(groups, (tgt_clouds[target_ids ? target_ids[k] : 0].padded / kTile + kXbCentreGroup - 1) / kXbCentreGroup);
+    uint32_t members = c->queue_members ? c->queue_members : static_cast<uint32_t>((2ull * c->scan_slots + total_src_blocks - 1) / total_src_blocks);
+    members = std::min<uint32_t>(std::min<uint32_t>(members, 8u), groups);
+    if (members >= 2) {
+      want_split = members;
+      model_split = true;  // no XCD rounding of the count
+      queue_split = true;
+    }
+  }
   uint64_t out_off = 0, partial_off = 0;
   for (int k = 0; k < n_jobs; ++k) {
     const CloudEntry& S = src_clouds[source_ids ? source_ids[k] : 0];
@@ -742,13 +767,22 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   // One-round matrix-core launches of a uniform batch (a request's candidates): between one and two workgroups per CU.  The
   // first round's workgroups are served first by every SIMD's arbiter and walk a tile in less than half the time of the ones
   // that join them; give them 13/6 of the tiles (MI355_ICP_CLASS_SPLIT=0: equal runs, A/B).
-  if (model_split && c->class_split && n_jobs <= 8) {
+  if (queue_split) {
+    plan.queued = true;
+    for (const JobDesc& J : plan.jobs) {
+      plan.grid3_x = std::max(plan.grid3_x, J.scan_blocks);
+      plan.grid3_z = std::max(plan.grid3_z, J.n_split);
+    }
+  }
+  if (model_split && !queue_split && c->class_split && n_jobs <= 8) {
     const JobDesc& J0 = plan.jobs[0];
     bool uniform = J0.n_split >= 2 && J0.tgt_tiles >= 4 * J0.n_split;
     for (const JobDesc& J : plan.jobs) uniform = uniform && J.scan_blocks == J0.scan_blocks && J.n_split == J0.n_split && J.tgt_tiles == J0.tgt_tiles;
     const uint64_t wgs = static_cast<uint64_t>(J0.scan_blocks) * J0.n_split * static_cast<uint64_t>(n_jobs);
     if (uniform && wgs > c->scan_slots / 2 && wgs <= c->scan_slots) {
       plan.classed = true;
+      plan.grid3_x = J0.scan_blocks;
+      plan.grid3_z = J0.n_split;
       for (JobDesc& J : plan.jobs) J.first_class = c->scan_slots / 2;
     }
   }
@@ -760,7 +794,7 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   if (c->plan_debug)
     std::fprintf(stderr, "mi355_icp plan: %d jobs, %.3g pairs, pruned %d fused %d xkind %d ppl %d, source blocks %llu, want_split %u%s -> split %u, %u workgroups x %d, sub_split %u\n",
                  n_jobs, total_pairs, int(plan.pruned), int(plan.fused), plan.xkind, plan.scan_ppl, static_cast<unsigned long long>(total_src_blocks), want_split,
-                 model_split ? " (model)" : "", plan.jobs[0].n_split, plan.max_blocks_x, n_jobs, plan.jobs[0].sub_split);
+                 queue_split ? " (queue)" : model_split ? " (model)" : "", plan.jobs[0].n_split, plan.max_blocks_x, n_jobs, plan.jobs[0].sub_split);
   return MI355_ICP_OK;
 }
 
@@ -987,14 +1021,27 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
     const size_t st = xstride;
     const int ppl = plan.scan_ppl == 2 ? 2 : 4;  // the MFMA kernel spans 128 * {4, 8} points per workgroup
     if (bx && plan.xkind == 3) {
-      // one-round launches: the class-weighted layout (JobDesc::first_class) needs the self-staged kernel and every active
-      // job to hold the plan's tag (the planner sets it on uniform batches only)
-      bool classed = self_staged && plan.classed;
-      for (int k = 0; k < n_active && classed; ++k) classed = staged->jobs[k].first_class != 0;
-      if (self_staged && !classed)
-        for (int k = 0; k < n_active; ++k) const_cast<StageArgs*>(staged)->jobs[k].first_class = 0;
+      // The launch's layout is decided HERE, once, and travels as the kernel's template argument: static runs (2-D grid), or the
+      // 3-D grid of the class-weighted layout (one-round launches; needs the self-staged kernel and every ACTIVE job to be one
+      // of the plan's uniform batch) or of the ticket queue (any subset of the plan's jobs: a team is a source block of a job).
+      int layout = kXbLayoutStatic;
+      if (plan.queued && c->xbf16_shape != 1) {
+        layout = kXbLayoutQueue;
+        const size_t words = 2 * static_cast<size_t>(plan.grid3_x) * static_cast<size_t>(n_active);
+        if (words > c->xb_queue_cap) {
+          if (c->xb_queue) { HIP_TRY(c, hipFree(c->xb_queue)); c->xb_queue = nullptr; c->xb_queue_cap = 0; }
+          HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->xb_queue), 2 * words * sizeof(uint32_t)));
+          HIP_TRY(c, hipMemsetAsync(c->xb_queue, 0, 2 * words * sizeof(uint32_t), c->stream));  // every launch leaves its words zeroed again
+          c->xb_queue_cap = 2 * words;
+        }
+      } else if (self_staged && plan.classed) {
+        layout = kXbLayoutClassed;
+        for (int k = 0; k < n_active; ++k)
+          if (staged->jobs[k].first_class == 0 || staged->jobs[k].scan_blocks != plan.grid3_x || staged->jobs[k].n_split != plan.grid3_z) layout = kXbLayoutStatic;
+      }
       launch_nn_scan_xbf16(c->stream, c->jobs_dev, n_active, bx, Sscan, X.bf, X.bf_table, c->keys3, plan.out_total, rank_stride, c->xbf16_shape,
-                           self_staged ? staged : nullptr, c->jobs_dev, staged && staged->has_ref ? c->rjobs_dev : nullptr, classed);
+                           self_staged ? staged : nullptr, c->jobs_dev, staged && staged->has_ref ? c->rjobs_dev : nullptr, layout, plan.grid3_x,
+                           plan.grid3_z, c->xb_queue);
     } else if (bx && plan.xkind == 0) {
       launch_nn_scan_xfilter(c->stream, plan.scan_ppl, c->jobs_dev, n_active, bx, S, xp, xp + st, xp + 2 * st, xp + 3 * st,
                              X.table, c->keys3, plan.out_total, rank_stride);
@@ -1764,6 +1811,9 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   if (const char* v = std::getenv("MI355_ICP_SPLIT_MODEL_PAIRS")) c->split_model_pairs = std::atof(v);
   c->plan_debug = env_u32("MI355_ICP_PLAN_DEBUG", 0) != 0;
   if (const char* v = std::getenv("MI355_ICP_CLASS_SPLIT")) c->class_split = std::atoi(v) != 0;
+  if (const char* v = std::getenv("MI355_ICP_SCAN_QUEUE")) c->scan_queue = std::atoi(v) != 0;
+  if (const char* v = std::getenv("MI355_ICP_QUEUE_PAIRS")) c->queue_pairs = std::atof(v);
+  c->queue_members = env_u32("MI355_ICP_QUEUE_MEMBERS", 0);
   if (const char* v = std::getenv("MI355_ICP_FILTER_PAIRS")) c->filter_pairs = std::atof(v);
   {
     const uint32_t wp = env_u32("MI355_ICP_RESOLVE_WAVE_POINTS", 0);
@@ -1851,6 +1901,7 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   (void)hipFree(c->xt_box);
   (void)hipFree(c->xt_temp);
   (void)hipFree(c->keys3);
+  (void)hipFree(c->xb_queue);
   (void)hipFree(c->overflow_list);
   (void)hipFree(c->overflow_count);
   if (c->overflow_count_host) (void)hipHostFree(c->overflow_count_host);

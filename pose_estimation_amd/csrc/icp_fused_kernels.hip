@@ -616,7 +616,20 @@ __device__ __forceinline__ uint32_t min16(const f32x16& acc, uint32_t seed) {
 __device__ unsigned long long* g_diag_xb = nullptr;
 #endif
 
-template <int kSets, int kThreads, bool kDump = false, bool kStaged = false>
+// kLayout: how the launch's workgroups map to (source block, run of tiles) - chosen ONCE, by the launcher, for the whole launch:
+//   0  grid (scan_blocks * n_split, jobs): workgroup b walks the static run b % n_split of source block b / n_split
+//   1  grid (scan_blocks, jobs, n_split), kStaged only: static runs sized by the class of the workgroup (JobDesc::first_class)
+//   2  grid (scan_blocks, jobs, n_split): the n_split workgroups of a source block form a TEAM that draws groups of kXbCentreGroup
+//      tiles from the block's ticket (queue[2 * team]) until the target is walked.  Launches of one to four rounds of resident
+//      workgroups are decided by their last round and, inside a CU, by the SIMD arbiter serving the older wave first (a tile
+//      takes 4.4 us for it and ~12 us for the younger one: tools/xb_timeline.py); with the split as the slow grid index every
+//      team has a member in the launch's first round and whoever is served faster simply draws more.  Each member still
+//      publishes its own key rows (the top three granules of the tiles IT walked); the resolve merges the rows of a point like
+//      so many splits, and since it settles every point with the exact formula, WHICH member walked which tiles - the one thing
+//      that now differs from run to run - cannot reach an output (it moves points between "settled by the filter" and "settled
+//      by the overflow pass", both exact).  A ticket is drawn one group ahead (the next tile's global->LDS transfer starts a
+//      tile early), the last member out clears the team's two words for the next launch.
+template <int kSets, int kThreads, bool kDump = false, bool kStaged = false, int kLayout = 0>
 __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDesc* __restrict__ jobs,
                                                                        const float* __restrict__ sx,
                                                                        const float* __restrict__ sy,
@@ -627,7 +640,10 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
                                                                        uint32_t key_stride, uint32_t rank_stride,
                                                                        float* __restrict__ dump = nullptr, uint32_t dump_stride = 0,
                                                                        StageArgs staged = StageArgs{}, JobDesc* __restrict__ jobs_out = nullptr,
-                                                                       RefJobDesc* __restrict__ rjobs_out = nullptr) {
+                                                                       RefJobDesc* __restrict__ rjobs_out = nullptr, uint32_t* __restrict__ queue = nullptr) {
+  static_assert(kLayout == 0 || kLayout == 2 || kStaged, "the class-weighted layout reads its descriptor from the kernel arguments");
+  constexpr bool kQueue = kLayout == 2;
+  __shared__ uint32_t q_next;  // kQueue: the group of tiles drawn ahead (written by thread 0, read by all behind a barrier)
   // [buffer][k half][row slot]: 2 x 32 KiB, + slots the fragment prefetch of a tile's last-but-one step runs into (it reads
   // blocks 31 and 32; block 32 does not exist and what is read there is never used: the tile's final step issues no MFMA for it)
   constexpr uint32_t kLdsPad = 96;
@@ -654,14 +670,26 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
   // workgroups of the launch's first round - one per CU, the older wave on every SIMD, which the SIMD's arbiter serves first -
   // are whole planes of the grid, and a source block's runs of tiles are sized by the class of the workgroup that walks them:
   // both workgroups of a CU then finish together instead of the younger one walking its last third alone (tools/xb_timeline.py)
-  const bool classed = kStaged && J.first_class != 0;
-  const uint32_t sb = classed ? blockIdx.x : blockIdx.x / n_split;
-  const uint32_t sp = classed ? blockIdx.z : blockIdx.x - sb * n_split;
+  constexpr bool classed = kLayout == 1;
+  const uint32_t sb = kLayout != 0 ? blockIdx.x : blockIdx.x / n_split;
+  const uint32_t sp = kLayout != 0 ? blockIdx.z : blockIdx.x - sb * n_split;
   if (sb >= J.scan_blocks || sp >= n_split) return;
   constexpr uint32_t kScanSrcPerBlock = (kThreads / 64) * 32 * kSets;
   uint32_t tile0 = sp * J.split_q + (sp < J.split_r ? sp : J.split_r);
   uint32_t tile1 = tile0 + J.split_q + (sp < J.split_r ? 1u : 0u);
-  if (classed) {
+  // kQueue: the team's two words (ticket, members done) and the number of tile groups there are to draw
+  uint32_t* const team = kQueue ? queue + 2 * (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) : nullptr;
+  const uint32_t n_groups = (J.tgt_tiles + kXbCentreGroup - 1) / kXbCentreGroup;
+  if constexpr (kQueue) {
+    if (threadIdx.x == 0) q_next = atomicAdd(team, 1u);
+    __syncthreads();
+    const uint32_t g0 = __builtin_amdgcn_readfirstlane(q_next);
+    __syncthreads();  // everybody has read the first ticket before thread 0 draws the next one
+    tile0 = g0 < n_groups ? g0 * kXbCentreGroup : 0u;
+    tile1 = g0 < n_groups ? (tile0 + kXbCentreGroup < J.tgt_tiles ? tile0 + kXbCentreGroup : J.tgt_tiles) : 0u;  // empty: nothing left for this member
+    if (g0 < n_groups && threadIdx.x == 0) q_next = atomicAdd(team, 1u);  // one group ahead; first read behind the first tile's barrier
+  }
+  if constexpr (classed) {
     const uint32_t plane = gridDim.x * gridDim.y, at = blockIdx.y * gridDim.x + blockIdx.x;
     uint32_t before = 0, mine = 0, total = 0;
     for (uint32_t k = 0; k < n_split; ++k) {
@@ -697,9 +725,11 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
   }
   const uint32_t tile_base = J.tgt_off / kTile;  // tgt_off is a multiple of kTile
   const uint4* __restrict__ image = bf_image + static_cast<size_t>(tile_base) * kXbTileVecs;
+  if (!kQueue || tile0 < tile1) {
 #pragma unroll
-  for (int k = 0; k < kXbTileVecs / kThreads; ++k)
-    lds[k * kThreads + tid] = image[static_cast<size_t>(tile0) * kXbTileVecs + k * kThreads + tid];
+    for (int k = 0; k < kXbTileVecs / kThreads; ++k)
+      lds[k * kThreads + tid] = image[static_cast<size_t>(tile0) * kXbTileVecs + k * kThreads + tid];
+  }
   __syncthreads();
 #ifdef MI355_ICP_DIAG
   const unsigned long long diag_t1 = wall_clock64();
@@ -723,16 +753,29 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
 #ifdef MI355_ICP_DIAG
   unsigned long long diag_q[3] = {0, 0, 0};  // the walk's quarter points
 #endif
-  for (uint32_t tile = tile0; tile < tile1; ++tile) {
+  [[maybe_unused]] uint32_t tiles_walked = 0;  // (diagnostics; kQueue: what this member drew)
+  for (uint32_t tile = tile0; tile < tile1;) {
 #ifdef MI355_ICP_DIAG
-    {
+    if constexpr (!kQueue) {
       const uint32_t done = tile - tile0, all = tile1 - tile0;
       if (done == all / 4) diag_q[0] = wall_clock64();
       if (done == all / 2) diag_q[1] = wall_clock64();
       if (done == all - all / 4) diag_q[2] = wall_clock64();
     }
 #endif
-    const bool more = tile + 1 < tile1;
+    ++tiles_walked;
+    uint32_t next_tile = tile + 1, next_end = tile1;
+    bool more = next_tile < tile1;
+    if constexpr (kQueue) {
+      if (!more) {  // the group's last tile: on to the group drawn ahead, if the target is not walked yet
+        const uint32_t gn = __builtin_amdgcn_readfirstlane(q_next);
+        if (gn < n_groups) {
+          more = true;
+          next_tile = gn * kXbCentreGroup;
+          next_end = next_tile + kXbCentreGroup < J.tgt_tiles ? next_tile + kXbCentreGroup : J.tgt_tiles;
+        }
+      }
+    }
     // The operand image of kXbCentreGroup consecutive tiles shares one centre and one r^2 (xtarget_kernels.hip): the
     // source points are re-split into bf16 pieces at the first tile of the walk and whenever a new group begins
     if (tile == tile0 || tile % kXbCentreGroup == 0) {
@@ -775,7 +818,7 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
     // the whole next tile, asynchronously: the barrier that ended the previous tile says every wave is done reading the
     // other buffer; the __syncthreads() at the end of this tile waits for these (vmcnt(0)) before anyone reads it
     if (more) {
-      const uint4* __restrict__ next = image + static_cast<size_t>(tile + 1) * kXbTileVecs;
+      const uint4* __restrict__ next = image + static_cast<size_t>(next_tile) * kXbTileVecs;
 #pragma unroll
       for (int k = 0; k < kXbTileVecs / kThreads; ++k)
         __builtin_amdgcn_global_load_lds(next + k * kThreads + tid, &lds[(cur ^ 1) * kXbTileVecs + k * kThreads + wave * 64], 16, 0, 0);
@@ -864,6 +907,22 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
     }
     __syncthreads();
     cur ^= 1;
+    if constexpr (kQueue) {
+      if (!more) break;
+      if (next_tile != tile + 1) {  // a new group begins: draw the one behind it (everybody read q_next before the barrier above)
+        if (threadIdx.x == 0) q_next = atomicAdd(team, 1u);
+        if (next_end - next_tile == 1) __syncthreads();  // a one-tile group reads the ticket at once: no tile barrier in between
+      }
+      tile1 = next_end;
+    }
+    tile = next_tile;
+  }
+  if constexpr (kQueue) {
+    // last member out clears the team's words for the next launch (every member has made its last draw by then)
+    if (threadIdx.x == 0 && atomicAdd(team + 1, 1u) + 1u == n_split) {
+      __hip_atomic_store(team, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(team + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 #ifdef MI355_ICP_DIAG
   const unsigned long long diag_t2 = wall_clock64();
@@ -891,7 +950,7 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
     g_diag_xb[slot + 5] = diag_q[0];
     g_diag_xb[slot + 6] = diag_q[1];
     g_diag_xb[slot + 7] = diag_q[2];
-    g_diag_xb[slot + 4] = (static_cast<unsigned long long>(tile1 - tile0) << 48) | (static_cast<unsigned long long>(blockIdx.y & 0xffu) << 40) |
+    g_diag_xb[slot + 4] = (static_cast<unsigned long long>(tiles_walked) << 48) | (static_cast<unsigned long long>(blockIdx.y & 0xffu) << 40) |
                            (static_cast<unsigned long long>(xcc & 0xf) << 32) | hwid;
   }
 #endif
@@ -917,17 +976,32 @@ extern "C" int mi355_icp_diag_xb_read(unsigned long long* out, size_t n_slots) {
 
 // a workgroup spans 512 source points either way (the planner's 2 points per lane); shape 0 = <4 sets, 256 threads> (default),
 // 1 = <2 sets, 512 threads> (1.4 % slower: profiles/r02b_scan_ab_lds_dma.txt)
+// layout: XbLayout of the WHOLE launch (the kernel's kLayout) - the one place it is decided is the caller (run_fused_index_phase);
+// layouts 1 and 2 launch the 3-D grid (grid3_x source blocks, jobs, grid3_z splits), layout 2 needs `queue` (2 zeroed words per
+// (job, source block) of that grid; the launch leaves them zeroed)
 void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
                           const void* bf_image, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
-                          uint32_t rank_stride, int shape, const StageArgs* staged, JobDesc* jobs_out, RefJobDesc* rjobs_out, bool classed) {
+                          uint32_t rank_stride, int shape, const StageArgs* staged, JobDesc* jobs_out, RefJobDesc* rjobs_out, int layout,
+                          uint32_t grid3_x, uint32_t grid3_z, uint32_t* queue) {
   if (!max_blocks_x) return;
   dim3 grid(max_blocks_x, static_cast<uint32_t>(n_jobs));
-  if (staged && shape != 1 && classed)  // JobDesc::first_class: (source blocks, jobs, splits) - the same for every job of the launch
-    grid = dim3(staged->jobs[0].scan_blocks, static_cast<uint32_t>(n_jobs), staged->jobs[0].n_split);
+  if (layout != kXbLayoutStatic) grid = dim3(grid3_x, static_cast<uint32_t>(n_jobs), grid3_z);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const uint4* image = static_cast<const uint4*>(bf_image);
+  const float4* table = static_cast<const float4*>(tile_table);
   if (staged && shape != 1) {  // small passes: this launch stages the descriptors itself
-    hipLaunchKernelGGL((nn_scan_xbf16_kernel<4, 256, false, true>), grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x,
-                       src.y, src.z, static_cast<const uint4*>(bf_image), static_cast<const float4*>(tile_table), keys4, key_stride,
-                       rank_stride, nullptr, 0u, *staged, jobs_out, rjobs_out);
+    auto go = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, image, table, keys4, key_stride, rank_stride,
+                         nullptr, 0u, *staged, jobs_out, rjobs_out, queue);
+    };
+    if (layout == kXbLayoutQueue) go(nn_scan_xbf16_kernel<4, 256, false, true, kXbLayoutQueue>);
+    else if (layout == kXbLayoutClassed) go(nn_scan_xbf16_kernel<4, 256, false, true, kXbLayoutClassed>);
+    else go(nn_scan_xbf16_kernel<4, 256, false, true, kXbLayoutStatic>);
+    return;
+  }
+  if (layout == kXbLayoutQueue && shape != 1) {
+    hipLaunchKernelGGL((nn_scan_xbf16_kernel<4, 256, false, false, kXbLayoutQueue>), grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z,
+                       image, table, keys4, key_stride, rank_stride, nullptr, 0u, StageArgs{}, nullptr, nullptr, queue);
     return;
   }
   if (shape == 1)

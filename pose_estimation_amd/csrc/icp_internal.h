@@ -113,7 +113,8 @@ struct JobDesc {
                              // targets x 512 source slots: tens of microseconds on one CU whatever the cloud holds, which is
                              // what a pass costs on the coarse pyramid levels of reference mode unless it is cut finer.
   uint32_t src_n_total;      // slab-sharded reference mode: points of the WHOLE level cloud over all ranks (0 = src_n)
-  uint32_t first_class;      // matrix-core scan of a ONE-ROUND launch (self-staged kernel only; 0 = off): the launch's grid is
+  uint32_t first_class;      // matrix-core scan launched with kXbLayoutClassed (a ONE-ROUND launch, self-staged kernel; the layout is
+                             // the LAUNCH's, decided by the launcher - this field only parametrises it): the grid is
                              // (scan_blocks, jobs, n_split) and the first `first_class` workgroups in grid order - one per CU,
                              // the older wave on every SIMD - get kClassFast / kClassSlow times the tiles of the later ones
 };
@@ -385,10 +386,13 @@ void launch_nn_scan_xmfma(void* stream, int points_per_lane, const JobDesc* jobs
                           uint32_t first_block, DevicePlanes src, const float* tcx, const float* tcy, const float* tcz,
                           const float* tt, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
                           uint32_t rank_stride);
+// how a matrix-core scan launch maps workgroups to (source block, run of tiles): nn_scan_xbf16_kernel's kLayout
+constexpr int kXbLayoutStatic = 0, kXbLayoutClassed = 1, kXbLayoutQueue = 2;
 void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_blocks_x, DevicePlanes src,
                           const void* bf_image, const void* tile_table, unsigned long long* keys4, uint32_t key_stride,
                           uint32_t rank_stride, int shape, const StageArgs* staged = nullptr, JobDesc* jobs_out = nullptr,
-                          RefJobDesc* rjobs_out = nullptr, bool classed = false);
+                          RefJobDesc* rjobs_out = nullptr, int layout = kXbLayoutStatic, uint32_t grid3_x = 0, uint32_t grid3_z = 0,
+                          uint32_t* queue = nullptr);
 void launch_nn_scan_xbf16_dump(void* stream, const JobDesc* jobs_dev, uint32_t blocks_x, DevicePlanes src, const void* bf_image,
                                const void* tile_table, unsigned long long* keys4, uint32_t key_stride, uint32_t rank_stride,
                                float* dump, uint32_t dump_stride);
