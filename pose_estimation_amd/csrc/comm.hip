@@ -112,6 +112,28 @@ int comm_sum_f64_rank_order(CommState& cs, double* dev_buf, size_t count, void* 
   return hip_fail(hipGetLastError(), err);
 }
 
+// The same sum for rows that are ALREADY on the host (a pass that ended itself wrote them to pinned memory: PassTail) - external
+// transports only: one all-gather through the caller's callback, no device copy in either direction.  A rank whose pass did not end
+// itself makes the device-side call above instead; both are one all-gather of count doubles per rank, so they match.
+int comm_sum_f64_rank_order_host(CommState& cs, double* host_buf, size_t count, const char** err) {
+  if (!cs.ext || count == 0) return MI355_ICP_OK;
+  const size_t bytes = count * sizeof(double);
+  const int st = ensure_stage(cs, bytes, bytes * static_cast<size_t>(cs.size), err);
+  if (st != MI355_ICP_OK) return st;
+  std::memcpy(cs.stage_send, host_buf, bytes);
+  if (cs.ext(cs.ext_user, cs.stage_send, cs.stage_recv, bytes) != 0) {
+    if (err) *err = "the caller's all-gather reported a failure";
+    return MI355_ICP_ERR_COMM;
+  }
+  const double* in = reinterpret_cast<const double*>(cs.stage_recv);
+  for (size_t i = 0; i < count; ++i) {
+    double acc = in[i];
+    for (int r = 1; r < cs.size; ++r) acc += in[static_cast<size_t>(r) * count + i];
+    host_buf[i] = acc;
+  }
+  return MI355_ICP_OK;
+}
+
 int comm_sum_u32(CommState& cs, uint32_t* dev_buf, size_t count, void* stream, const char** err) {
   if (!cs.attached() || count == 0) return MI355_ICP_OK;
   if (cs.ext) return external_reduce(cs, dev_buf, count, stream, err, [](uint32_t a, uint32_t b) { return a + b; });

@@ -1173,7 +1173,10 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
     return fail(c, MI355_ICP_ERR_INTERNAL, "work buffers are smaller than the plan (ensure_buffers not run for this plan)");
   // single GPU, align loop: the accumulation launch ends the pass by itself (PassTail)
   const bool exchange = c->comm.attached() && !local_only;
-  const PassTail tail = make_pass_tail(c, plan, n_active, sbx, tail_allowed && !exchange, defer, c->p2p_done, c->sums_mapped);
+  // an external transport (gloo in the tests; the in-process exchange of a multi-device handle) meets on the HOST anyway: the pass
+  // may end itself and the rows are exchanged where finish_pass left them - no device-to-host-to-device round trip around the callback
+  const bool host_exchange = exchange && c->comm.ext != nullptr;
+  const PassTail tail = make_pass_tail(c, plan, n_active, sbx, tail_allowed && (!exchange || host_exchange), defer, c->p2p_done, c->sums_mapped);
   const bool tail_on = tail.done != nullptr;
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (plan.pruned) {
@@ -1202,7 +1205,7 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
   HIP_TRY(c, hipGetLastError());
   const size_t n_sums = static_cast<size_t>(n_active) * MI355_ICP_NSUMS, n_act = static_cast<size_t>(n_active);
-  if (exchange) {  // the rows and the flags: every rank learns whether ANY rank's device-side overflow pass was too small
+  if (exchange && !tail_on) {  // the rows and the flags: every rank learns whether ANY rank's device-side overflow pass was too small
     const char* why = nullptr;
     const int cst = comm_sum_f64_rank_order(c->comm, c->sums_dev, n_sums + n_act, c->stream, &why);
     if (cst != MI355_ICP_OK) return fail(c, cst == MI355_ICP_ERR_HIP ? MI355_ICP_ERR_HIP : MI355_ICP_ERR_COMM, std::string("cross-rank exchange: ") + (why ? why : "?"));
@@ -1211,6 +1214,11 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
     if (const int sst = wait_pass(c, tail.seq, n_active, &c->error_word); sst != MI355_ICP_OK) return sst;
     c->error_word_known = true;
     if (profile) HIP_TRY(c, hipStreamSynchronize(c->stream));  // the events are read below
+    if (exchange) {  // host_exchange: the same rows and flags, summed in rank order where the pass left them
+      const char* why = nullptr;
+      const int cst = comm_sum_f64_rank_order_host(c->comm, c->sums_host, n_sums + n_act, &why);
+      if (cst != MI355_ICP_OK) return fail(c, cst, std::string("cross-rank exchange: ") + (why ? why : "?"));
+    }
   } else {
     HIP_TRY(c, hipMemcpyAsync(c->sums_host, c->sums_dev, (n_sums + 2 * n_act) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (const int sst = sync_pass(c); sst != MI355_ICP_OK) return sst;
@@ -1552,7 +1560,8 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, const RefLevel& level,
     HIP_TRY(c, hipMemcpyAsync(c->thr_dev, c->thr_host, static_cast<size_t>(n_active) * sizeof(float), hipMemcpyHostToDevice, c->stream));
   }
   // single GPU: the accumulate launch ends the pass by itself (PassTail)
-  const PassTail tail = make_pass_tail(c, plan, n_active, sbx, !sharded, defer, c->pass_done, c->ref_sums_mapped);
+  const bool host_exchange = sharded && c->comm.ext != nullptr;  // see run_pass_once
+  const PassTail tail = make_pass_tail(c, plan, n_active, sbx, !sharded || host_exchange, defer, c->pass_done, c->ref_sums_mapped);
   const bool tail_on = tail.done != nullptr;
   if (sbx || sharded) {
     if (sbx && !scattered) launch_picky_scatter(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, c->out_index, c->out_dist2, c->thr_dev, c->owner);
@@ -1569,7 +1578,7 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, const RefLevel& level,
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   HIP_TRY(c, hipGetLastError());
   const size_t n_sums = static_cast<size_t>(n_active) * kRefSums, n_act = static_cast<size_t>(n_active);
-  if (sharded) {
+  if (sharded && !tail_on) {
     const int cst = comm_sum_f64_rank_order(c->comm, c->ref_sums_dev, n_sums + n_act, c->stream, &why);
     if (cst != MI355_ICP_OK) return fail(c, cst == MI355_ICP_ERR_HIP ? MI355_ICP_ERR_HIP : MI355_ICP_ERR_COMM, std::string("cross-rank exchange: ") + (why ? why : "?"));
   }
@@ -1577,6 +1586,10 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, const RefLevel& level,
     if (const int sst = wait_pass(c, tail.seq, n_active, &c->error_word); sst != MI355_ICP_OK) return sst;
     c->error_word_known = true;
     if (profile) HIP_TRY(c, hipStreamSynchronize(c->stream));  // the events are read below
+    if (sharded) {
+      const int cst = comm_sum_f64_rank_order_host(c->comm, c->ref_sums_host, n_sums + n_act, &why);
+      if (cst != MI355_ICP_OK) return fail(c, cst, std::string("cross-rank exchange: ") + (why ? why : "?"));
+    }
   } else {
     HIP_TRY(c, hipMemcpyAsync(c->ref_sums_host, c->ref_sums_dev, (n_sums + 3 * n_act) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (const int sst = sync_pass(c); sst != MI355_ICP_OK) return sst;

@@ -533,6 +533,7 @@ struct CommState {
 };
 // dev_buf[0..count) <- sum over ranks r = 0, 1, ... (in that order) of rank r's dev_buf.  Returns an mi355_icp_status.
 int comm_sum_f64_rank_order(CommState& cs, double* dev_buf, size_t count, void* stream, const char** err);
+int comm_sum_f64_rank_order_host(CommState& cs, double* host_buf, size_t count, const char** err);  // external transports: rows already on the host
 int comm_sum_u32(CommState& cs, uint32_t* dev_buf, size_t count, void* stream, const char** err);
 int comm_min_u64(CommState& cs, unsigned long long* dev_buf, size_t count, void* stream, const char** err);
 // host-side all-gather of a few bytes per rank (cloud sizes at the start of a sharded reference-mode call)
