@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 
 #include "icp_internal.h"
@@ -792,8 +793,18 @@ bool launch_rejection_select(void* stream, const JobDesc* jobs_dev, int n_jobs, 
     return scatter;
   }
   if (max_n < 65536u || !hists) {
-    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(rejection_select_kernel),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+    // the attribute belongs to the DEVICE the kernel is loaded on: asked once per device (a multi-device handle launches this
+    // from one thread per device, each with its own current device)
+    static std::atomic<unsigned long long> asked{0}, granted{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (static_cast<unsigned>(dev) & 63u);
+    if (!(asked.load(std::memory_order_acquire) & bit)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(rejection_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess)
+        granted.fetch_or(bit, std::memory_order_release);
+      asked.fetch_or(bit, std::memory_order_release);
+    }
+    const bool big_lds = (granted.load(std::memory_order_acquire) & bit) != 0;
     const uint32_t cache_n = std::min<uint32_t>(max_n, big_lds ? 32768u : 12288u);
     // one workgroup offering 20k pairs takes longer than the launch it saves (26 + 7 -> 58 us); a few thousand do not
     const bool scatter = rjobs_dev && index && owner && max_n <= 4096u;
