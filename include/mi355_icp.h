@@ -445,7 +445,8 @@ int mi355_icp_comm_unique_id(unsigned char out_id[MI355_ICP_UNIQUE_ID_BYTES]);
  * in rank order on every rank, so the sums - hence poses and convergence decisions - are bit-identical on all ranks
  * and do not depend on the collective algorithm RCCL picks.  Reference mode adds integer
  * collectives, exact in any order: six ncclAllReduce(sum, uint32) of a 2048-bin histogram per pass for the MAD
- * threshold and one ncclAllReduce(min, uint64) of the picky owner table. */
+ * threshold, and for the picky dedupe either one ncclAllReduce(min, uint64) of the owner table or - when it is fewer bytes -
+ * one ncclAllGather of the (key, slot) pairs each rank offers, applied locally with atomicMin (the same table either way). */
 int mi355_icp_comm_attach(mi355_icp_ctx* ctx, const unsigned char id[MI355_ICP_UNIQUE_ID_BYTES], int rank,
                           int n_ranks);
 

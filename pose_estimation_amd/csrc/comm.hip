@@ -146,6 +146,22 @@ int comm_min_u64(CommState& cs, unsigned long long* dev_buf, size_t count, void*
   return rccl_allreduce_u64_min(cs.rccl, dev_buf, count, stream, err);
 }
 
+int comm_allgather_device(CommState& cs, const void* dev_send, void* dev_recv, size_t bytes_per_rank, void* stream, const char** err) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!cs.attached()) return hip_fail(hipMemcpyAsync(dev_recv, dev_send, bytes_per_rank, hipMemcpyDeviceToDevice, s), err);
+  if (!cs.ext) return rccl_allgather_bytes(cs.rccl, dev_send, dev_recv, bytes_per_rank, stream, err);
+  const size_t total = bytes_per_rank * static_cast<size_t>(cs.size);
+  int st = ensure_stage(cs, bytes_per_rank, total, err);
+  if (st != MI355_ICP_OK) return st;
+  if ((st = hip_fail(hipMemcpyAsync(cs.stage_send, dev_send, bytes_per_rank, hipMemcpyDeviceToHost, s), err)) != MI355_ICP_OK) return st;
+  if ((st = hip_fail(hipStreamSynchronize(s), err)) != MI355_ICP_OK) return st;
+  if (cs.ext(cs.ext_user, cs.stage_send, cs.stage_recv, bytes_per_rank) != 0) {
+    if (err) *err = "the caller's all-gather reported a failure";
+    return MI355_ICP_ERR_COMM;
+  }
+  return hip_fail(hipMemcpyAsync(dev_recv, cs.stage_recv, total, hipMemcpyHostToDevice, s), err);
+}
+
 int comm_allgather_host(CommState& cs, const void* send, void* recv, size_t bytes_per_rank, void* stream, const char** err) {
   if (!cs.attached()) {
     std::memcpy(recv, send, bytes_per_rank);

@@ -202,6 +202,8 @@ struct mi355_icp_ctx {
 
   // reference-mode work buffers
   unsigned long long* owner = nullptr; size_t owner_cap = 0;
+  unsigned long long* offer_block = nullptr; unsigned long long* offer_all = nullptr; size_t offer_words_cap = 0;  // slab-sharded: this rank's offer list / all ranks'
+  bool picky_offers = true;            // MI355_ICP_PICKY_OFFERS=0: always min-reduce the whole owner table across ranks (A/B)
   uint32_t owner_epoch = 0;  // pass tag of the picky owner keys (picky_key): 1..63, 0 = the table must be cleared first
   uint8_t* selected = nullptr;         size_t selected_cap = 0;
   double* ref_partials = nullptr;      size_t ref_partials_cap = 0;
@@ -1421,6 +1423,8 @@ DevicePlanes level_view(const CloudSet& set, int slot) { return slot ? set.level
 struct RefLevel {
   int sslot = 0, tslot = 0;  // level_slot of the sources / of the targets for the level's step
   bool upstream = false;     // MI355_ICP_FLAG_UPSTREAM: model rows with normals, plane equations about RefJobDesc::centre
+  uint32_t offer_cap = 0;    // slab-sharded: the most level points any rank holds over the jobs of this level (every rank computes the
+                             // same number from the slab geometry): the size of a rank's offer list, see run_ref_pass_once
 };
 
 int ensure_ref_buffers(mi355_icp_ctx* c, const Plan& plan, size_t n_jobs, size_t owner_total) {
@@ -1564,10 +1568,32 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, const RefLevel& level,
   const PassTail tail = make_pass_tail(c, plan, n_active, sbx, !sharded || host_exchange, defer, c->pass_done, c->ref_sums_mapped);
   const bool tail_on = tail.done != nullptr;
   if (sbx || sharded) {
-    if (sbx && !scattered) launch_picky_scatter(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, c->out_index, c->out_dist2, c->thr_dev, c->owner);
-    if (sharded) {  // targets are replicated: the owner of a target is the smallest key any rank offered
-      const int cst = comm_min_u64(c->comm, c->owner, std::max<size_t>(owner_total, 1), c->stream, &why);
-      if (cst != MI355_ICP_OK) return fail(c, cst, std::string("cross-rank owner table: ") + (why ? why : "?"));
+    // Slab-sharded: targets are replicated, the owner of a target is the smallest key ANY rank offered.  Two exchanges give the
+    // same table: min-reducing the whole table (8 B x level targets), or all-gathering the ranks' OFFERS (16 B x the level points
+    // of the whole model) and applying them locally - bytes in proportion to the accepted points instead of the scene.  The
+    // cheaper one by bytes is taken; every rank computes the same sizes, hence the same choice.
+    const size_t offer_words = 1 + 2 * static_cast<size_t>(level.offer_cap);
+    const bool offers = sharded && c->picky_offers && level.offer_cap > 0 &&
+                        offer_words * sizeof(unsigned long long) * static_cast<size_t>(c->comm.size) < std::max<size_t>(owner_total, 1) * sizeof(unsigned long long);
+    if (offers) {
+      const size_t need = offer_words * (static_cast<size_t>(c->comm.size) + 1);
+      if (need > c->offer_words_cap) {
+        if (c->offer_block) { HIP_TRY(c, hipFree(c->offer_block)); c->offer_block = nullptr; c->offer_words_cap = 0; }
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->offer_block), 2 * need * sizeof(unsigned long long)));
+        c->offer_words_cap = 2 * need;
+      }
+      c->offer_all = c->offer_block + offer_words;
+      HIP_TRY(c, hipMemsetAsync(c->offer_block, 0, sizeof(unsigned long long), c->stream));
+      if (sbx) launch_picky_offer(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, c->out_index, c->out_dist2, c->thr_dev, c->owner, c->offer_block, level.offer_cap);
+      const int cst = comm_allgather_device(c->comm, c->offer_block, c->offer_all, offer_words * sizeof(unsigned long long), c->stream, &why);
+      if (cst != MI355_ICP_OK) return fail(c, cst, std::string("cross-rank picky offers: ") + (why ? why : "?"));
+      launch_picky_apply(c->stream, c->offer_all, static_cast<uint32_t>(offer_words), c->comm.size, c->comm.rank, level.offer_cap, c->owner);
+    } else {
+      if (sbx && !scattered) launch_picky_scatter(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, c->out_index, c->out_dist2, c->thr_dev, c->owner);
+      if (sharded) {
+        const int cst = comm_min_u64(c->comm, c->owner, std::max<size_t>(owner_total, 1), c->stream, &why);
+        if (cst != MI355_ICP_OK) return fail(c, cst, std::string("cross-rank owner table: ") + (why ? why : "?"));
+      }
     }
     if (sbx) launch_ref_accumulate(c->stream, c->jobs_dev, c->rjobs_dev, n_active, sbx, S, source_rows, target_rows, c->out_index,
                                    c->out_dist2, c->thr_dev, c->owner, c->want_selected ? c->selected : nullptr, c->ref_partials, tail);
@@ -1863,6 +1889,7 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->ready_mapped), c->ready_host, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
   std::memset(c->ready_host, 0, kReadyWords * sizeof(uint32_t));
   if (const char* v = std::getenv("MI355_ICP_PASS_TAIL")) c->pass_tail = std::atoi(v) != 0;
+  if (const char* v = std::getenv("MI355_ICP_PICKY_OFFERS")) c->picky_offers = std::atoi(v) != 0;
   if (const char* v = std::getenv("MI355_ICP_SERVICE_PRUNE")) c->service_prune = std::string(v) == "auto" ? -1 : (std::atoi(v) != 0 ? 1 : 0);
   if (const char* v = std::getenv("MI355_ICP_LEVEL_SORT")) c->level_sort = std::atoi(v) != 0;
   *out = c;
@@ -1924,6 +1951,7 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   (void)hipFree(c->jobs2_dev);
   if (c->jobs2_host) (void)hipHostFree(c->jobs2_host);
   (void)hipFree(c->owner);
+  (void)hipFree(c->offer_block);
   (void)hipFree(c->selected);
   (void)hipFree(c->ref_partials);
   (void)hipFree(c->ref_sums_dev);
@@ -2173,10 +2201,12 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
   // indices (the tie rule of the picky dedupe is "lowest source index": it must be the index in the WHOLE cloud).
   const bool sharded = c->comm.attached();
   std::vector<uint64_t> shard_begin, shard_total;
+  std::vector<uint32_t> all;  // sharded: every rank's (cloud count, slab sizes...)
   if (sharded) {
 
     const size_t n_clouds = c->sources.clouds.size();
-    std::vector<uint32_t> mine(n_clouds + 1), all((n_clouds + 1) * static_cast<size_t>(c->comm.size));
+    std::vector<uint32_t> mine(n_clouds + 1);
+    all.assign((n_clouds + 1) * static_cast<size_t>(c->comm.size), 0u);
     mine[0] = static_cast<uint32_t>(n_clouds);
     for (size_t k = 0; k < n_clouds; ++k) mine[k + 1] = c->sources.clouds[k].n;
     const char* why = nullptr;
@@ -2278,6 +2308,20 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
     lvl.tslot = level_slot(c->targets, step);
     lvl.upstream = upstream;
     if (lvl.sslot < 0 || lvl.tslot < 0) return fail(c, MI355_ICP_ERR_INTERNAL, "align_reference: a pyramid level is missing");
+    if (sharded) {  // the most level points any rank holds over this group's jobs (from the slab geometry: the same on every rank)
+      const size_t n_clouds = c->sources.clouds.size();
+      for (int r = 0; r < c->comm.size; ++r) {
+        uint64_t held = 0;
+        for (const int s_id : psid) {
+          uint64_t begin = 0;
+          for (int q = 0; q < r; ++q) begin += all[static_cast<size_t>(q) * (n_clouds + 1) + 1 + static_cast<size_t>(s_id)];
+          uint64_t f = 0, n_loc = 0, base = 0, n_all = 0;
+          level_slab(shard_total[static_cast<size_t>(s_id)], begin, all[static_cast<size_t>(r) * (n_clouds + 1) + 1 + static_cast<size_t>(s_id)], step, &f, &n_loc, &base, &n_all);
+          held += n_loc;
+        }
+        lvl.offer_cap = std::max<uint32_t>(lvl.offer_cap, static_cast<uint32_t>(std::min<uint64_t>(held, 0xFFFFFFF0ull)));
+      }
+    }
     auto level_total = [&](int s) -> uint64_t { return model_rows(s) / step; };  // points of the whole (all ranks) level cloud
     Plan plan;
     const int np = static_cast<int>(part.size());

@@ -449,6 +449,12 @@ void launch_select_pick(void* stream, const JobDesc* jobs_dev, int n_jobs, uint3
 void launch_picky_scatter(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs,
                           uint32_t max_src_blocks, const int32_t* index, const float* dist2, const float* thr,
                           unsigned long long* owner);
+// slab-sharded passes: this rank's offers as a list (block[0] = count, then {key, slot} records) beside the local atomicMin, and
+// the other ranks' gathered lists applied to this rank's table
+void launch_picky_offer(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs, uint32_t max_src_blocks, const int32_t* index,
+                        const float* dist2, const float* thr, unsigned long long* owner, unsigned long long* block, uint32_t capacity);
+void launch_picky_apply(void* stream, const unsigned long long* all, uint32_t block_words, int n_ranks, int my_rank, uint32_t capacity,
+                        unsigned long long* owner);
 // rows: 32 bytes per point of a pyramid level, (x, y, z, nx | ny, nz, 0, 0); normal of level-0 row normal_off + j * step
 void launch_target_rows(void* stream, DevicePlanes level, uint32_t level_off, uint32_t n, DevicePlanes normals, uint32_t normal_off,
                         uint32_t step, void* rows);
@@ -536,6 +542,8 @@ int comm_sum_f64_rank_order(CommState& cs, double* dev_buf, size_t count, void* 
 int comm_sum_f64_rank_order_host(CommState& cs, double* host_buf, size_t count, const char** err);  // external transports: rows already on the host
 int comm_sum_u32(CommState& cs, uint32_t* dev_buf, size_t count, void* stream, const char** err);
 int comm_min_u64(CommState& cs, unsigned long long* dev_buf, size_t count, void* stream, const char** err);
+// dev_recv[r * bytes_per_rank ...] <- rank r's dev_send (device buffers; enqueued on `stream`, external transports stage through the host)
+int comm_allgather_device(CommState& cs, const void* dev_send, void* dev_recv, size_t bytes_per_rank, void* stream, const char** err);
 // host-side all-gather of a few bytes per rank (cloud sizes at the start of a sharded reference-mode call)
 int comm_allgather_host(CommState& cs, const void* send, void* recv, size_t bytes_per_rank, void* stream, const char** err);
 void comm_release(CommState& cs);  // frees the staging buffers and destroys a native communicator

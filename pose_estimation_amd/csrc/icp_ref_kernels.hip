@@ -577,6 +577,61 @@ __global__ __launch_bounds__(kBlockThreads) void picky_scatter_kernel(const JobD
 }
 
 // ---------------------------------------------------------------------------------------------
+// Slab-sharded passes whose model is small against the scene: instead of min-reducing the WHOLE owner table across ranks
+// (8 B x level targets per pass), every rank lists the pairs it OFFERS (<= its accepted slab points), the lists are
+// all-gathered and every rank applies the others' offers to its own table.  atomicMin is order-free, so the table ends up the
+// same as under the table-wide reduction whatever order the lists are written and applied in.
+// block: [0] = number of records (as uint64), then records {key, owner slot}.  grid = (max src_blocks, n_jobs).
+__global__ __launch_bounds__(kBlockThreads) void picky_offer_kernel(const JobDesc* __restrict__ jobs, const RefJobDesc* __restrict__ rjobs,
+                                                                     const int32_t* __restrict__ index, const float* __restrict__ dist2,
+                                                                     const float* __restrict__ thr, unsigned long long* __restrict__ owner,
+                                                                     unsigned long long* __restrict__ block, uint32_t capacity) {
+  const JobDesc& J = jobs[blockIdx.y];
+  if (blockIdx.x >= J.src_blocks) return;
+  const float t = thr[blockIdx.y];
+  const RefJobDesc& RJ = rjobs[blockIdx.y];
+#pragma unroll
+  for (int p = 0; p < kResolvePointsPerLane; ++p) {
+    const uint32_t local = blockIdx.x * kSrcPerBlock + p * kBlockThreads + threadIdx.x;
+    if (local >= J.src_n) continue;
+    const float d = dist2[J.out_off + local];
+    if (!(d < t)) continue;
+    const uint32_t slot = RJ.owner_off + static_cast<uint32_t>(index[J.out_off + local]);
+    const unsigned long long key = picky_key(RJ.owner_prefix, d, RJ.src_index_base + local);
+    atomicMin(&owner[slot], key);
+    const unsigned long long at = atomicAdd(&block[0], 1ull);
+    if (at < capacity) {  // (the capacity covers every point of the slab: never exceeded)
+      block[1 + 2 * at] = key;
+      block[2 + 2 * at] = slot;
+    }
+  }
+}
+
+// all: n_ranks blocks of `block_words` uint64 each (the gathered lists); every record of every OTHER rank is offered to this
+// rank's table.  grid = (ceil(capacity / 256), n_ranks).
+__global__ __launch_bounds__(kBlockThreads) void picky_apply_kernel(const unsigned long long* __restrict__ all, uint32_t block_words, int my_rank,
+                                                                     uint32_t capacity, unsigned long long* __restrict__ owner) {
+  if (static_cast<int>(blockIdx.y) == my_rank) return;
+  const unsigned long long* __restrict__ block = all + static_cast<size_t>(blockIdx.y) * block_words;
+  const unsigned long long n = block[0] < capacity ? block[0] : capacity;
+  const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
+  if (i >= n) return;
+  atomicMin(&owner[block[2 + 2 * static_cast<size_t>(i)]], block[1 + 2 * static_cast<size_t>(i)]);
+}
+
+void launch_picky_offer(void* stream, const JobDesc* jobs_dev, const RefJobDesc* rjobs_dev, int n_jobs, uint32_t max_src_blocks, const int32_t* index,
+                        const float* dist2, const float* thr, unsigned long long* owner, unsigned long long* block, uint32_t capacity) {
+  hipLaunchKernelGGL(picky_offer_kernel, dim3(max_src_blocks, static_cast<uint32_t>(n_jobs)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
+                     jobs_dev, rjobs_dev, index, dist2, thr, owner, block, capacity);
+}
+void launch_picky_apply(void* stream, const unsigned long long* all, uint32_t block_words, int n_ranks, int my_rank, uint32_t capacity,
+                        unsigned long long* owner) {
+  if (!capacity || n_ranks < 2) return;
+  hipLaunchKernelGGL(picky_apply_kernel, dim3((capacity + kBlockThreads - 1) / kBlockThreads, static_cast<uint32_t>(n_ranks)), dim3(kBlockThreads), 0,
+                     static_cast<hipStream_t>(stream), all, block_words, my_rank, capacity, owner);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Rows of the pass result: [n x 29 sums][n overflow-excess flags][n thresholds][n overflow counts], n = jobs of the pass.
 __device__ __forceinline__ void write_pass_tail(double* sums, uint32_t n_jobs, uint32_t job, const float* thr,
                                                 uint32_t* overflow_count, uint32_t overflow_cap) {

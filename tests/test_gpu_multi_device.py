@@ -175,3 +175,43 @@ def test_failures_come_back_as_errors_not_hangs(multi):
     multi.set_targets([tgt])
     res = multi.align(np.eye(4)[None], pa.default_params(max_iterations=3))   # and the handle still works
     assert res.status[0] == 0 and res.iterations[0] == 3
+
+
+@pytest.mark.parametrize("upstream", [False, True], ids=["round1to3_form", "upstream_form"])
+def test_picky_offers_exchange_gives_the_table_reductions_bits(engine, upstream):
+    """Slab-sharded reference mode exchanges the picky dedupe either as the whole owner table (min-reduced: 8 B x level targets)
+    or as the ranks' OFFERED pairs (all-gathered and applied locally: 16 B x the model's level points) - whichever is fewer bytes.
+    A 9000-point model against a 70000-point scene takes the offers on every level; MI355_ICP_PICKY_OFFERS=0 forces the table.
+    Same owner table either way, hence the same bits; and the single engine's result to 1e-9."""
+    import os
+    import pose_estimation_amd as pa
+    flags = pa._lib.FLAG_UPSTREAM if upstream else 0
+    shift = (0.1, 0.0, 0.9)
+    src, tgt, gt = pair66(9000, 70000, shift=shift)
+    S = np.eye(4)
+    S[:3, 3] = shift
+    init = (st.rigid_transform(2.0, (0.2, 1, -0.4), (0.01, -0.02, 0.015)) @ gt)[None]
+    results = []
+    for knob in (None, "0"):
+        old = os.environ.get("MI355_ICP_PICKY_OFFERS")
+        if knob is not None:
+            os.environ["MI355_ICP_PICKY_OFFERS"] = knob
+        try:
+            eng = pa.IcpEngine(device_ids=[0, 0, 0])
+        finally:
+            if knob is not None:
+                if old is None:
+                    os.environ.pop("MI355_ICP_PICKY_OFFERS")
+                else:
+                    os.environ["MI355_ICP_PICKY_OFFERS"] = old
+        with eng:
+            eng.set_targets([tgt])
+            eng.set_sources([src])
+            results.append(eng.align_reference(init, 250, 0.005, 2.5, 8, flags=flags))
+    a, b = results
+    assert np.array_equal(a.passes, b.passes) and np.array_equal(a.poses.view(np.uint64), b.poses.view(np.uint64))
+    assert np.array_equal(np.asarray(a.residual).view(np.uint64), np.asarray(b.residual).view(np.uint64))
+    engine.set_targets([tgt])
+    engine.set_sources([src])
+    one = engine.align_reference(init, 250, 0.005, 2.5, 8, flags=flags)
+    assert a.passes[0] == one.passes[0] and np.linalg.norm(a.poses[0] - one.poses[0]) <= 1e-9
