@@ -298,9 +298,12 @@ def test_service_path_picks_the_faster_exact_scan_per_pass(capfd):
             capfd.readouterr()
             auto = eng.align_reference(inits, 250, 0.005, 2.5, 8, flags=flags)
             plans = [ln for ln in capfd.readouterr().err.splitlines() if ln.startswith("mi355_icp plan:")]
-            assert any(" pruned 1 " in ln for ln in plans) and any(" pruned 0 " in ln for ln in plans), plans
+            # (a forced MI355_ICP_SCAN_MODE / MI355_ICP_SERVICE_PRUNE - tools/gpu_check.sh - takes the choice away from the planner:
+            # then only the equality of the results is left to check)
+            free = not os.environ.get("MI355_ICP_SCAN_MODE") and not os.environ.get("MI355_ICP_SERVICE_PRUNE")
+            assert not free or (any(" pruned 1 " in ln for ln in plans) and any(" pruned 0 " in ln for ln in plans)), plans
             brute = eng.align_reference(inits, 250, 0.005, 2.5, 8, flags=flags | pa._lib.FLAG_BRUTE_SCAN)
-            assert not any(" pruned 1 " in ln for ln in capfd.readouterr().err.splitlines())
+            assert not free or not any(" pruned 1 " in ln for ln in capfd.readouterr().err.splitlines())
             pruned = eng.align_reference(inits, 250, 0.005, 2.5, 8, flags=flags | pa._lib.FLAG_PRUNED_SCAN)
             for other in (brute, pruned):
                 assert np.array_equal(auto.passes, other.passes)
@@ -311,4 +314,4 @@ def test_service_path_picks_the_faster_exact_scan_per_pass(capfd):
         eng.set_sources([src[:20_000].copy()])
         capfd.readouterr()
         eng.align_reference(inits, 250, 0.005, 2.5, 8, flags=pa._lib.FLAG_UPSTREAM)
-        assert not any(" pruned 1 " in ln for ln in capfd.readouterr().err.splitlines())
+        assert not free or not any(" pruned 1 " in ln for ln in capfd.readouterr().err.splitlines())
