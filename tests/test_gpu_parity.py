@@ -344,6 +344,17 @@ def test_config4_8m_vs_1m_eight_slabs_on_one_gpu(engine):
     assert res.status[0] == 0 and res.iterations[0] == o["iterations"] == 5
     assert np.linalg.norm(res.poses[0] - o["pose"]) <= POSE_TOL
     assert abs(res.residual[0] - o["residual"]) <= 1e-9
+    # ... and through ONE handle over eight device slots (mi355_icp_create_multi; all eight on this box's one GPU): the library
+    # cuts the 8M-point model into the same eight slabs itself and adds the slots' rows in slot order on the host - the same
+    # expression as the rank-ordered loop above, so the same pose to rounding of the last bit
+    with pa.IcpEngine(device_ids=[0] * world) as multi:
+        assert multi.comm_info() == (0, world, 3)
+        multi.set_targets([tgt])
+        multi.set_sources([src])
+        got = multi.align(np.eye(4)[None], params)
+    assert got.status[0] == 0 and got.iterations[0] == 5
+    assert np.linalg.norm(got.poses[0] - res.poses[0]) <= 1e-12
+    assert np.linalg.norm(got.poses[0] - o["pose"]) <= POSE_TOL
 
 
 def test_cpp_host_mirror_harness_matches_python_engine(engine):
