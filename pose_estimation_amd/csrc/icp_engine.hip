@@ -2337,7 +2337,9 @@ int mi355_icp_align_reference(mi355_icp_ctx* c, int n_jobs, const int* source_id
     // the selection histograms are left clear by every completed pass; make that true whatever an earlier call left behind
     // (sharded passes only: the single-GPU selection of jobs below 64k points keeps its histograms in LDS)
     // (once per call: within a call nothing but completed passes touches them)
-    if ((sharded || plan.out_total >= 65536u) && !select_cleared) {
+    uint32_t largest_job = 0;  // the many-workgroup selection (global histograms) starts at 64k points PER JOB (launch_rejection_select)
+    for (const JobDesc& J : plan.jobs) largest_job = std::max(largest_job, J.src_n);
+    if ((sharded || largest_job >= 65536u) && !select_cleared) {
       HIP_TRY(c, hipMemsetAsync(c->select_work, 0, c->ref_jobs_cap * (2048 + 4) * sizeof(uint32_t), c->stream));
       select_cleared = true;
     }
@@ -2757,7 +2759,11 @@ int mi355_icp_scene_fit_plane(mi355_icp_ctx* c, const mi355_plane_fit_params* fp
   launch_plane_hypotheses(c->stream, scene, n, fp->seed, n_hyp, c->plane_hyp, c->plane_counts);  // also clears the counters it will need
   launch_plane_support(c->stream, scene, n, c->plane_hyp, n_hyp, fp->distance_threshold, c->plane_counts);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(c->plane_host, c->plane_hyp, kHypBytes + kCountBytes, hipMemcpyDeviceToHost, c->stream));
+  // only the rows in use come back (100 hypotheses: 2 KB).  The whole block is 20.5 KB, which the runtime hands to a DMA engine
+  // instead of a copy kernel - and the first copy an engine sees costs its queue's creation (7-8 ms; which engine a copy gets depends
+  // on what is in flight, and a service met a new one in the middle of its SECOND request: profiles/r04t_second_request_stall.txt)
+  HIP_TRY(c, hipMemcpyAsync(c->plane_host, c->plane_hyp, static_cast<size_t>(n_hyp) * 4 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->plane_host + kHypBytes, c->plane_counts, static_cast<size_t>(n_hyp) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   int iterations = 0;
   const int best = plane_choose(counts, planes, n_hyp, n, fp->probability, &iterations);

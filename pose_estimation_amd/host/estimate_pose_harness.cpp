@@ -98,17 +98,22 @@ int main(int argc, char** argv) {
       // pose_estimation.cpp, opencv_surface_match.cpp:load_model); a request brings a new scene only
       eng.set_sources({mi355::CloudView{model.data(), n_model, 4 * model_cols}});
       // the request is run three times: the last pass shows the steady state of a service (buffers sized, code loaded)
-      for (int rep = 0; rep < 3; ++rep) {
+      const char* reps_env = std::getenv("MI355_HARNESS_PASSES");  // diagnostic: more repetitions of the request
+      const int reps = reps_env && std::atoi(reps_env) > 0 ? std::atoi(reps_env) : 3;
+      for (int rep = 0; rep < reps; ++rep) {
       for (int k = 0; k < n_cand; ++k) results[k]->updatePose(rotation_about(0.2, 1, -0.4, 1.0 + k, 0.01, -0.02, 0.015));
       const auto t0 = std::chrono::steady_clock::now();
       eng.scene_load(mi355::CloudView{raw.data(), raw.size() / 3, 12});
+      const auto ta = std::chrono::steady_clock::now();
       // create_surface_match_pc's chain (pose_estimation.cpp:248-258): NaN removal, then remove_planes(num_planes = 1):
       // RANSAC plane fit (:285-297) on the cleaned cloud, then the distance band around the FITTED plane (:310-333)
       mi355_scene_filter fin{};
       fin.kind = MI355_SCENE_FILTER_FINITE;
       eng.scene_filter({fin});
+      const auto tb = std::chrono::steady_clock::now();
       std::size_t plane_inliers = 0;
       const std::array<float, 4> plane = eng.scene_fit_plane(0.0001f, 100, &plane_inliers);
+      const auto tc = std::chrono::steady_clock::now();
       mi355_scene_filter band{};
       band.kind = MI355_SCENE_FILTER_PLANE_BAND_REMOVE;  // band 0.005 (pose_estimation.cpp:320)
       band.p[0] = plane[0]; band.p[1] = plane[1]; band.p[2] = plane[2]; band.p[3] = plane[3]; band.p[4] = 0.005f;
@@ -130,6 +135,8 @@ int main(int argc, char** argv) {
       std::printf("pipeline pass %d: %zu raw points -> %zu kept | upload+filters+plane fit %.3f ms, normals %.3f ms, commit %.3f ms, "
                   "ICP of %zu candidates %.3f ms, total %.3f ms\n",
                   rep, raw.size() / 3, kept, ms(t0, t1), ms(t1, t2), ms(t2, t3), subset.size(), ms(t3, t4), ms(t0, t4));
+      std::printf("  detail pass %d: load %.3f ms, NaN removal %.3f ms, plane fit %.3f ms, band removal %.3f ms\n", rep, ms(t0, ta), ms(ta, tb),
+                  ms(tb, tc), ms(tc, t1));
       }
       pose.assign(7, 0.f);
       mi355_icp_pose_to_pose7(results[best]->pose.data(), pose.data(), 1);
