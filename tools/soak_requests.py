@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak: thousands of requests with scenes of changing size through one engine - device memory must level off (the buffer
 pool reuses, nothing leaks), every request must succeed, and a repeated scene must give the same bits at the end as at the
-start.  python tools/soak_requests.py [requests]"""
+start.  python tools/soak_requests.py [requests] [device slots of the handle, default 1: a plain context; n > 1: mi355_icp_create_multi
+over n slots of device 0, requests sharded by candidate]"""
 import json
 import os
 import sys
@@ -25,6 +26,7 @@ def free_bytes():
 
 def main():
     n_req = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    slots = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(7)
     T = st.perturbation(-1)
     model = pa.synth_cloud(st.SOURCE_SEED, 20_000, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T)
@@ -32,7 +34,7 @@ def main():
     inits = np.stack([np.eye(4)] + [st.rigid_transform(k, (0.2, 1, -0.4), (0.01, -0.02, 0.015)) @ gt for k in (1.0, 2.0, 3.0, 4.0, 5.0)])
     big = pa.synth_cloud(st.TARGET_SEED, 130_000)
     mem, first, t0 = [], None, time.perf_counter()
-    with pa.IcpEngine(0) as eng:
+    with (pa.IcpEngine(0) if slots == 1 else pa.IcpEngine(device_ids=[0] * slots)) as eng:
         eng.set_sources([model])
         for r in range(n_req):
             n = 100_000 if r in (0, n_req - 1) else int(rng.integers(70_000, 130_000))
@@ -47,7 +49,7 @@ def main():
             if r % 250 == 0 or r == n_req - 1:
                 mem.append(free_bytes())
         same = np.array_equal(first.poses.view(np.uint64), res.poses.view(np.uint64)) and np.array_equal(first.passes, res.passes)
-    print(json.dumps({"requests": n_req, "seconds": time.perf_counter() - t0, "first_equals_last_bitwise": bool(same),
+    print(json.dumps({"requests": n_req, "device_slots": slots, "seconds": time.perf_counter() - t0, "first_equals_last_bitwise": bool(same),
                       "free_mib_every_250": [m >> 20 for m in mem],
                       "free_mib_spread_after_warmup": (max(mem[2:]) - min(mem[2:])) >> 20 if len(mem) > 3 else None}))
     assert same
