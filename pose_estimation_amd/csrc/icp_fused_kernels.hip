@@ -514,9 +514,13 @@ __global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xmfma_kernel(const J
 //   q'  = -2 qc (exact), split into bf16 pieces q'h + q'l, |q' - (q'h + q'l)| <= 2^-16 |q'| per coordinate
 //         (two round-to-nearest bf16 roundings: 2^-8 of 2^-8); qc' := -(q'h + q'l) / 2
 //   tc' = th + tl likewise (xtarget_kernels.hip), tt' = fl(|tc'|^2) from double, in three bf16 pieces t1 + t2 + t3
-//   slots 0-11: (th, th, tl, tl) x (q'h, q'l, q'h, q'l) per coordinate   = q'.tc' (every product is exact in float32)
+//   slots 0-11: (th, th, tl, 0) x (q'h, q'l, q'h, 0) per coordinate      = q'.tc' - sum tl q'l (every product is exact in float32)
 //   slots 12-14: (t1, t2, t3) x (1, 1, 1)                                = tt'     slot 15: 1 x b, a bias (see min16)
-//   s = fl(MFMA + fl(qq - b)),  qq = fl(|qc'|^2)      ~   S := |qc' - tc'|^2, the squared distance of the QUANTISED points.
+//   s = fl(MFMA + fl(qq - b)),  qq = fl(|qc'|^2)      ~   S := |qc' - tc'|^2, the squared distance of the QUANTISED points,
+//   short of the three LOW x LOW products.  Since round 4 their slots hold zero on both sides: this kernel runs at the clock the
+//   chip can hold under its load (1.95-2.05 GHz of 2.4), and what raises that clock is less energy per MFMA - zero operands in 3
+//   of the 16 slots bought 3.5-3.9 % of the launch (profiles/r04u_zero_slots_ab.txt; cdna_hip_programming.md rule 28), against
+//   term (h) below.  Zeroing more (the third piece of tt', every low piece of the source) gained nothing further.
 //
 // What the code needs is ONE inequality per granule:  exact contract minimum d^2 >= L := max((s_min - E) * 0.99902, 0),
 // which follows from  s <= (1 + 2^-10) d^2 + E  for every pair  (0.99902 < 1 / (1 + 2^-10)).  The terms of that
@@ -536,9 +540,13 @@ __global__ __launch_bounds__(kBlockThreads, 2) void nn_scan_xmfma_kernel(const J
 //       quantity <= T, i.e. 16 * 2u * T                                                                           =  65   u N
 //       (tools/probe_mfma_bf16.hip measures <= 4.2 u T for the whole sum on 2*10^6 cancelling contractions:
 //       profiles/r01n_probe_mfma_bf16.txt, re-run by tests/test_gpu_mfma_probe.py - 15x inside the model.)
-//   total (1 + e) * ((b) + (c)) + the rest                                                                       <  97   u N
-// E = 2^-16 N + 2^-120 = 256 u N: 2.6x the worst case.  (Round 1 shipped 2^-17 = 128 u N, which the model above
-// still fits, by 1.3x; the wider band costs ~3x the overflow points - a few hundred of 10^6 - and no scan time.)
+//   (h) the dropped low x low products: |tl| <= 2^-8 |tc| and |q'l| <= 2^-8 |q'| per coordinate (round to nearest), so
+//       |sum tl q'l| <= 2^-16 |tc| |q'| = 2^-16 * 2 |tc| |qc'| <= 2^-16 (1 + 2^-15) N                              = 256.1 u N
+//   total (1 + e) * ((b) + (c)) + the rest                                                                       < 353.1 u N
+// E = 1.75 * 2^-16 N + 2^-120 = 448 u N: 1.27x the worst case, of which the matrix unit's 65 u N are a model the probe sits
+// 15x inside and (h) is attained only by coordinates that all sit just above a power of two on both sides.  (Rounds 1-3
+// computed the low x low products and shipped 2^-17, then 2^-16 = 2.6x the worst case of that form; a band twice as wide costs
+// ~3x the overflow points - a few hundred of 10^6, 0.1 ms at 1M<->1M for 2^-15 - and no scan time.)
 // The absolute floor 2^-120 is for the matrix unit flushing subnormal operand pieces, products or sums (17 x 2^-126 at
 // most, plus 6 x 2^-126 (|q'| + r) for flushed low pieces, which the relative part covers once |qc| + r >= 2^-106):
 // squared distances that small make every granule a candidate and the all-exact scan answers.  A point whose E is not
@@ -789,12 +797,13 @@ __global__ __launch_bounds__(kThreads, 2) void nn_scan_xbf16_kernel(const JobDes
       split_bf16(q2y[m] + c2y, py, vy);
       split_bf16(q2z[m] + c2z, pz, vz);
       const float qq = 0.25f * __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));  // |qc'|^2 of the quantised point (x 1/4: exact)
-      ee[m] = __builtin_fmaf(1.52587890625e-05f, qq + tc.w, 7.5231638e-37f);  // E = 2^-16 (|qc'|^2 + r^2) + 2^-120
+      ee[m] = __builtin_fmaf(2.6702880859375e-05f, qq + tc.w, 7.5231638e-37f);  // E = 1.75 * 2^-16 (|qc'|^2 + r^2) + 2^-120
       unsafe[m] = unsafe[m] || !(ee[m] < 1.0e37f);                              // inf / NaN bound: exact scan instead
       const uint32_t bias = (__float_as_uint(__builtin_fmaf(2.0f, ee[m], qq)) + 0xFFFFu) >> 16;  // bf16, rounded up
       adj[m] = qq - bf16_value(bias);  // s = MFMA + adj
       const uint32_t w0 = hi ? pz : px;
-      bq[m] = make_uint4(w0, w0, hi ? 0x3F803F80u : py, hi ? (0x00003F80u | (bias << 16)) : py);
+      // the slot that would meet the target's low piece with the source's low piece holds zero on both sides (see "low x low" above)
+      bq[m] = make_uint4(w0, w0 & 0xFFFFu, hi ? 0x3F803F80u : py, hi ? (0x00003F80u | (bias << 16)) : (py & 0xFFFFu));
       rawthr[m] = raw_threshold(l3[m], adj[m], ee[m]);
     }
     }

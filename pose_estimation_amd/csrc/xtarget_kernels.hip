@@ -275,8 +275,9 @@ __global__ __launch_bounds__(kBlockThreads) void centre_kernel(uint32_t off, uin
       const uint32_t t2 = bf16_bits(rem1);
       const uint32_t t3 = bf16_bits(rem1 - bf16_value(t2));
       uint4* img = bf_image + static_cast<size_t>((off + t0) / kTile) * kXbTileVecs;
-      img[slot] = make_uint4(hx | (hx << 16), lx | (lx << 16), hy | (hy << 16), ly | (ly << 16));
-      img[kTile + slot] = make_uint4(hz | (hz << 16), lz | (lz << 16), t1 | (t2 << 16), t3 | 0x3F800000u);  // slot 15: 1.0 (bias row)
+      // slots 3, 7 and 11 (low piece x low piece) are zero: see nn_scan_xbf16_kernel
+      img[slot] = make_uint4(hx | (hx << 16), lx, hy | (hy << 16), ly);
+      img[kTile + slot] = make_uint4(hz | (hz << 16), lz, t1 | (t2 << 16), t3 | 0x3F800000u);  // slot 15: 1.0 (bias row)
     }
   }
 #pragma unroll

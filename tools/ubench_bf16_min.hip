@@ -82,7 +82,8 @@ __device__ __forceinline__ uint32_t fmin16(const f32x16& a, uint32_t seed_bits) 
 }
 
 template <int MODE>  // 0 M, 1 V2, 2 V3, 3 B2, 4 B3, 5 B3 with two values per MFMA through ds_min_u32; 6/7/8: MFMA + float minima (fmin16<0/1/2>); 9/10/11: those minima alone
-__global__ __launch_bounds__(256, 2) void k(float* out, int iters, const u32x4* in) {
+__global__ __launch_bounds__(256, 2) void k(float* out, int iters, const u32x4* in, long long* cyc = nullptr) {
+  const long long c0 = clock64();  // s_memtime: ticks at the shader clock (profiles/r01a_clock_probe.txt)
   f32x16 acc[4];
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -113,6 +114,26 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters, const u32x4* 
 #pragma unroll
   for (int m = 0; m < 4; ++m) s += acc[m][0] + acc[m][7] + __uint_as_float(cm[m]) + (MODE == 5 ? __uint_as_float(slots[m][threadIdx.x]) : 0.f);
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (cyc && threadIdx.x == 0) cyc[blockIdx.x] = clock64() - c0;
+}
+
+// the same loop in SHADER cycles (clock64 inside the kernel): what the wall-clock figures above are at the clock the chip
+// really holds under that load - the number the scan kernel's GRBM_GUI_ACTIVE / MFMA count compares with
+template <int MODE>
+double run_cycles(float* out, const u32x4* in, int grid, int iters, long long* cyc_dev, float* ms_out) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  k<MODE><<<grid, 256>>>(out, iters / 4, in, cyc_dev);
+  (void)hipEventRecord(e0);
+  k<MODE><<<grid, 256>>>(out, iters, in, cyc_dev);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  (void)hipEventElapsedTime(ms_out, e0, e1);
+  static long long h[4096];
+  (void)hipMemcpy(h, cyc_dev, sizeof(long long) * grid, hipMemcpyDeviceToHost);
+  double sum = 0;
+  for (int b = 0; b < grid; ++b) sum += static_cast<double>(h[b]);
+  return sum / grid;  // cycles one workgroup (= one wave per SIMD) spent on iters x 4 steps
 }
 
 template <int MODE>
@@ -148,6 +169,17 @@ int main() {
     const float f9 = run<9>(out, in, grid, iters), f10 = run<10>(out, in, grid, iters), f11 = run<11>(out, in, grid, iters);
     printf("              float minima (asm, no canonicalise): MFMA + 8 v_min3_f32 %.1f | MFMA + 16 v_min_f32 %.1f | MFMA + 8 v_minimum3_f32 %.1f || alone: %.1f | %.1f | %.1f\n",
            cyc(f6), cyc(f7), cyc(f8), cyc(f9), cyc(f10), cyc(f11));
+  }
+  long long* cyc_dev;
+  if (hipMalloc(&cyc_dev, sizeof(long long) * 4096) != hipSuccess) return 1;
+  for (int wps : {1, 2, 3, 4}) {
+    const int grid = 256 * wps;
+    float ms_v = 0, ms_b = 0;
+    const double cv = run_cycles<2>(out, in, grid, iters, cyc_dev, &ms_v), cb = run_cycles<4>(out, in, grid, iters, cyc_dev, &ms_b);
+    // a workgroup's wave shares its SIMD with wps - 1 others: steps per SIMD in that time = wps x its own
+    const double steps_wave = 4.0 * iters;
+    printf("waves/SIMD=%d  SHADER cycles per step per SIMD:  8 v_min3_u32 %.1f (clock %.2f GHz) | MFMA + 8 v_min3_u32 %.1f (clock %.2f GHz)\n", wps,
+           cv / steps_wave / wps, cv / (ms_v * 1e-3) * 1e-9, cb / steps_wave / wps, cb / (ms_b * 1e-3) * 1e-9);
   }
   return 0;
 }
