@@ -40,7 +40,8 @@ SCAN_MODELS = {
     "xbf16": ("nn_scan_xbf16_kernel (split-bf16 expansion filter on the matrix cores) + exact resolve", "mfma",
               BF16_MFMA_PEAK_TFLOPS, 32.0, 9.0 / 1024.0,
               "Every pair is evaluated by one K=16 bf16 MFMA contraction (32 flop per pair: the expansion surrogate of "
-              "points quantised to two bfloat16 pieces per coordinate) and one vector issue slot per 128 pairs per lane for "
+              "points quantised to two bfloat16 pieces per coordinate; the three low x low slots hold zeros - less energy per "
+              "MFMA, a higher clock: profiles/r04u_zero_slots_ab.txt) and one vector issue slot per 128 pairs per lane for "
               "the minimum (8 v_min3_u32 + the MFMA issue per 1024 pairs: the binding resource, see roofline_issue; a "
               "register-only loop of that mix takes 44.8 cycles per MFMA, the kernel 49.5 - and issues no MFMA whose result is dropped: "
               "profiles/r03s_pmc_summary.txt; round 2: 49.7 per issued, 51.3 per useful MFMA); "
@@ -487,7 +488,9 @@ def main():
                 "note": "arithmetic floor of the instruction mix: vector instructions per evaluated pair x 4 cycles per integer or "
                         "MFMA wave-instruction (float32: 2 with >= 2 waves per SIMD) at 2.4 GHz on 1024 SIMDs.  Measured on the "
                         "hardware the same mix costs more: 44.8 cycles per MFMA + 8 minima instead of 36 (tools/ubench_bf16_min.hip), "
-                        "and the chip holds 1.95-2.1 GHz under this load - against THAT loop the kernel runs at 91 % (DESIGN.md 3.1); "
+                        "and the chip holds 1.95-2.1 GHz under this load - against THAT loop the kernel runs at 91 % in cycles (DESIGN.md 3.1); "
+                        "the loop itself, on constant operands, holds 2.39 GHz (profiles/r04u_ubench_cycles.txt): what is left is clock, "
+                        "i.e. energy per MFMA; "
                         "`traffic` counts Infinity-Cache hits too (the 33.5 MB operand image re-streamed per workgroup round and XCD)",
             },
             "roofline_hbm": {

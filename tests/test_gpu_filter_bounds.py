@@ -117,3 +117,26 @@ def test_bound_on_random_geometry(engine):
             src = random_cloud(rng, ns)
             pose = st.rigid_transform(rng.uniform(0, 180), rng.standard_normal(3), rng.standard_normal(3))
         check(engine, src, tgt, pose)
+
+
+def test_bound_where_the_dropped_low_products_are_largest(engine):
+    """Term (h) of the filter's error budget (csrc/icp_fused_kernels.hip): the three low x low products the matrix-core
+    contraction leaves out are largest - 2^-16 (|tc|^2 + |qc|^2) - when every coordinate of both points sits exactly half-way
+    between two bfloat16 values just above a power of two (the low piece is then a full half ulp) and all low pieces agree in
+    sign.  One group of four tiles, mirrored so that its centre is exactly 0: coordinates 1 + a/256 with a = 1 (mod 4)
+    round DOWN to even (low piece +2^-8), sources from the same lattice (q' = -2 q: low piece -2^-7), so s overshoots the
+    squared distance of the quantised points by the whole term on every pair."""
+    a = 1.0 + (4.0 * np.arange(16) + 1.0) / 256.0
+    b = 1.0 + (4.0 * np.arange(8) + 1.0) / 256.0
+    pos = np.stack(np.meshgrid(a, a, b, indexing="ij"), axis=-1).reshape(-1, 3)
+    tgt = np.concatenate([pos, -pos]).astype(np.float32)                      # 4096 targets, box symmetric about 0
+    assert np.array_equal(tgt.astype(np.float64), np.concatenate([pos, -pos]))  # the lattice is exact in float32
+    rng = np.random.default_rng(11)
+    src = np.concatenate([pos[rng.permutation(len(pos))[:700]], -pos[rng.permutation(len(pos))[:324]]]).astype(np.float32)
+    lower, exact = check(engine, src, tgt, np.eye(4))
+    # not vacuous here either: away from the point's own lattice site (exact 0) the bound keeps most of the distance
+    far = exact > 1e-3
+    assert (lower[far] > 0.5 * exact[far]).mean() > 0.99
+    # the same lattice at the other scales of a float32's exponent the tests above use
+    for scale in (2.0 ** -20, 2.0 ** 12):
+        check(engine, src * np.float32(scale), tgt * np.float32(scale), np.eye(4))
