@@ -293,7 +293,7 @@ struct mi355_icp_ctx {
   bool call_auto_prune = false;      // this call (mi355_icp_align_reference without a scan flag) lets the planner take the exact pruned
                                      // scan for the passes where it is the faster way to the same bits (service_prune_pays)
   int service_prune = -1;            // MI355_ICP_SERVICE_PRUNE: -1 auto (default), 0 never, 1 every pass of such a call
-  int xbf16_shape = 0;               // 0: <4 sets, 256 threads> workgroups, 1: <2 sets, 512 threads>, 2: <4 sets, 512 threads> = 1024 points, one per CU (MI355_ICP_XBF16_SHAPE)
+  int xbf16_shape = 0;               // 0: <4 sets, 256 threads> workgroups, 1: <2 sets, 512 threads> (MI355_ICP_XBF16_SHAPE)
   uint32_t min_tiles_per_split = 2;  // planner: never cut the target finer than this many tiles per workgroup
   int resolve_wave_points = 0;       // MI355_ICP_RESOLVE_WAVE_POINTS=16|32|64: points per wave of the filter's resolve (0: by launch size)
   double filter_pairs = 2.5e8;        // launches from this many pairs on take the filter scan (MI355_ICP_FILTER_PAIRS: A/B)
@@ -646,7 +646,7 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   }
   if (plan.xfilter) plan.scan_ppl = c->scan_ppl ? c->scan_ppl : 4;
   if (plan.xfilter && plan.xkind && plan.scan_ppl != 2) plan.scan_ppl = 4;  // the MFMA kernel spans 128 * {4, 8} points
-  if (plan.xfilter && plan.xkind == 3) plan.scan_ppl = c->xbf16_shape == 2 ? 4 : 2;  // split-bf16 kernel: 512 points per workgroup (shape 2: 1024)
+  if (plan.xfilter && plan.xkind == 3) plan.scan_ppl = 2;                     // split-bf16 kernel: 512 points per workgroup
   // The matrix-core scan keeps, per lane, the three best granules of its point and takes a wave-uniform branch whenever
   // ANY of the wave's 32 points improves one.  In upload order those 32 points are anywhere on the model, each improving
   // at its own places of the (Morton-ordered) target walk: the branch is taken in most chunks.  Walking the sources in
@@ -693,7 +693,7 @@ int make_plan_on(mi355_icp_ctx* c, const std::vector<CloudEntry>& src_clouds, co
   // that draws groups of tiles from the block's ticket (nn_scan_xbf16_kernel, kXbLayoutQueue) - about two workgroups per slot over
   // the whole launch, never more members than a target has tile groups.
   bool queue_split = false;
-  if (plan.xfilter && plan.xkind == 3 && c->scan_queue && c->xbf16_shape == 0 && !c->target_blocks_mfma_forced && total_pairs < c->queue_pairs && total_src_blocks) {
+  if (plan.xfilter && plan.xkind == 3 && c->scan_queue && c->xbf16_shape != 1 && !c->target_blocks_mfma_forced && total_pairs < c->queue_pairs && total_src_blocks) {
     uint32_t groups = 0xFFFFFFFFu;
     for (int k = 0; k < n_jobs; ++k) groups = std::min(groups, (tgt_clouds[target_ids ? target_ids[k] : 0].padded / kTile + kXbCentreGroup - 1) / kXbCentreGroup);
     uint32_t members = c->queue_members ? c->queue_members : static_cast<uint32_t>((2ull * c->scan_slots + total_src_blocks - 1) / total_src_blocks);
@@ -1014,7 +1014,7 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
     Sscan = DevicePlanes{xs->planes + 4 * sstride, xs->planes + 5 * sstride, xs->planes + 6 * sstride};
     src_perm = xs->perm;
   }
-  const bool self_staged = staged && xf && bx && plan.xkind == 3 && c->xbf16_shape == 0;
+  const bool self_staged = staged && xf && bx && plan.xkind == 3 && c->xbf16_shape != 1;
   if (staged && !self_staged &&
       stage_jobs(c->stream, c->jobs_host, staged->has_ref ? c->rjobs_host : nullptr, n_active, c->jobs_dev, staged->has_ref ? c->rjobs_dev : nullptr) != MI355_ICP_OK)
     return fail(c, MI355_ICP_ERR_HIP, "staging the job descriptors failed");
@@ -1027,7 +1027,7 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
       // 3-D grid of the class-weighted layout (one-round launches; needs the self-staged kernel and every ACTIVE job to be one
       // of the plan's uniform batch) or of the ticket queue (any subset of the plan's jobs: a team is a source block of a job).
       int layout = kXbLayoutStatic;
-      if (plan.queued && c->xbf16_shape == 0) {
+      if (plan.queued && c->xbf16_shape != 1) {
         layout = kXbLayoutQueue;
         const size_t words = 2 * static_cast<size_t>(plan.grid3_x) * static_cast<size_t>(n_active);
         if (words > c->xb_queue_cap) {

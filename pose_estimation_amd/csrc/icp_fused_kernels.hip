@@ -998,7 +998,7 @@ void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uin
   hipStream_t st = static_cast<hipStream_t>(stream);
   const uint4* image = static_cast<const uint4*>(bf_image);
   const float4* table = static_cast<const float4*>(tile_table);
-  if (staged && shape == 0) {  // small passes: this launch stages the descriptors itself
+  if (staged && shape != 1) {  // small passes: this launch stages the descriptors itself
     auto go = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z, image, table, keys4, key_stride, rank_stride,
                          nullptr, 0u, *staged, jobs_out, rjobs_out, queue);
@@ -1008,17 +1008,13 @@ void launch_nn_scan_xbf16(void* stream, const JobDesc* jobs_dev, int n_jobs, uin
     else go(nn_scan_xbf16_kernel<4, 256, false, true, kXbLayoutStatic>);
     return;
   }
-  if (layout == kXbLayoutQueue && shape == 0) {
+  if (layout == kXbLayoutQueue && shape != 1) {
     hipLaunchKernelGGL((nn_scan_xbf16_kernel<4, 256, false, false, kXbLayoutQueue>), grid, dim3(kBlockThreads), 0, st, jobs_dev, src.x, src.y, src.z,
                        image, table, keys4, key_stride, rank_stride, nullptr, 0u, StageArgs{}, nullptr, nullptr, queue);
     return;
   }
   if (shape == 1)
     hipLaunchKernelGGL((nn_scan_xbf16_kernel<2, 512>), grid, dim3(512), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x, src.y,
-                       src.z, static_cast<const uint4*>(bf_image), static_cast<const float4*>(tile_table), keys4, key_stride,
-                       rank_stride);
-  else if (shape == 2)  // 8 waves x 4 source sets: 1024 points per workgroup, one workgroup per CU - half the tile traffic per pair
-    hipLaunchKernelGGL((nn_scan_xbf16_kernel<4, 512>), grid, dim3(512), 0, static_cast<hipStream_t>(stream), jobs_dev, src.x, src.y,
                        src.z, static_cast<const uint4*>(bf_image), static_cast<const float4*>(tile_table), keys4, key_stride,
                        rank_stride);
   else
