@@ -347,10 +347,11 @@ int sync_pass(mi355_icp_ctx* c) {
 // The same for a pass whose last workgroup publishes `seq` in pinned memory behind its results (PassTail): no copy command
 // to wait for, the word is there as soon as the rows are.
 uint32_t overflow_cap(const mi355_icp_ctx* c, int n_active);
+uint32_t pass_overflow_cap(const mi355_icp_ctx* c, const Plan& plan, int n_active, const float* target_planes);
 
 // The PassTail of the next pass, if its accumulation launch may end it (single GPU; every job has a workgroup to be its
 // last one; no more jobs than publish words); done / sums: the loop's own counter array and mapped result block.
-PassTail make_pass_tail(mi355_icp_ctx* c, const Plan& plan, int n_active, uint32_t sbx, bool allowed, bool defer, uint32_t* done, double* sums) {
+PassTail make_pass_tail(mi355_icp_ctx* c, const Plan& plan, int n_active, uint32_t sbx, bool allowed, bool defer, uint32_t* done, double* sums, const float* target_planes) {
   bool on = allowed && c->pass_tail && sbx > 0 && static_cast<size_t>(n_active) <= kReadyWords;
   for (int k = 0; k < n_active; ++k) on = on && c->jobs_host[k].src_blocks > 0;
   PassTail tail;
@@ -358,7 +359,7 @@ PassTail make_pass_tail(mi355_icp_ctx* c, const Plan& plan, int n_active, uint32
     tail.done = done;
     tail.sums = sums;
     tail.overflow_count = plan.fused ? c->overflow_count : nullptr;
-    tail.overflow_cap = defer ? overflow_cap(c, n_active) : 0xFFFFFFFFu;
+    tail.overflow_cap = defer ? pass_overflow_cap(c, plan, n_active, target_planes) : 0xFFFFFFFFu;
     c->pass_seq = (c->pass_seq + 1) & 0x7FFFFFFFu;
     tail.seq = c->pass_seq;
     tail.ready = c->ready_mapped;
@@ -984,6 +985,25 @@ uint32_t overflow_cap(const mi355_icp_ctx* c, int n_active) {
   return std::max<uint32_t>(kOverflowCap, n / 128u);
 }
 
+// the sorted copy (expansion filters) that was built from exactly these target planes - level 0 or a pyramid level - if any
+const XCopy* sorted_copy_of(const mi355_icp_ctx* c, const float* target_planes, size_t* stride) {
+  const XCopy* found = nullptr;
+  if (target_planes == c->targets.planes) { found = &c->targets.xt; if (stride) *stride = c->targets.stride; }
+  for (const LevelPlanes& lv : c->targets.levels)
+    if (target_planes == lv.planes) { found = &lv.xt; if (stride) *stride = lv.stride; }
+  return found;
+}
+
+// What a deferred pass tells its tail: how many listed points per job the device-side overflow pass settles.  With a sorted copy
+// of the targets that pass (overflow_tiles_kernel) strides over the WHOLE list of a job - there is nothing it leaves to the host,
+// so no count may send the pass round again.  (Until round 4 the cap of the other pass was applied here too: harmless while the
+// matrix-core filter listed 0.25 % of a cloud, a repeated 50 ms pass at 700k<->3M once the wider band listed 1.1 % -
+// profiles/r04w_overflow_cap.txt.)  Without a sorted copy (the fused filter) overflow_exact_kernel takes `overflow_cap` points.
+uint32_t pass_overflow_cap(const mi355_icp_ctx* c, const Plan& plan, int n_active, const float* target_planes) {
+  const XCopy* x = plan.xfilter ? sorted_copy_of(c, target_planes, nullptr) : nullptr;
+  return x && x->valid ? 0xFFFFFFFFu : overflow_cap(c, n_active);
+}
+
 // Fused-filter path up to "index and dist2 of every point are final": filter scan -> exact resolve of the candidate
 // chunks -> (rarely) the all-exact scan for points whose candidates overflowed the band.  Records ev[1] after the scan.
 // `defer`: the points the resolve could not settle are answered on the device (overflow_exact_kernel, up to kOverflowCap
@@ -995,11 +1015,8 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
                           DevicePlanes T, bool profile, bool defer, const StageArgs* staged = nullptr) {
   const uint32_t rank_stride = plan.key_rows() * plan.out_total;
   // the expansion-filter copy that was built from exactly these target planes (level 0 or a pyramid level), if any
-  const XCopy* Xp = nullptr;
   size_t xstride = 0;
-  if (T.x == c->targets.planes) { Xp = &c->targets.xt; xstride = c->targets.stride; }
-  for (const LevelPlanes& lv : c->targets.levels)
-    if (T.x == lv.planes) { Xp = &lv.xt; xstride = lv.stride; }
+  const XCopy* Xp = sorted_copy_of(c, T.x, &xstride);
   const bool xf = plan.xfilter && Xp && Xp->valid;
   const XCopy none;
   const XCopy& X = xf ? *Xp : none;
@@ -1092,7 +1109,7 @@ int run_fused_index_phase(mi355_icp_ctx* c, const Plan& plan, int n_active, uint
   if (defer) {  // the counts reach the host with the sums (final-reduce kernels), after the pass's one synchronisation
     if (sbx && xf) {  // a sorted copy with tile spheres exists: only the tiles a point can still reach (any target size)
       const float* xp = X.planes;
-      launch_overflow_tiles(c->stream, c->jobs_dev, n_active, overflow_cap(c, n_active), S, DevicePlanes{xp + 4 * xstride, xp + 5 * xstride, xp + 6 * xstride},
+      launch_overflow_tiles(c->stream, c->jobs_dev, n_active, S, DevicePlanes{xp + 4 * xstride, xp + 5 * xstride, xp + 6 * xstride},
                             X.perm, X.table, c->overflow_list, c->overflow_count, c->out_index, c->out_dist2, c->error_flag);
     } else if (sbx) {
       launch_overflow_exact(c->stream, c->jobs_dev, n_active, overflow_cap(c, n_active), S, T, c->overflow_list, c->overflow_count, c->out_index,
@@ -1178,7 +1195,7 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
   // an external transport (gloo in the tests; the in-process exchange of a multi-device handle) meets on the HOST anyway: the pass
   // may end itself and the rows are exchanged where finish_pass left them - no device-to-host-to-device round trip around the callback
   const bool host_exchange = exchange && c->comm.ext != nullptr;
-  const PassTail tail = make_pass_tail(c, plan, n_active, sbx, tail_allowed && (!exchange || host_exchange), defer, c->p2p_done, c->sums_mapped);
+  const PassTail tail = make_pass_tail(c, plan, n_active, sbx, tail_allowed && (!exchange || host_exchange), defer, c->p2p_done, c->sums_mapped, T.x);
   const bool tail_on = tail.done != nullptr;
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (plan.pruned) {
@@ -1203,7 +1220,7 @@ int run_pass_once(mi355_icp_ctx* c, const Plan& plan, int n_active, bool profile
   }
   // the pass result, sums_dev or (PassTail) sums_host directly: [n x 17 sums][n overflow-excess flags][n overflow counts]
   if (!tail_on) launch_final_reduce(c->stream, c->jobs_dev, n_active, c->partials, c->sums_dev, plan.fused ? c->overflow_count : nullptr,
-                                    defer ? overflow_cap(c, n_active) : 0xFFFFFFFFu);
+                                    defer ? pass_overflow_cap(c, plan, n_active, T.x) : 0xFFFFFFFFu);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
   HIP_TRY(c, hipGetLastError());
   const size_t n_sums = static_cast<size_t>(n_active) * MI355_ICP_NSUMS, n_act = static_cast<size_t>(n_active);
@@ -1565,7 +1582,7 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, const RefLevel& level,
   }
   // single GPU: the accumulate launch ends the pass by itself (PassTail)
   const bool host_exchange = sharded && c->comm.ext != nullptr;  // see run_pass_once
-  const PassTail tail = make_pass_tail(c, plan, n_active, sbx, !sharded || host_exchange, defer, c->pass_done, c->ref_sums_mapped);
+  const PassTail tail = make_pass_tail(c, plan, n_active, sbx, !sharded || host_exchange, defer, c->pass_done, c->ref_sums_mapped, T.x);
   const bool tail_on = tail.done != nullptr;
   if (sbx || sharded) {
     // Slab-sharded: targets are replicated, the owner of a target is the smallest key ANY rank offered.  Two exchanges give the
@@ -1600,7 +1617,7 @@ int run_ref_pass_once(mi355_icp_ctx* c, const Plan& plan, const RefLevel& level,
   }
   // the pass result, ref_sums_dev or (PassTail) ref_sums_host directly: [n x 29 sums][n overflow-excess flags][n thresholds][n overflow counts]
   if (!tail_on) launch_ref_final_reduce(c->stream, c->jobs_dev, n_active, c->ref_partials, c->ref_sums_dev, c->thr_dev, plan.fused ? c->overflow_count : nullptr,
-                                        defer ? overflow_cap(c, n_active) : 0xFFFFFFFFu);
+                                        defer ? pass_overflow_cap(c, plan, n_active, T.x) : 0xFFFFFFFFu);
   if (profile) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   HIP_TRY(c, hipGetLastError());
   const size_t n_sums = static_cast<size_t>(n_active) * kRefSums, n_act = static_cast<size_t>(n_active);

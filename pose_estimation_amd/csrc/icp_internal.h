@@ -411,7 +411,8 @@ constexpr uint32_t kOverflowCap = 1024;  // overflow points per job the device-s
 void launch_overflow_exact(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t cap, DevicePlanes src, DevicePlanes tgt,
                            const uint32_t* overflow_list, const uint32_t* overflow_count, int32_t* out_index, float* out_dist2,
                            uint32_t* error_flag);
-void launch_overflow_tiles(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t cap, DevicePlanes src, DevicePlanes sorted_tgt,
+// settles EVERY listed point of every job (its workgroups stride over the list): the pass behind it never needs the host
+void launch_overflow_tiles(void* stream, const JobDesc* jobs_dev, int n_jobs, DevicePlanes src, DevicePlanes sorted_tgt,
                            const uint32_t* tgt_perm, const void* tgt_table, const uint32_t* overflow_list, const uint32_t* overflow_count,
                            int32_t* out_index, float* out_dist2, uint32_t* error_flag);
 void launch_accumulate(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t max_src_blocks, DevicePlanes src,

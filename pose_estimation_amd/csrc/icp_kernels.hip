@@ -1468,11 +1468,12 @@ void launch_overflow_exact(void* stream, const JobDesc* jobs_dev, int n_jobs, ui
                      out_index, out_dist2, error_flag);
 }
 
-void launch_overflow_tiles(void* stream, const JobDesc* jobs_dev, int n_jobs, uint32_t cap, DevicePlanes src, DevicePlanes sorted_tgt,
+void launch_overflow_tiles(void* stream, const JobDesc* jobs_dev, int n_jobs, DevicePlanes src, DevicePlanes sorted_tgt,
                            const uint32_t* tgt_perm, const void* tgt_table, const uint32_t* overflow_list, const uint32_t* overflow_count,
                            int32_t* out_index, float* out_dist2, uint32_t* error_flag) {
-  // `cap` listed points per job are settled on the device (more: the host path); the job's workgroups stride over its list
-  const uint32_t per_job = std::min<uint32_t>(cap, std::max<uint32_t>(16u, std::min<uint32_t>(256u, 2048u / static_cast<uint32_t>(std::max(n_jobs, 1)))));
+  // every listed point of a job is settled here, however many: the job's workgroups stride over its list (two 1024-thread
+  // workgroups fit a CU; an empty list costs the launch and one count read per workgroup)
+  const uint32_t per_job = std::max<uint32_t>(16u, std::min<uint32_t>(512u, 2048u / static_cast<uint32_t>(std::max(n_jobs, 1))));
   hipLaunchKernelGGL(overflow_tiles_kernel, dim3(per_job, static_cast<uint32_t>(n_jobs)), dim3(kOverflowThreads), 0, static_cast<hipStream_t>(stream),
                      jobs_dev, src.x, src.y, src.z, sorted_tgt.x, sorted_tgt.y, sorted_tgt.z, tgt_perm, static_cast<const float4*>(tgt_table),
                      overflow_list, overflow_count, out_index, out_dist2, error_flag);

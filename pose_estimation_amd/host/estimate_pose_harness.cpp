@@ -8,7 +8,9 @@
 //     prints the 7-float pose and per-candidate results; "reference" selects Mode::Reference (scene with normals);
 //     "pipeline" starts from a raw camera-like frame (NaN dropouts + a table plane) and runs the whole
 //     create_surface_match_pc -> computeNormalsPC3d -> ICP chain on the device: NaN removal, plane band, k = 20
-//     normals, commit, reference-mode refine (pose_estimation.cpp:211-279, opencv_surface_match.cpp:57-94)
+//     normals, commit, reference-mode refine (pose_estimation.cpp:211-279, opencv_surface_match.cpp:57-94); the request is
+//     repeated three times (MI355_HARNESS_PASSES=n: n times) with one "pipeline pass" line and one "detail pass" line
+//     (per-call stamps of the scene preparation) each - the second request must already be as fast as the third
 #include <cmath>
 #include <chrono>
 #include <cstdio>

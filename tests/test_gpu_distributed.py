@@ -111,11 +111,13 @@ def _tie_cloud():
 
 
 def _retry_worker(rank, world, port, q):
-    """Rank 0 runs the matrix-core filter on a slab whose overflow exceeds what the device-side pass covers (-> the pass
-    must be repeated through the host path); rank 1 runs the all-exact scan on its slab and has nothing to repeat.  Both
-    must repeat it - the decision is taken on flags summed across ranks - or rank 0's second exchange never completes."""
+    """Rank 0 runs the fused filter (no sorted copy of the targets: its device-side overflow pass takes a bounded number of
+    points) on a slab whose overflow exceeds that (-> the pass must be repeated through the host path); rank 1 runs the
+    all-exact scan on its slab and has nothing to repeat.  Both must repeat it - the decision is taken on flags summed across
+    ranks - or rank 0's second exchange never completes.  (The expansion filters settle every listed point on the device since
+    round 4 - overflow_tiles_kernel strides over the whole list - and never ask for a repeat.)"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      MI355_ICP_SCAN_MODE="xbf16" if rank == 0 else "exact")
+                      MI355_ICP_SCAN_MODE="fused" if rank == 0 else "exact")
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist

@@ -33,23 +33,27 @@ def main():
     gt = np.linalg.inv(T)
     inits = np.stack([np.eye(4)] + [st.rigid_transform(k, (0.2, 1, -0.4), (0.01, -0.02, 0.015)) @ gt for k in (1.0, 2.0, 3.0, 4.0, 5.0)])
     big = pa.synth_cloud(st.TARGET_SEED, 130_000)
-    mem, first, t0 = [], None, time.perf_counter()
+    mem, first, t0, lat = [], None, time.perf_counter(), []
     with (pa.IcpEngine(0) if slots == 1 else pa.IcpEngine(device_ids=[0] * slots)) as eng:
         eng.set_sources([model])
         for r in range(n_req):
             n = 100_000 if r in (0, n_req - 1) else int(rng.integers(70_000, 130_000))
+            t_req = time.perf_counter()
             eng.scene_load(big[:n])
             eng.scene_filter([(pa._lib.SCENE_FILTER_FINITE, [])])
             eng.scene_normals(20, True, (0.0, 0.0, 0.0))
             eng.scene_commit_target()
             res = eng.align_reference(inits, 250, 0.005, 2.5, 8)
             assert (np.asarray(res.status) == 0).all(), r
+            lat.append((time.perf_counter() - t_req) * 1e3)
             if r == 0:
                 first = res
             if r % 250 == 0 or r == n_req - 1:
                 mem.append(free_bytes())
         same = np.array_equal(first.poses.view(np.uint64), res.poses.view(np.uint64)) and np.array_equal(first.passes, res.passes)
     print(json.dumps({"requests": n_req, "device_slots": slots, "seconds": time.perf_counter() - t0, "first_equals_last_bitwise": bool(same),
+                      "request_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)), "max": float(np.max(lat)),
+                                     "slowest_requests": [[int(i), round(float(lat[i]), 2)] for i in np.argsort(lat)[::-1][:8]]},
                       "free_mib_every_250": [m >> 20 for m in mem],
                       "free_mib_spread_after_warmup": (max(mem[2:]) - min(mem[2:])) >> 20 if len(mem) > 3 else None}))
     assert same
