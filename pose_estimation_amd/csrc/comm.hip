@@ -205,6 +205,14 @@ bool fill_stage_args(const JobDesc* jobs_host, const RefJobDesc* rjobs_host, int
   return true;
 }
 
+// one system-scope store behind everything that is on the stream: what sync_pass (icp_engine.hip) waits for
+__global__ void publish_word_kernel(uint32_t* word, uint32_t value) {
+  __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_publish_word(void* stream, uint32_t* mapped_word, uint32_t value) {
+  hipLaunchKernelGGL(publish_word_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), mapped_word, value);
+}
+
 int stage_jobs(void* stream, const JobDesc* jobs_host, const RefJobDesc* rjobs_host, int n, JobDesc* jobs_dev, RefJobDesc* rjobs_dev) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (n > 32) {  // large batches: plain copies from the pinned tables

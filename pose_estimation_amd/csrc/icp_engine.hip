@@ -219,6 +219,7 @@ struct mi355_icp_ctx {
   uint32_t* ready_host = nullptr;      // pinned, mapped: one word per job, where a pass publishes (sequence number << 1 | error bit)
   uint32_t* ready_mapped = nullptr;
   uint32_t pass_seq = 0;
+  uint32_t sync_seq = 0;               // sync_pass: the last value published to ready_host[kReadyWords]
   bool error_word_known = false;       // the last pass brought the call's error word along (PassTail::error_flag): no copy needed
   uint32_t max_sub_split = 32;        // finest cut of a tile for small all-exact launches (a divisor of the 32 chunks of a tile)
   uint32_t sub_split_wgs = 2048;      // ... cut finer only while the launch has fewer workgroups than this
@@ -331,16 +332,25 @@ int fail(mi355_icp_ctx* c, int code, const std::string& msg) {
 template <typename T>
 int grow(mi355_icp_ctx* c, T*& ptr, size_t& cap, size_t need);
 
-// The one synchronisation of a pass.  A blocking hipStreamSynchronize sleeps on an interrupt and wakes tens of microseconds
-// after the copy has landed - as long as a whole pass on a coarse pyramid level.  Poll the stream for a bounded while
-// first (a short pass ends within it), then block like before (long scans: no core is burnt waiting for them).
+// The one synchronisation of a pass that does not end itself (PassTail): a one-thread launch behind everything on the stream
+// stores a sequence number to a word of pinned memory, and the host polls THAT for a bounded while (a short pass ends within it)
+// before it blocks in hipStreamSynchronize (long scans: no core is burnt waiting for them; a faulted launch: the error comes out
+// there).  Rounds 2-3 polled with hipStreamQuery instead.  On this runtime a query hands the stream's completion to the
+// runtime's signal-handler thread, and a hipStreamSynchronize behind it then waits for that thread: 24 ms after a 2.6 ms pass
+// on the boxes of round 4 (profiles/r04w_sync_pass.txt) - every mi355_icp_correspond of a large cloud and every pass of the
+// rank-per-process loop paid it.  A synchronise that no query preceded polls the signal itself and returns within microseconds.
 int sync_pass(mi355_icp_ctx* c) {
-  for (int spin = 0; spin < 2000; ++spin) {
-    const hipError_t e = hipStreamQuery(c->stream);
-    if (e == hipSuccess) return MI355_ICP_OK;
-    if (e != hipErrorNotReady) return fail(c, MI355_ICP_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+  c->sync_seq = c->sync_seq == 0xFFFFFFFFu ? 1u : c->sync_seq + 1u;  // never the word's initial 0
+  uint32_t* const word = c->ready_host + kReadyWords;                  // the word behind the PassTail's
+  launch_publish_word(c->stream, c->ready_mapped + kReadyWords, c->sync_seq);
+  HIP_TRY(c, hipGetLastError());
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spin = 1;; ++spin) {
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == c->sync_seq) return MI355_ICP_OK;
+    if ((spin & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1500)) break;
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != c->sync_seq) return fail(c, MI355_ICP_ERR_INTERNAL, "a pass ended without publishing its sequence number");
   return MI355_ICP_OK;
 }
 
@@ -1902,9 +1912,9 @@ int mi355_icp_create(int device_id, mi355_icp_ctx** out) {
   if ((e = hipMalloc(reinterpret_cast<void**>(&c->error_flag), sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(c->error_flag, 0, sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->flag_host), sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
-  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->ready_host), kReadyWords * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->ready_host), (kReadyWords + 1) * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
   if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->ready_mapped), c->ready_host, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
-  std::memset(c->ready_host, 0, kReadyWords * sizeof(uint32_t));
+  std::memset(c->ready_host, 0, (kReadyWords + 1) * sizeof(uint32_t));  // [kReadyWords]: sync_pass's word
   if (const char* v = std::getenv("MI355_ICP_PASS_TAIL")) c->pass_tail = std::atoi(v) != 0;
   if (const char* v = std::getenv("MI355_ICP_PICKY_OFFERS")) c->picky_offers = std::atoi(v) != 0;
   if (const char* v = std::getenv("MI355_ICP_SERVICE_PRUNE")) c->service_prune = std::string(v) == "auto" ? -1 : (std::atoi(v) != 0 ? 1 : 0);

@@ -550,6 +550,8 @@ int comm_allgather_host(CommState& cs, const void* send, void* recv, size_t byte
 void comm_release(CommState& cs);  // frees the staging buffers and destroys a native communicator
 // this pass's job descriptors (and reference-mode descriptors, or nullptr) to the device tables, asynchronously on `stream`
 int stage_jobs(void* stream, const JobDesc* jobs_host, const RefJobDesc* rjobs_host, int n, JobDesc* jobs_dev, RefJobDesc* rjobs_dev);
+// a one-thread launch that stores `value` (system scope) to a word of pinned, device-mapped memory once everything before it on the stream is done
+void launch_publish_word(void* stream, uint32_t* mapped_word, uint32_t value);
 // the same descriptors as one StageArgs value, for a launch that stages them itself (launch_nn_scan); false: more than 8 jobs
 bool fill_stage_args(const JobDesc* jobs_host, const RefJobDesc* rjobs_host, int n, StageArgs* out);
 

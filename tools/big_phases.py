@@ -16,6 +16,7 @@ import synth_twin as st  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--ns", type=int, default=700_000)
 ap.add_argument("--nt", type=int, default=3_000_000)
+ap.add_argument("--no-profile", action="store_true", help="wall time only (the engine records no events)")
 ap.add_argument("modes", nargs="*", default=["xbf16", "pruned"])
 a = ap.parse_args()
 tgt = pa.synth_cloud(st.TARGET_SEED, a.nt)
@@ -26,7 +27,8 @@ for mode in a.modes:
         e.set_targets([tgt])
         e.set_sources([src])
         e.correspond(np.eye(4)[None])
-        e.set_profiling(True)
+        if not a.no_profile:
+            e.set_profiling(True)
         e.reset_profile()
         t0 = time.perf_counter()
         e.correspond(np.eye(4)[None])
