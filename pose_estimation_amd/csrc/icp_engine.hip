@@ -220,6 +220,7 @@ struct mi355_icp_ctx {
   uint32_t* ready_mapped = nullptr;
   uint32_t pass_seq = 0;
   uint32_t sync_seq = 0;               // sync_pass: the last value published to ready_host[kReadyWords]
+  unsigned char* stage_host = nullptr;  // pinned, two halves of kStageHalf bytes: results travel through it to the caller's memory (copy_to_user)
   bool error_word_known = false;       // the last pass brought the call's error word along (PassTail::error_flag): no copy needed
   uint32_t max_sub_split = 32;        // finest cut of a tile for small all-exact launches (a divisor of the 32 chunks of a tile)
   uint32_t sub_split_wgs = 2048;      // ... cut finer only while the launch has fewer workgroups than this
@@ -351,6 +352,29 @@ int sync_pass(mi355_icp_ctx* c) {
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != c->sync_seq) return fail(c, MI355_ICP_ERR_INTERNAL, "a pass ended without publishing its sequence number");
+  return MI355_ICP_OK;
+}
+
+// Device memory -> the caller's buffer, through the context's own pinned block.  A blocking hipMemcpy into pageable memory
+// makes the runtime pin the caller's pages for the copy: into a buffer nobody has touched yet (a fresh std::vector, numpy.empty)
+// that cost 14 ms per 2.8 MB copy on the boxes of round 4 - mi355_icp_correspond of 700k points took 30 ms for 2.7 ms of kernels
+// (profiles/r04x_result_copies.txt).  Here the device writes into memory that is pinned once, and the host copies from there
+// while the next piece is in flight.
+constexpr size_t kStageHalf = size_t(4) << 20;
+int copy_to_user(mi355_icp_ctx* c, void* dst, const void* src_dev, size_t bytes) {
+  if (!bytes) return MI355_ICP_OK;
+  if (!c->stage_host) HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->stage_host), 2 * kStageHalf, hipHostMallocDefault));
+  const unsigned char* src = static_cast<const unsigned char*>(src_dev);
+  unsigned char* out = static_cast<unsigned char*>(dst);
+  const size_t pieces = (bytes + kStageHalf - 1) / kStageHalf;
+  auto piece_bytes = [&](size_t k) { return std::min(kStageHalf, bytes - k * kStageHalf); };
+  HIP_TRY(c, hipMemcpyAsync(c->stage_host, src, piece_bytes(0), hipMemcpyDeviceToHost, c->stream));
+  for (size_t k = 0; k < pieces; ++k) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // piece k has landed in half k & 1
+    if (k + 1 < pieces)
+      HIP_TRY(c, hipMemcpyAsync(c->stage_host + ((k + 1) & 1) * kStageHalf, src + (k + 1) * kStageHalf, piece_bytes(k + 1), hipMemcpyDeviceToHost, c->stream));
+    std::memcpy(out + k * kStageHalf, c->stage_host + (k & 1) * kStageHalf, piece_bytes(k));
+  }
   return MI355_ICP_OK;
 }
 
@@ -1990,6 +2014,7 @@ void mi355_icp_destroy(mi355_icp_ctx* c) {
   if (c->pass_done) (void)hipFree(c->pass_done);
   if (c->p2p_done) (void)hipFree(c->p2p_done);
   if (c->ready_host) (void)hipHostFree(c->ready_host);
+  if (c->stage_host) (void)hipHostFree(c->stage_host);
   if (c->thr_host) (void)hipHostFree(c->thr_host);
   (void)hipFree(c->keys);
   (void)hipFree(c->out_index);
@@ -2110,8 +2135,9 @@ int mi355_icp_correspond(mi355_icp_ctx* c, int n_jobs, const int* source_ids, co
   for (int k = 0; k < n_jobs; ++k) {
     const JobDesc& J = plan.jobs[static_cast<size_t>(k)];
     if (J.src_n) {
-      if (out_index) HIP_TRY(c, hipMemcpy(out_index + cursor, c->out_index + J.out_off, J.src_n * sizeof(int32_t), hipMemcpyDeviceToHost));
-      if (out_dist2) HIP_TRY(c, hipMemcpy(out_dist2 + cursor, c->out_dist2 + J.out_off, J.src_n * sizeof(float), hipMemcpyDeviceToHost));
+      int cst = MI355_ICP_OK;
+      if (out_index && (cst = copy_to_user(c, out_index + cursor, c->out_index + J.out_off, J.src_n * sizeof(int32_t))) != MI355_ICP_OK) return cst;
+      if (out_dist2 && (cst = copy_to_user(c, out_dist2 + cursor, c->out_dist2 + J.out_off, J.src_n * sizeof(float))) != MI355_ICP_OK) return cst;
     }
     cursor += J.src_n;
   }
@@ -2518,9 +2544,10 @@ int mi355_icp_reference_pass_ex(mi355_icp_ctx* c, int source_id, int target_id, 
   // ordered before these copies only by the end of the kernel: wait for it.
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (J.src_n) {
-    if (out_index) HIP_TRY(c, hipMemcpy(out_index, c->out_index + J.out_off, J.src_n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (out_dist2) HIP_TRY(c, hipMemcpy(out_dist2, c->out_dist2 + J.out_off, J.src_n * sizeof(float), hipMemcpyDeviceToHost));
-    if (out_selected) HIP_TRY(c, hipMemcpy(out_selected, c->selected + J.out_off, J.src_n * sizeof(uint8_t), hipMemcpyDeviceToHost));
+    int cst = MI355_ICP_OK;
+    if (out_index && (cst = copy_to_user(c, out_index, c->out_index + J.out_off, J.src_n * sizeof(int32_t))) != MI355_ICP_OK) return cst;
+    if (out_dist2 && (cst = copy_to_user(c, out_dist2, c->out_dist2 + J.out_off, J.src_n * sizeof(float))) != MI355_ICP_OK) return cst;
+    if (out_selected && (cst = copy_to_user(c, out_selected, c->selected + J.out_off, J.src_n * sizeof(uint8_t))) != MI355_ICP_OK) return cst;
   }
   return check_error_flag(c);
 }
@@ -2648,7 +2675,8 @@ int mi355_icp_scene_download(mi355_icp_ctx* c, float* out_xyz, size_t capacity_p
   if (!out_xyz) return MI355_ICP_OK;
   if (capacity_points < c->scene_n) return fail(c, MI355_ICP_ERR_INVALID_ARGUMENT, "scene_download: buffer too small");
   HIP_TRY(c, hipSetDevice(c->device));
-  if (c->scene_n) HIP_TRY(c, hipMemcpy(out_xyz, c->scene[c->scene_cur], static_cast<size_t>(c->scene_n) * 12, hipMemcpyDeviceToHost));
+  if (c->scene_n)
+    if (const int cst = copy_to_user(c, out_xyz, c->scene[c->scene_cur], static_cast<size_t>(c->scene_n) * 12); cst != MI355_ICP_OK) return cst;
   return MI355_ICP_OK;
 }
 
@@ -2738,8 +2766,10 @@ int mi355_icp_scene_normals(mi355_icp_ctx* c, int k, int flip_viewpoint, const f
   }
   c->scene_normals_valid = true;
   c->scene_normals_padded = padded;
-  if (out_normals) HIP_TRY(c, hipMemcpy(out_normals, c->scene_normals_aos, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost));
-  if (out_neighbors) HIP_TRY(c, hipMemcpy(out_neighbors, c->knn_out, static_cast<size_t>(n) * k_eff * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (out_normals)
+    if (const int cst = copy_to_user(c, out_normals, c->scene_normals_aos, static_cast<size_t>(n) * 12); cst != MI355_ICP_OK) return cst;
+  if (out_neighbors)
+    if (const int cst = copy_to_user(c, out_neighbors, c->knn_out, static_cast<size_t>(n) * k_eff * sizeof(int32_t)); cst != MI355_ICP_OK) return cst;
   return MI355_ICP_OK;
 }
 

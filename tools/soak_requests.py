@@ -2,7 +2,7 @@
 """Soak: thousands of requests with scenes of changing size through one engine - device memory must level off (the buffer
 pool reuses, nothing leaks), every request must succeed, and a repeated scene must give the same bits at the end as at the
 start.  python tools/soak_requests.py [requests] [device slots of the handle, default 1: a plain context; n > 1: mi355_icp_create_multi
-over n slots of device 0, requests sharded by candidate]"""
+over n slots of device 0, requests sharded by candidate] [idle ms before each request, default 0: back to back]"""
 import json
 import os
 import sys
@@ -27,6 +27,7 @@ def free_bytes():
 def main():
     n_req = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     slots = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    idle_ms = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0   # the device left idle this long before every request (a camera's frame period)
     rng = np.random.default_rng(7)
     T = st.perturbation(-1)
     model = pa.synth_cloud(st.SOURCE_SEED, 20_000, noise_seed=st.NOISE_SEED, sigma=st.SIGMA, transform=T)
@@ -38,6 +39,8 @@ def main():
         eng.set_sources([model])
         for r in range(n_req):
             n = 100_000 if r in (0, n_req - 1) else int(rng.integers(70_000, 130_000))
+            if idle_ms > 0:
+                time.sleep(idle_ms * 1e-3)
             t_req = time.perf_counter()
             eng.scene_load(big[:n])
             eng.scene_filter([(pa._lib.SCENE_FILTER_FINITE, [])])
@@ -51,7 +54,7 @@ def main():
             if r % 250 == 0 or r == n_req - 1:
                 mem.append(free_bytes())
         same = np.array_equal(first.poses.view(np.uint64), res.poses.view(np.uint64)) and np.array_equal(first.passes, res.passes)
-    print(json.dumps({"requests": n_req, "device_slots": slots, "seconds": time.perf_counter() - t0, "first_equals_last_bitwise": bool(same),
+    print(json.dumps({"requests": n_req, "device_slots": slots, "idle_ms_before_each_request": idle_ms, "seconds": time.perf_counter() - t0, "first_equals_last_bitwise": bool(same),
                       "request_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)), "max": float(np.max(lat)),
                                      "slowest_requests": [[int(i), round(float(lat[i]), 2)] for i in np.argsort(lat)[::-1][:8]]},
                       "free_mib_every_250": [m >> 20 for m in mem],
