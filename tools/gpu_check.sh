@@ -34,7 +34,7 @@ MI355_ICP_KNN_MODE=brute step 600 pytest_gpu_knn_brute.txt python -m pytest test
 MI355_ICP_LEVEL_SORT=1 MI355_ICP_PASS_TAIL=0 MI355_ICP_SOLVE_ISA=scalar step 600 pytest_gpu_plain_passes.txt python -m pytest tests/test_gpu_reference_mode.py tests/test_gpu_normals.py tests/test_gpu_parity.py -m gpu -x -q
 # round-3 planner knobs: odd cuts of the target (a chip of 48 or 200 resident workgroups makes the split model pick 3, 5, 7, 11 ...
 # runs of tiles; the split model off; every tile of a small launch in 32 runs, or whole), and each wave blocking of the filter's resolve
-FORCED="tests/test_gpu_fused_filter.py tests/test_gpu_parity.py tests/test_gpu_filter_bounds.py tests/test_gpu_reference_mode.py tests/test_gpu_reference_random.py tests/test_gpu_upstream_variant.py tests/test_gpu_multi_device.py"
+FORCED="tests/test_gpu_fused_filter.py tests/test_gpu_parity.py tests/test_gpu_filter_bounds.py tests/test_gpu_reference_mode.py tests/test_gpu_reference_random.py tests/test_gpu_upstream_variant.py tests/test_gpu_multi_device.py tests/test_gpu_state_fuzz.py"
 MI355_ICP_SCAN_SLOTS=48 step 600 pytest_gpu_slots48.txt python -m pytest $FORCED -m gpu -x -q
 MI355_ICP_SCAN_SLOTS=200 MI355_ICP_RESOLVE_WAVE_POINTS=32 step 600 pytest_gpu_slots200.txt python -m pytest $FORCED -m gpu -x -q
 MI355_ICP_SPLIT_MODEL=0 MI355_ICP_RESOLVE_WAVE_POINTS=64 MI355_ICP_MAX_SUB_SPLIT=1 step 600 pytest_gpu_model0.txt python -m pytest $FORCED -m gpu -x -q
